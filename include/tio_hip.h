@@ -1,0 +1,214 @@
+/*
+ * tio_hip.h — C ABI of the MI355X (gfx950) 3-D augmentation engine.
+ *
+ * This is the drop-in boundary.  The reference (TorchIO 2.0.0a2)
+ * has no FFI of its own: its transforms call torch.nn.functional directly.  Each
+ * entry point below replaces one of the reference's private functional seams;
+ * the file:line next to it is the reference code whose arithmetic it reproduces.
+ *
+ * Conventions
+ *   - every pointer named *_dev (and x / y / in / out) is DEVICE memory unless
+ *     the comment says HOST; nothing here allocates, frees or synchronises;
+ *   - tensors are dense row-major (B, C, I, J, K) — K fastest — exactly the
+ *     layout of ImagesBatch.data (reference src/torchio/data/batch.py:21-50);
+ *   - inputs are borrowed, outputs must not alias inputs;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns TIO_OK (0) or a negative tio_status; the failing
+ *     call's message is available through tio_last_error() (thread-local);
+ *   - re-entrant: no global mutable state besides the thread-local error text
+ *     (the reference calls transforms from Queue worker threads,
+ *     src/torchio/data/queue.py:119-123).
+ *
+ * The CPU restatement in oracle/ exports the same functions with the prefix
+ * tio_oracle_ and HOST pointers (stream ignored); it is test infrastructure.
+ */
+#ifndef TIO_HIP_H
+#define TIO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIO_ABI_VERSION 1
+#define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
+
+typedef enum tio_status {
+  TIO_OK = 0,
+  TIO_ERR_INVALID_ARGUMENT = -1,
+  TIO_ERR_UNSUPPORTED_DTYPE = -2,
+  TIO_ERR_LAUNCH = -3,
+  TIO_ERR_NO_DEVICE = -4
+} tio_status;
+
+/* Element types of image tensors (torch dtype ↔ code is fixed here). */
+typedef enum tio_dtype {
+  TIO_F32 = 0,
+  TIO_F64 = 1,
+  TIO_F16 = 2,
+  TIO_BF16 = 3,
+  TIO_U8 = 4,
+  TIO_I8 = 5,
+  TIO_I16 = 6,
+  TIO_I32 = 7,
+  TIO_I64 = 8
+} tio_dtype;
+
+typedef enum tio_interp {
+  TIO_NEAREST = 0, /* grid_sample(mode="nearest"): nearbyint, half-to-even      */
+  TIO_LINEAR = 1   /* grid_sample(mode="bilinear"): 8-tap trilinear, zero pad   */
+} tio_interp;
+
+/* ------------------------------------------------------------------------ */
+/* Fused spatial resampling                                                  */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * Geometry shared by every image of one resampling launch.  Replaces the
+ * materialised (I,J,K,3) sampling grid of the reference:
+ *   _build_sampling_grid            spatial.py:1504-1579
+ *   _output_voxel_coordinates       spatial.py:1604-1613
+ *   _apply_voxel_mapping            spatial.py:1616-1624   ([c,1] @ M^T, float32)
+ *   _upsample_displacement_field    spatial.py:2171-2189   (trilinear, align_corners)
+ *   _voxel_coordinates_to_grid      spatial.py:1627-1648   (g = 2 v / max(S-1,1) - 1)
+ *   ATen grid_sampler un-normalise  ((g + 1) / 2) * (S - 1)
+ *   per-instance variant            spatial.py:1881-1918   (B matrices / fields, no
+ *                                                           (B,I,J,K,3) stack)
+ */
+typedef struct tio_resample_geom {
+  int32_t batch;        /* B                                                     */
+  int32_t in_shape[3];  /* input  (I, J, K)                                      */
+  int32_t out_shape[3]; /* output (I, J, K)                                      */
+  int32_t affine_first; /* 1: v = M c + d / in_spacing ; 0: v = M (c + d / out_spacing) */
+  /* Output-voxel → input-voxel mapping, float32 rows [m00 m01 m02 m03 | m10 ...]
+   * (the first three rows of spatial.py:1582-1601's matrix, already cast to f32).
+   * mapping_batched = 0: one 3x4 shared by the batch; 1: B matrices.            */
+  const float* mapping_dev;
+  int32_t mapping_batched;
+  /* Elastic control points in mm, (n, ni, nj, nk, 3) float32, n = B if
+   * cp_batched else 1; NULL = no elastic component.                            */
+  const float* control_points_dev;
+  int32_t cp_batched;
+  int32_t cp_shape[3];
+  /* Optional per-element flags (B bytes each, NULL = all zero):
+   *   cp_skip[b]     != 0 → element b has no elastic component
+   *                         (control_points None, spatial.py:1542-1543);
+   *   passthrough[b] != 0 → element b is copied bit-exactly (gated-out rows,
+   *                         spatial.py:1078-1107); needs in_shape == out_shape. */
+  const uint8_t* cp_skip_dev;
+  const uint8_t* passthrough_dev;
+  float in_spacing[3];  /* AffineMatrix.spacing of the input grid, as float32    */
+  float out_spacing[3]; /* ... of the output grid                                */
+} tio_resample_geom;
+
+/* One image tensor resampled with the shared geometry
+ * (_resample_image_batch, spatial.py:1194-1272; _sample_batch_grid_sample,
+ * spatial.py:1695-1731). */
+typedef struct tio_resample_image {
+  const void* in;       /* (B, C, I, J, K)                                       */
+  void* out;            /* (B, C, Io, Jo, Ko), same dtype                        */
+  int32_t channels;     /* C                                                     */
+  int32_t dtype;        /* tio_dtype; computed in float32, cast back like
+                           `.float()` / `.to(data.dtype)` (spatial.py:1708,1731) */
+  int32_t interp;       /* tio_interp                                            */
+  /* Per-channel fill (C floats, device).  NULL = reference's "fill is scalar 0"
+   * branch (no mask step, spatial.py:2075-2076).  Non-NULL = trilinear in-bounds
+   * weight mask, out = mask > 0.5 ? sampled : fill[c]  (spatial.py:1719-1728).  */
+  const float* fill_dev;
+} tio_resample_image;
+
+/* Resample n_images image tensors through ONE coordinate computation. */
+int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
+                   const tio_resample_image* images, void* stream);
+
+/* Per-channel minimum of the FIRST batch element, kept on the device (the
+ * reference's default_pad_value="minimum": spatial.py:2054-2060,2094-2095 —
+ * there a host .item() per channel; here out_dev[c] feeds fill_dev directly).
+ * x is (B, C, n_spatial); out_dev receives C floats. */
+int tio_channel_min(const void* x, int32_t dtype, int32_t channels,
+                    int64_t n_spatial, float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Intensity path                                                            */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * Separable 3-axis cross-correlation with replicate padding — the stencil under
+ * Blur (blur.py:157-252: F.pad(mode="replicate") + F.conv3d per axis, order
+ * I, J, K) and the antialias filter (spatial.py:1980-2031).
+ *   taps_dev: (n, 3, tap_stride) float32, n = B if taps_batched else 1; for
+ *             axis a the 2*radius[a]+1 centred taps start at offset 0 (already
+ *             normalised / zero-extended / delta for sigma = 0 exactly as
+ *             blur.py:179-183 and blur.py:292-328 build them);
+ *   radius:   HOST int32[3]; radius[a] = 0 skips axis a (sigma <= 0, blur.py:177);
+ *   skip_dev: optional B bytes; non-zero rows are copied bit-exactly
+ *             (blur.py:249-251).
+ *   tmp:      scratch with the size of y (may be NULL when at most one axis is
+ *             active).
+ * Computes in float32 (blur.py:173 `.float()`), stores dtype (blur.py:204).
+ */
+int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t dtype,
+                         int32_t batch, int32_t channels, const int32_t shape[3],
+                         const float* taps_dev, int32_t taps_batched,
+                         int32_t tap_stride, const int32_t radius[3],
+                         const uint8_t* skip_dev, void* stream);
+
+/*
+ * BiasField: y = x * exp(trilinear_upsample(coarse))   (or x / ... when divide)
+ *   bias_field.py:296-341 (_generate_bias_field), :201-255 (_apply_bias_per_element),
+ *   :130 / :196 (multiply / divide).  coarse_dev is (B, C, si, sj, sk) float32 —
+ *   the seeded CPU-generator draw of bias_field.py:321-330 stays on the host
+ *   side of this boundary.  skip_dev: optional B bytes, rows copied bit-exactly
+ *   (std == 0 rows, bias_field.py:247-253).
+ */
+int tio_bias_field_apply(const void* x, void* y, int32_t dtype, int32_t batch,
+                         int32_t channels, const int32_t shape[3],
+                         const float* coarse_dev, const int32_t coarse_shape[3],
+                         int32_t divide, const uint8_t* skip_dev, void* stream);
+
+/*
+ * Noise: y = x + (mean + std * z)            (noise.py:98-123, :166-178)
+ *        rician: y = sqrt((x + n1)^2 + n2^2), n_i = mean + std * z_i
+ *   mean_dev / std_dev: per-element (B floats) when params_batched, else the
+ *   scalars mean / std are used.
+ *   base1_dev / base2_dev: standard-normal draws shaped like x.  Parity mode: the
+ *   caller fills them from the reference's seeded CPU generator (noise.py:177).
+ *   Fast mode (base1_dev == NULL): drawn in-kernel from Philox4x32-10 keyed by
+ *   (philox_seed, element index) + Box-Muller; base2 uses stream id 1.
+ *   keep_dev: optional B bytes; rows with keep == 0 are copied bit-exactly
+ *   (noise.py:126-146).
+ */
+int tio_add_noise(const void* x, void* y, int32_t dtype, int32_t batch,
+                  int64_t n_per_element, float mean, float std,
+                  const float* mean_dev, const float* std_dev,
+                  int32_t params_batched, int32_t rician, const float* base1_dev,
+                  const float* base2_dev, uint64_t philox_seed,
+                  const uint8_t* keep_dev, void* stream);
+
+/* Fill out_dev[0..n) with the same standard normals the fast noise mode draws
+ * (stream_id 0 → base1, 1 → base2). */
+int tio_philox_normal(float* out_dev, int64_t n, uint64_t philox_seed,
+                      int32_t stream_id, void* stream);
+
+/*
+ * Gamma: y = sign(x) * |x| ^ gamma            (gamma.py:80-91, :133-142)
+ *   gamma_dev: per-element exponents (B floats) when params_batched, else the
+ *   scalar gamma (= exp(log_gamma), gamma.py:103-120).
+ */
+int tio_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch,
+                  int64_t n_per_element, float gamma, const float* gamma_dev,
+                  int32_t params_batched, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Introspection                                                             */
+/* ------------------------------------------------------------------------ */
+int tio_abi_version(void);
+const char* tio_last_error(void);
+/* Number of visible HIP devices (0 when none; never throws). */
+int tio_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIO_HIP_H */

@@ -1,0 +1,611 @@
+/*
+ * tio_oracle.c — CPU restatement of TorchIO's augmentation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under torchio_amd/ links, imports or calls
+ * this file; it is used by tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py as the checker / baseline.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-for-bit (integer /
+ * nearest results) or to 1e-5 (float results) against outputs of the unmodified
+ * reference (TorchIO 2.0.0a2 on torch 2.10.0 CPU kernels, run in the build
+ * container by tests/golden/make_golden.py); the vectors live in tests/golden/.
+ *
+ * The arithmetic the reference delegates to PyTorch ATen (not vendored under
+ * /root/reference) is restated here from its published source semantics and was
+ * pinned empirically (tests/golden/README.md):
+ *   - mm of (N,4)x(4,4) float32 (MKL sgemm)       == forward FMA chain over k
+ *   - upsample_trilinear3d(align_corners=True)    == nested lerp, W innermost
+ *   - grid_sampler_3d(bilinear|nearest, zeros, align_corners=True)
+ *   - replication_pad3d + conv3d (cross-correlation)
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fopenmp -mfma -ffp-contract=off).
+ * Floating-point contraction MUST stay off: where the reference fuses
+ * (BLAS FMA) this file calls fmaf() explicitly, everywhere else products and
+ * sums round separately exactly like the ATen scalar code.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../include/tio_hip.h"
+
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* dtype helpers: `.float()` on load, `.to(dtype)` on store                   */
+/* ------------------------------------------------------------------------ */
+static inline float half_to_float(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1Fu;
+  uint32_t man = h & 0x3FFu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else { /* subnormal */
+      int e = -1;
+      do {
+        man <<= 1;
+        e++;
+      } while (!(man & 0x400u));
+      man &= 0x3FFu;
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7F800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 112u) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+static inline uint16_t float_to_half(float f) { /* round-to-nearest-even */
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t ax = x & 0x7FFFFFFFu;
+  if (ax >= 0x7F800000u) return (uint16_t)(sign | (ax > 0x7F800000u ? 0x7E00u : 0x7C00u));
+  if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u); /* overflow → inf */
+  if (ax < 0x33000001u) return (uint16_t)sign;               /* underflow → 0 */
+  int32_t exp = (int32_t)(ax >> 23) - 127;
+  uint32_t man = (ax & 0x7FFFFFu) | 0x800000u;
+  int shift;
+  uint32_t base;
+  if (exp < -14) { /* subnormal half */
+    shift = 13 + (-14 - exp);
+    base = 0;
+  } else {
+    shift = 13;
+    base = (uint32_t)(exp + 15) << 10;
+    man &= 0x7FFFFFu;
+  }
+  uint32_t q = man >> shift;
+  uint32_t rem = man & ((1u << shift) - 1u);
+  uint32_t halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+  return (uint16_t)(sign | (base + q));
+}
+
+static inline float bf16_to_float(uint16_t h) {
+  uint32_t bits = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+static inline uint16_t float_to_bf16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
+  uint32_t lsb = (x >> 16) & 1u;
+  x += 0x7FFFu + lsb;
+  return (uint16_t)(x >> 16);
+}
+
+static inline float load_as_float(const void* p, int dtype, int64_t i) {
+  switch (dtype) {
+    case TIO_F32: return ((const float*)p)[i];
+    case TIO_F64: return (float)((const double*)p)[i];
+    case TIO_F16: return half_to_float(((const uint16_t*)p)[i]);
+    case TIO_BF16: return bf16_to_float(((const uint16_t*)p)[i]);
+    case TIO_U8: return (float)((const uint8_t*)p)[i];
+    case TIO_I8: return (float)((const int8_t*)p)[i];
+    case TIO_I16: return (float)((const int16_t*)p)[i];
+    case TIO_I32: return (float)((const int32_t*)p)[i];
+    case TIO_I64: return (float)((const int64_t*)p)[i];
+    default: return 0.0f;
+  }
+}
+
+static inline void store_from_float(void* p, int dtype, int64_t i, float v) {
+  switch (dtype) {
+    case TIO_F32: ((float*)p)[i] = v; break;
+    case TIO_F64: ((double*)p)[i] = (double)v; break;
+    case TIO_F16: ((uint16_t*)p)[i] = float_to_half(v); break;
+    case TIO_BF16: ((uint16_t*)p)[i] = float_to_bf16(v); break;
+    case TIO_U8: ((uint8_t*)p)[i] = (uint8_t)(int64_t)v; break; /* trunc toward zero */
+    case TIO_I8: ((int8_t*)p)[i] = (int8_t)(int64_t)v; break;
+    case TIO_I16: ((int16_t*)p)[i] = (int16_t)(int64_t)v; break;
+    case TIO_I32: ((int32_t*)p)[i] = (int32_t)(int64_t)v; break;
+    case TIO_I64: ((int64_t*)p)[i] = (int64_t)v; break;
+    default: break;
+  }
+}
+
+static inline size_t dtype_size(int dtype) {
+  switch (dtype) {
+    case TIO_F32: case TIO_I32: return 4;
+    case TIO_F64: case TIO_I64: return 8;
+    case TIO_F16: case TIO_BF16: case TIO_I16: return 2;
+    case TIO_U8: case TIO_I8: return 1;
+    default: return 0;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* ATen upsample_{tri}linear (align_corners=True) index / lambda             */
+/*   used by spatial.py:2182-2187 and bias_field.py:333-338                   */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int32_t i0, i1;
+  float l0, l1;
+} lerp1d;
+
+static inline lerp1d lerp_index(int32_t o, int32_t n_in, int32_t n_out) {
+  lerp1d r;
+  if (n_out == n_in) { /* scale factor 1: plain copy */
+    r.i0 = o;
+    r.i1 = o;
+    r.l0 = 1.0f;
+    r.l1 = 0.0f;
+    return r;
+  }
+  float scale = (n_out > 1) ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
+  float real = scale * (float)o;
+  int32_t i0 = (int32_t)floorf(real);
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  float l1 = real - (float)i0;
+  if (l1 < 0.0f) l1 = 0.0f;
+  if (l1 > 1.0f) l1 = 1.0f;
+  r.i0 = i0;
+  r.i1 = i0 + ((i0 < n_in - 1) ? 1 : 0);
+  r.l1 = l1;
+  r.l0 = 1.0f - l1;
+  return r;
+}
+
+/* Nested linear interpolation exactly as ATen's Interpolate<n>::eval:
+ * innermost = last (K / W) axis, `output = t0*w0; output += t1*w1`.
+ * The dispatch build (AVX2/AVX512 flags, -ffp-contract=fast) contracts this to
+ * fma(t0, w0, t1*w1) — pinned bit-for-bit against F.interpolate (the other
+ * three candidates: separate roundings, fma(t1,w1,t0*w0), differ in ~25 % of
+ * the voxels by 1 ulp). */
+static inline float lerp2(float t0, float w0, float t1, float w1) {
+  return fmaf(t0, w0, t1 * w1);
+}
+
+static inline float trilerp(const float* v, int64_t s_i, int64_t s_j, int64_t s_k,
+                            lerp1d li, lerp1d lj, lerp1d lk) {
+  const float* p00 = v + li.i0 * s_i + lj.i0 * s_j;
+  const float* p01 = v + li.i0 * s_i + lj.i1 * s_j;
+  const float* p10 = v + li.i1 * s_i + lj.i0 * s_j;
+  const float* p11 = v + li.i1 * s_i + lj.i1 * s_j;
+  float a00 = lerp2(p00[lk.i0 * s_k], lk.l0, p00[lk.i1 * s_k], lk.l1);
+  float a01 = lerp2(p01[lk.i0 * s_k], lk.l0, p01[lk.i1 * s_k], lk.l1);
+  float a10 = lerp2(p10[lk.i0 * s_k], lk.l0, p10[lk.i1 * s_k], lk.l1);
+  float a11 = lerp2(p11[lk.i0 * s_k], lk.l0, p11[lk.i1 * s_k], lk.l1);
+  float b0 = lerp2(a00, lj.l0, a01, lj.l1);
+  float b1 = lerp2(a10, lj.l0, a11, lj.l1);
+  return lerp2(b0, li.l0, b1, li.l1);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Coordinates: spatial.py:1504-1648 + ATen un-normalise                     */
+/* ------------------------------------------------------------------------ */
+
+/* [c, 1] @ M^T for one row of M — MKL sgemm rounding: forward FMA chain. */
+static inline float affine_row(const float* m, float a, float b, float c) {
+  float t = a * m[0];
+  t = fmaf(b, m[1], t);
+  t = fmaf(c, m[2], t);
+  t = fmaf(1.0f, m[3], t);
+  return t;
+}
+
+/* g = 2 v / max(S-1,1) - 1  (spatial.py:1638-1646), then ATen
+ * grid_sampler_unnormalize(align_corners=True): ((g + 1) / 2) * (S - 1). */
+static inline float normalise_roundtrip(float v, int32_t size) {
+  float denom = (float)((size - 1 > 1) ? size - 1 : 1);
+  float g = 2.0f * v / denom - 1.0f;
+  return ((g + 1.0f) / 2.0f) * (float)(size - 1);
+}
+
+static inline int in_bounds(float f, int32_t n) { return f >= 0.0f && f <= (float)(n - 1); }
+
+int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
+                          const tio_resample_image* images, void* stream) {
+  (void)stream;
+  if (!g || !images || n_images < 1 || n_images > TIO_MAX_IMAGES) return TIO_ERR_INVALID_ARGUMENT;
+  const int32_t B = g->batch;
+  const int32_t I = g->in_shape[0], J = g->in_shape[1], K = g->in_shape[2];
+  const int32_t Io = g->out_shape[0], Jo = g->out_shape[1], Ko = g->out_shape[2];
+  const int64_t n_in = (int64_t)I * J * K, n_out = (int64_t)Io * Jo * Ko;
+  const int has_cp = g->control_points_dev != NULL;
+  const int32_t ni = g->cp_shape[0], nj = g->cp_shape[1], nk = g->cp_shape[2];
+  const float* spacing = g->affine_first ? g->in_spacing : g->out_spacing;
+
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int32_t b = 0; b < B; b++) {
+    for (int32_t io = 0; io < Io; io++) {
+      const float* m = g->mapping_dev + (g->mapping_batched ? (int64_t)b * 12 : 0);
+      const int pass = g->passthrough_dev && g->passthrough_dev[b];
+      const int elastic = has_cp && !(g->cp_skip_dev && g->cp_skip_dev[b]);
+      const float* cp = has_cp ? g->control_points_dev + (g->cp_batched ? (int64_t)b * ni * nj * nk * 3 : 0) : NULL;
+      lerp1d li = {0, 0, 1.0f, 0.0f};
+      if (elastic) li = lerp_index(io, ni, Io);
+      for (int32_t jo = 0; jo < Jo; jo++) {
+        lerp1d lj = {0, 0, 1.0f, 0.0f};
+        if (elastic) lj = lerp_index(jo, nj, Jo);
+        for (int32_t ko = 0; ko < Ko; ko++) {
+          const int64_t o_idx = ((int64_t)io * Jo + jo) * Ko + ko;
+          if (pass) { /* exact copy: spatial.py:1101-1106 */
+            for (int32_t im = 0; im < n_images; im++) {
+              const tio_resample_image* img = &images[im];
+              size_t es = dtype_size(img->dtype);
+              for (int32_t c = 0; c < img->channels; c++) {
+                int64_t off = ((int64_t)b * img->channels + c) * n_out + o_idx;
+                memcpy((char*)img->out + off * es, (const char*)img->in + off * es, es);
+              }
+            }
+            continue;
+          }
+          float ci = (float)io, cj = (float)jo, ck = (float)ko;
+          float vi, vj, vk;
+          if (elastic) {
+            lerp1d lk = lerp_index(ko, nk, Ko);
+            /* field layout (ni, nj, nk, 3): component stride 1 */
+            float di = trilerp(cp + 0, (int64_t)nj * nk * 3, (int64_t)nk * 3, 3, li, lj, lk);
+            float dj = trilerp(cp + 1, (int64_t)nj * nk * 3, (int64_t)nk * 3, 3, li, lj, lk);
+            float dk = trilerp(cp + 2, (int64_t)nj * nk * 3, (int64_t)nk * 3, 3, li, lj, lk);
+            if (g->affine_first) { /* spatial.py:1570-1573 */
+              vi = affine_row(m + 0, ci, cj, ck) + di / spacing[0];
+              vj = affine_row(m + 4, ci, cj, ck) + dj / spacing[1];
+              vk = affine_row(m + 8, ci, cj, ck) + dk / spacing[2];
+            } else { /* spatial.py:1574-1577 */
+              float ei = ci + di / spacing[0];
+              float ej = cj + dj / spacing[1];
+              float ek = ck + dk / spacing[2];
+              vi = affine_row(m + 0, ei, ej, ek);
+              vj = affine_row(m + 4, ei, ej, ek);
+              vk = affine_row(m + 8, ei, ej, ek);
+            }
+          } else { /* spatial.py:1542-1543 */
+            vi = affine_row(m + 0, ci, cj, ck);
+            vj = affine_row(m + 4, ci, cj, ck);
+            vk = affine_row(m + 8, ci, cj, ck);
+          }
+          /* torchio axis i ≡ grid x ≡ ATen W; j ≡ y ≡ H; k ≡ z ≡ D */
+          const float x = normalise_roundtrip(vi, I);
+          const float y = normalise_roundtrip(vj, J);
+          const float z = normalise_roundtrip(vk, K);
+
+          /* trilinear corner indices and weights (ATen grid_sampler_3d) */
+          const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+          const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+          float w[8];
+          w[0] = (x1 - x) * (y1 - y) * (z1 - z); /* tnw: (x0,y0,z0) */
+          w[1] = (x - x0) * (y1 - y) * (z1 - z); /* tne: (x1,y0,z0) */
+          w[2] = (x1 - x) * (y - y0) * (z1 - z); /* tsw: (x0,y1,z0) */
+          w[3] = (x - x0) * (y - y0) * (z1 - z); /* tse: (x1,y1,z0) */
+          w[4] = (x1 - x) * (y1 - y) * (z - z0); /* bnw: (x0,y0,z1) */
+          w[5] = (x - x0) * (y1 - y) * (z - z0); /* bne */
+          w[6] = (x1 - x) * (y - y0) * (z - z0); /* bsw */
+          w[7] = (x - x0) * (y - y0) * (z - z0); /* bse */
+          int ok[8];
+          int64_t off[8];
+          for (int t = 0; t < 8; t++) {
+            float fx = (t & 1) ? x1 : x0, fy = (t & 2) ? y1 : y0, fz = (t & 4) ? z1 : z0;
+            ok[t] = in_bounds(fx, I) && in_bounds(fy, J) && in_bounds(fz, K);
+            off[t] = ok[t] ? ((int64_t)fx * J + (int64_t)fy) * K + (int64_t)fz : 0;
+          }
+          float mask = 0.0f; /* grid_sample(ones): spatial.py:1721-1727 */
+          for (int t = 0; t < 8; t++)
+            if (ok[t]) mask += w[t];
+          /* nearest: nearbyint, half-to-even */
+          const float xn = nearbyintf(x), yn = nearbyintf(y), zn = nearbyintf(z);
+          const int okn = in_bounds(xn, I) && in_bounds(yn, J) && in_bounds(zn, K);
+          const int64_t offn = okn ? ((int64_t)xn * J + (int64_t)yn) * K + (int64_t)zn : 0;
+
+          for (int32_t im = 0; im < n_images; im++) {
+            const tio_resample_image* img = &images[im];
+            for (int32_t c = 0; c < img->channels; c++) {
+              const int64_t base_in = ((int64_t)b * img->channels + c) * n_in;
+              const int64_t base_out = ((int64_t)b * img->channels + c) * n_out;
+              float val;
+              if (img->interp == TIO_LINEAR) {
+                val = 0.0f;
+                for (int t = 0; t < 8; t++)
+                  if (ok[t]) val += load_as_float(img->in, img->dtype, base_in + off[t]) * w[t];
+              } else {
+                val = okn ? load_as_float(img->in, img->dtype, base_in + offn) : 0.0f;
+              }
+              if (img->fill_dev) val = (mask > 0.5f) ? val : img->fill_dev[c];
+              store_from_float(img->out, img->dtype, base_out + o_idx, val);
+            }
+          }
+        }
+      }
+    }
+  }
+  return TIO_OK;
+}
+
+/* spatial.py:2054-2060,2094-2095: float(tensor.min()) per channel of sample 0 */
+int tio_oracle_channel_min(const void* x, int32_t dtype, int32_t channels,
+                           int64_t n_spatial, float* out, void* stream) {
+  (void)stream;
+  for (int32_t c = 0; c < channels; c++) {
+    float best = INFINITY;
+    int has_nan = 0;
+    for (int64_t i = 0; i < n_spatial; i++) {
+      float v = load_as_float(x, dtype, (int64_t)c * n_spatial + i);
+      if (v != v) has_nan = 1;
+      if (v < best) best = v;
+    }
+    out[c] = has_nan ? NAN : best;
+  }
+  return TIO_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Blur stencil: blur.py:157-252 (and spatial.py:1980-2031)                   */
+/* ------------------------------------------------------------------------ */
+static void conv_axis(const float* src, float* dst, const int32_t shape[3], int axis,
+                      const float* taps, int32_t r) {
+  const int32_t I = shape[0], J = shape[1], K = shape[2];
+  const int64_t stride = axis == 0 ? (int64_t)J * K : (axis == 1 ? K : 1);
+  const int32_t n = shape[axis];
+#pragma omp parallel for schedule(static)
+  for (int32_t i = 0; i < I; i++)
+    for (int32_t j = 0; j < J; j++)
+      for (int32_t k = 0; k < K; k++) {
+        const int64_t idx = ((int64_t)i * J + j) * K + k;
+        const int32_t p = axis == 0 ? i : (axis == 1 ? j : k);
+        const int64_t line = idx - (int64_t)p * stride;
+        float acc = 0.0f;
+        for (int32_t t = 0; t <= 2 * r; t++) {
+          int32_t q = p + t - r; /* replicate padding = clamp */
+          q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+          acc += taps[t] * src[line + (int64_t)q * stride];
+        }
+        dst[idx] = acc;
+      }
+}
+
+int tio_oracle_separable_conv3d(const void* x, void* y, void* tmp, int32_t dtype,
+                                int32_t batch, int32_t channels, const int32_t shape[3],
+                                const float* taps, int32_t taps_batched,
+                                int32_t tap_stride, const int32_t radius[3],
+                                const uint8_t* skip, void* stream) {
+  (void)stream;
+  (void)tmp;
+  const int64_t n = (int64_t)shape[0] * shape[1] * shape[2];
+  float* a = (float*)__builtin_malloc((size_t)n * sizeof(float));
+  float* bbuf = (float*)__builtin_malloc((size_t)n * sizeof(float));
+  if (!a || !bbuf) return TIO_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype_size(dtype);
+  for (int32_t b = 0; b < batch; b++)
+    for (int32_t c = 0; c < channels; c++) {
+      const int64_t base = ((int64_t)b * channels + c) * n;
+      if (skip && skip[b]) {
+        memcpy((char*)y + base * es, (const char*)x + base * es, (size_t)n * es);
+        continue;
+      }
+      for (int64_t i = 0; i < n; i++) a[i] = load_as_float(x, dtype, base + i);
+      const float* t = taps + (taps_batched ? (int64_t)b * 3 * tap_stride : 0);
+      float* src = a;
+      float* dst = bbuf;
+      for (int axis = 0; axis < 3; axis++) {
+        if (radius[axis] <= 0) continue;
+        conv_axis(src, dst, shape, axis, t + (int64_t)axis * tap_stride, radius[axis]);
+        float* sw = src;
+        src = dst;
+        dst = sw;
+      }
+      for (int64_t i = 0; i < n; i++) store_from_float(y, dtype, base + i, src[i]);
+    }
+  __builtin_free(a);
+  __builtin_free(bbuf);
+  return TIO_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* BiasField: bias_field.py:201-255, 296-341                                  */
+/* ------------------------------------------------------------------------ */
+int tio_oracle_bias_field_apply(const void* x, void* y, int32_t dtype, int32_t batch,
+                                int32_t channels, const int32_t shape[3],
+                                const float* coarse, const int32_t cs[3],
+                                int32_t divide, const uint8_t* skip, void* stream) {
+  (void)stream;
+  const int32_t I = shape[0], J = shape[1], K = shape[2];
+  const int64_t n = (int64_t)I * J * K, nc = (int64_t)cs[0] * cs[1] * cs[2];
+  const size_t es = dtype_size(dtype);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int32_t bc = 0; bc < batch * channels; bc++) {
+    for (int32_t i = 0; i < I; i++) {
+      const int32_t b = bc / channels;
+      const int64_t base = (int64_t)bc * n;
+      if (skip && skip[b]) {
+        memcpy((char*)y + (base + (int64_t)i * J * K) * es,
+               (const char*)x + (base + (int64_t)i * J * K) * es, (size_t)J * K * es);
+        continue;
+      }
+      const float* f = coarse + (int64_t)bc * nc;
+      lerp1d li = lerp_index(i, cs[0], I);
+      for (int32_t j = 0; j < J; j++) {
+        lerp1d lj = lerp_index(j, cs[1], J);
+        for (int32_t k = 0; k < K; k++) {
+          lerp1d lk = lerp_index(k, cs[2], K);
+          const int64_t idx = base + ((int64_t)i * J + j) * K + k;
+          float field = expf(trilerp(f, (int64_t)cs[1] * cs[2], cs[2], 1, li, lj, lk));
+          if (dtype == TIO_F64) { /* f64 data * f32 field promotes to f64 */
+            double v = ((const double*)x)[idx];
+            ((double*)y)[idx] = divide ? v / (double)field : v * (double)field;
+          } else {
+            float v = load_as_float(x, dtype, idx);
+            store_from_float(y, dtype, idx, divide ? v / field : v * field);
+          }
+        }
+      }
+    }
+  }
+  return TIO_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Philox4x32-10 standard normals for the fast noise mode (this engine's own   */
+/* counter-based stream — NOT a reference algorithm; the reference draws from  */
+/* a CPU mt19937, noise.py:177).  The GPU kernel follows this definition.      */
+/* ------------------------------------------------------------------------ */
+static inline void philox4x32_10(uint32_t ctr[4], uint32_t k0, uint32_t k1) {
+  for (int round = 0; round < 10; round++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ ctr[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ ctr[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    ctr[0] = n0; ctr[1] = n1; ctr[2] = n2; ctr[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+/* four normals for counter block q of stream `stream_id` */
+static inline void philox_normal4(uint64_t seed, int32_t stream_id, uint64_t q, float z[4]) {
+  uint32_t ctr[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, 0u};
+  philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+  for (int h = 0; h < 2; h++) {
+    float u1 = ((float)(ctr[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(ctr[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float radius = sqrtf(-2.0f * logf(u1));
+    float theta = 6.28318530717958647692f * u2;
+    z[2 * h] = radius * cosf(theta);
+    z[2 * h + 1] = radius * sinf(theta);
+  }
+}
+
+int tio_oracle_philox_normal(float* out, int64_t n, uint64_t seed, int32_t stream_id, void* stream) {
+  (void)stream;
+#pragma omp parallel for schedule(static)
+  for (int64_t q = 0; q < (n + 3) / 4; q++) {
+    float z[4];
+    philox_normal4(seed, stream_id, (uint64_t)q, z);
+    for (int t = 0; t < 4; t++)
+      if (4 * q + t < n) out[4 * q + t] = z[t];
+  }
+  return TIO_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Noise: noise.py:98-123, 166-178                                            */
+/* ------------------------------------------------------------------------ */
+int tio_oracle_add_noise(const void* x, void* y, int32_t dtype, int32_t batch,
+                         int64_t n_per_element, float mean, float std,
+                         const float* mean_b, const float* std_b, int32_t params_batched,
+                         int32_t rician, const float* base1, const float* base2,
+                         uint64_t philox_seed, const uint8_t* keep, void* stream) {
+  (void)stream;
+  const size_t es = dtype_size(dtype);
+  for (int32_t b = 0; b < batch; b++) {
+    const float mu = params_batched ? mean_b[b] : mean;
+    const float sd = params_batched ? std_b[b] : std;
+    const int64_t base = (int64_t)b * n_per_element;
+    if (keep && !keep[b]) { /* noise.py:126-146 */
+      memcpy((char*)y + base * es, (const char*)x + base * es, (size_t)n_per_element * es);
+      continue;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_per_element; i++) {
+      const int64_t idx = base + i;
+      float z1, z2 = 0.0f;
+      if (base1) {
+        z1 = base1[idx];
+        if (rician) z2 = base2[idx];
+      } else {
+        float z[4];
+        philox_normal4(philox_seed, 0, (uint64_t)(idx >> 2), z);
+        z1 = z[idx & 3];
+        if (rician) {
+          philox_normal4(philox_seed, 1, (uint64_t)(idx >> 2), z);
+          z2 = z[idx & 3];
+        }
+      }
+      const float n1 = mu + sd * z1; /* noise.py:178 */
+      if (dtype == TIO_F64) {
+        double v = ((const double*)x)[idx];
+        if (rician) {
+          double n2 = (double)(mu + sd * z2);
+          double s = v + (double)n1;
+          ((double*)y)[idx] = sqrt(s * s + n2 * n2);
+        } else {
+          ((double*)y)[idx] = v + (double)n1;
+        }
+      } else {
+        float v = load_as_float(x, dtype, idx);
+        float r;
+        if (rician) { /* noise.py:117 */
+          float n2 = mu + sd * z2;
+          float s = v + n1;
+          r = sqrtf(s * s + n2 * n2);
+        } else {
+          r = v + n1; /* noise.py:119 */
+        }
+        store_from_float(y, dtype, idx, r);
+      }
+    }
+  }
+  return TIO_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Gamma: gamma.py:90 — sign(x) * |x| ** gamma                                 */
+/* ------------------------------------------------------------------------ */
+int tio_oracle_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch,
+                         int64_t n_per_element, float gamma, const float* gamma_b,
+                         int32_t params_batched, void* stream) {
+  (void)stream;
+  for (int32_t b = 0; b < batch; b++) {
+    const float gm = params_batched ? gamma_b[b] : gamma;
+    const int64_t base = (int64_t)b * n_per_element;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_per_element; i++) {
+      const int64_t idx = base + i;
+      if (dtype == TIO_F64) {
+        double v = ((const double*)x)[idx];
+        double s = (v > 0) - (v < 0);
+        ((double*)y)[idx] = s * pow(fabs(v), (double)gm);
+      } else {
+        float v = load_as_float(x, dtype, idx);
+        float s = (float)((v > 0.0f) - (v < 0.0f));
+        store_from_float(y, dtype, idx, s * powf(fabsf(v), gm));
+      }
+    }
+  }
+  return TIO_OK;
+}
+
+int tio_oracle_abi_version(void) { return TIO_ABI_VERSION; }
+
+int tio_oracle_num_threads(void) {
+#if defined(_OPENMP)
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,43 @@
+"""Shared pytest configuration.
+
+Markers
+    gpu  — needs a real MI355X (run by the driver with ``-m gpu``); everything
+           else must pass on a CPU-only box.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
+    config.addinivalue_line("markers", "reference: test imports the reference from /root/reference (build container only)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle engine (test infrastructure)."""
+    from oracle.oracle import oracle_engine
+
+    return oracle_engine()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The HIP engine; GPU tests fail loudly if it cannot be loaded."""
+    import torch
+
+    from torchio_amd import ops
+
+    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    return ops.engine()

@@ -1,0 +1,281 @@
+"""GPU parity: every C-ABI entry point of libtio_hip.so vs the CPU oracle.
+
+Same seeded inputs through ``torchio_amd.ops.engine()`` (HIP, cuda tensors) and
+``oracle.oracle_engine()`` (C restatement pinned against the reference, CPU
+tensors).  Bars: bit-exact for resampling (nearest AND linear: the kernel follows
+the oracle's float32 operation order), the stencil, noise with explicit draws and
+the channel minimum; 1e-6 relative where a transcendental (exp / pow / log / cos)
+is evaluated by different math libraries.
+"""
+from __future__ import annotations
+
+import itertools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _mapping(batch, seed, scale=0.15, shift=3.0):
+    g = torch.Generator().manual_seed(seed)
+    m = torch.eye(3, 4).repeat(batch, 1, 1)
+    m[:, :, :3] += scale * torch.randn(batch, 3, 3, generator=g)
+    m[:, :, 3] = shift * torch.randn(batch, 3, generator=g)
+    return m.float()
+
+
+def _control_points(batch, shape, seed, amplitude=4.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(batch, *shape, 3, generator=g) - 0.5) * 2 * amplitude).float()
+
+
+def _data(shape, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    if dtype.is_floating_point:
+        return (torch.rand(*shape, generator=g) * 4 - 1).to(dtype)
+    return torch.randint(0, 7, shape, generator=g).to(dtype)
+
+
+def _both(oracle, hip, fn, tensors, **kwargs):
+    """Run engine method *fn* on CPU (oracle) and GPU (hip) with the same arguments."""
+
+    def move(obj, device):
+        if isinstance(obj, torch.Tensor):
+            return obj.to(device)
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(move(o, device) for o in obj)
+        return obj
+
+    cpu = getattr(oracle, fn)(*move(tensors, "cpu"), **{k: move(v, "cpu") for k, v in kwargs.items()})
+    gpu = getattr(hip, fn)(*move(tensors, DEV), **{k: move(v, DEV) for k, v in kwargs.items()})
+    torch.cuda.synchronize()
+    return cpu, gpu
+
+
+RESAMPLE_CASES = list(
+    itertools.product(
+        [False, True],  # elastic
+        [True, False],  # affine_first
+        ["linear", "nearest"],
+        [True, False],  # fill
+    )
+)
+
+
+@pytest.mark.parametrize("elastic,affine_first,interp,with_fill", RESAMPLE_CASES)
+def test_resample_matches_oracle_bit_exact(oracle, hip, elastic, affine_first, interp, with_fill):
+    batch, channels = 2, 2
+    in_shape, out_shape = (20, 24, 70), (22, 19, 67)
+    data = _data((batch, channels, *in_shape), torch.float32, 1)
+    kwargs = dict(
+        out_shape=out_shape,
+        mapping=_mapping(1, 2),
+        control_points=_control_points(1, (7, 6, 5), 3) if elastic else None,
+        in_spacing=(1.0, 1.25, 0.8),
+        out_spacing=(0.9, 1.1, 0.75),
+        affine_first=affine_first,
+        interps=[interp],
+        fills=[torch.tensor([-1.0, 0.5]) if with_fill else None],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+@pytest.mark.parametrize(
+    "dtype", [torch.float64, torch.float16, torch.bfloat16, torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64]
+)
+@pytest.mark.parametrize("interp", ["linear", "nearest"])
+def test_resample_dtypes(oracle, hip, dtype, interp):
+    data = _data((1, 2, 17, 18, 40), dtype, 4)
+    kwargs = dict(
+        out_shape=(17, 18, 40),
+        mapping=_mapping(1, 5, scale=0.1),
+        control_points=_control_points(1, (7, 7, 7), 6),
+        in_spacing=(1, 1, 1),
+        out_spacing=(1, 1, 1),
+        affine_first=True,
+        interps=[interp],
+        fills=[torch.tensor([2.0, 3.0])],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert gpu[0].dtype == dtype
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_resample_multi_image_per_instance_flags(oracle, hip):
+    """2 float modalities + int label map, per-element matrices/fields, skip + passthrough rows."""
+    batch = 4
+    shape = (16, 20, 66)
+    t1 = _data((batch, 1, *shape), torch.float32, 7)
+    t2 = _data((batch, 2, *shape), torch.float32, 8)
+    seg = _data((batch, 1, *shape), torch.int16, 9)
+    kwargs = dict(
+        out_shape=shape,
+        mapping=_mapping(batch, 10, scale=0.08),
+        control_points=_control_points(batch, (7, 7, 7), 11),
+        in_spacing=(1, 1, 1),
+        out_spacing=(1, 1, 1),
+        affine_first=True,
+        interps=["linear", "linear", "nearest"],
+        fills=[torch.tensor([0.25]), torch.tensor([-1.0, 0.0]), None],
+        cp_skip=torch.tensor([0, 1, 0, 0], dtype=torch.uint8),
+        passthrough=torch.tensor([0, 0, 1, 0], dtype=torch.uint8),
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([t1, t2, seg],), **kwargs)
+    for c, g in zip(cpu, gpu, strict=True):
+        assert torch.equal(c, g.cpu())
+    assert torch.equal(gpu[2][2].cpu(), seg[2])  # passthrough row is bit-exact input
+
+
+def test_resample_identity_and_half_voxel_ties(oracle, hip):
+    """Identity mapping reproduces the input; a half-voxel shift exercises round-half-to-even."""
+    data = _data((1, 1, 9, 10, 65), torch.int32, 12)
+    ident = torch.eye(3, 4).reshape(1, 3, 4)
+    common = dict(out_shape=(9, 10, 65), control_points=None, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1),
+                  affine_first=True, interps=["nearest"], fills=[None])
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), mapping=ident, **common)
+    assert torch.equal(gpu[0].cpu(), data) and torch.equal(cpu[0], data)
+    half = ident.clone()
+    half[0, :, 3] = 0.5
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), mapping=half, **common)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_resample_2d_and_out_of_view(oracle, hip):
+    data = _data((2, 1, 33, 65, 1), torch.float32, 13)  # 2-D image: K == 1
+    far = torch.eye(3, 4).reshape(1, 3, 4).clone()
+    far[0, 0, 3] = 500.0  # everything maps outside → all fill
+    for mapping in (_mapping(1, 14, scale=0.05, shift=1.0), far):
+        mapping = mapping.clone()
+        mapping[:, 2, :] = torch.tensor([0.0, 0.0, 1.0, 0.0])
+        kwargs = dict(out_shape=(33, 65, 1), mapping=mapping, control_points=None, in_spacing=(1, 1, 1),
+                      out_spacing=(1, 1, 1), affine_first=True, interps=["linear"], fills=[torch.tensor([7.0])])
+        cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+        assert torch.equal(cpu[0], gpu[0].cpu())
+    assert bool((gpu[0] == 7.0).all())
+
+
+def test_channel_min(oracle, hip):
+    for dtype in (torch.float32, torch.float16, torch.int16, torch.float64):
+        data = _data((3, 4, 11, 13, 17), dtype, 15)
+        cpu, gpu = _both(oracle, hip, "channel_min", (data,))
+        assert torch.equal(cpu, gpu.cpu())
+        assert torch.equal(cpu, data[0].float().amin(dim=(1, 2, 3)))
+
+
+def _taps(batch, sigmas, stride):
+    taps = torch.zeros(batch, 3, stride)
+    radius = [0, 0, 0]
+    for b in range(batch):
+        for axis in range(3):
+            s = sigmas[b][axis]
+            if s <= 0:
+                continue
+            r = max(int(-(-3 * s // 1)), 1)
+            radius[axis] = max(radius[axis], r)
+    for b in range(batch):
+        for axis in range(3):
+            r = radius[axis]
+            if r == 0:
+                continue
+            s = sigmas[b][axis]
+            x = torch.arange(2 * r + 1, dtype=torch.float32) - r
+            if s > 0:
+                k = torch.exp(-0.5 * (x / s) ** 2)
+                k[(x.abs() > max(int(-(-3 * s // 1)), 1))] = 0
+            else:
+                k = (x == 0).float()
+            taps[b, axis, : 2 * r + 1] = k / k.sum()
+    return taps, radius
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.float64, torch.bfloat16])
+def test_separable_conv_matches_oracle(oracle, hip, dtype):
+    data = _data((2, 2, 19, 23, 70), dtype, 16)
+    taps, radius = _taps(1, [(1.3, 0.6, 2.0)], 32)
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, radius))
+    assert torch.equal(cpu, gpu.cpu())
+
+
+def test_separable_conv_per_element_and_skip(oracle, hip):
+    data = _data((3, 1, 12, 14, 66), torch.float32, 17)
+    taps, radius = _taps(3, [(1.0, 0.0, 0.7), (0.0, 0.0, 0.0), (0.4, 0.0, 1.9)], 16)
+    assert radius[1] == 0
+    skip = torch.tensor([0, 1, 0], dtype=torch.uint8)
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, radius), skip=skip)
+    assert torch.equal(cpu, gpu.cpu())
+    assert torch.equal(gpu[1].cpu(), data[1])
+    # single-axis and no-axis corner cases
+    taps1, radius1 = _taps(1, [(0.0, 0.0, 1.1)], 16)
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps1, radius1))
+    assert torch.equal(cpu, gpu.cpu())
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps1, [0, 0, 0]))
+    assert torch.equal(gpu.cpu(), data)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.float16])
+@pytest.mark.parametrize("divide", [False, True])
+def test_bias_field(oracle, hip, dtype, divide):
+    data = _data((3, 2, 18, 21, 68), dtype, 18)
+    g = torch.Generator().manual_seed(19)
+    coarse = 0.5 * torch.randn(3, 2, 4, 5, 6, generator=g)
+    skip = torch.tensor([0, 0, 1], dtype=torch.uint8)
+    cpu, gpu = _both(oracle, hip, "bias_field_apply", (data, coarse), divide=divide, skip=skip)
+    rtol = {torch.float32: 2e-6, torch.float64: 2e-6, torch.float16: 2e-3}[dtype]
+    torch.testing.assert_close(gpu.cpu(), cpu, rtol=rtol, atol=0)
+    assert torch.equal(gpu[2].cpu(), data[2])
+
+
+@pytest.mark.parametrize("rician", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_noise_with_explicit_draws_is_exact(oracle, hip, rician, dtype):
+    data = _data((3, 2, 9, 11, 31), dtype, 20)
+    g = torch.Generator().manual_seed(21)
+    base1 = torch.randn(data.shape, generator=g)
+    base2 = torch.randn(data.shape, generator=g)
+    mean = torch.tensor([0.1, 0.0, -0.2])
+    std = torch.tensor([0.25, 0.0, 0.5])
+    keep = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    cpu, gpu = _both(oracle, hip, "add_noise", (data, mean, std), rician=rician, base1=base1, base2=base2, keep=keep)
+    if rician:
+        torch.testing.assert_close(gpu.cpu(), cpu, rtol=1e-6, atol=1e-7)
+    else:
+        assert torch.equal(cpu, gpu.cpu())
+    assert torch.equal(gpu[1].cpu(), data[1])
+    cpu, gpu = _both(oracle, hip, "add_noise", (data, 0.05, 0.3), rician=False, base1=base1)
+    assert torch.equal(cpu, gpu.cpu())
+
+
+def test_philox_stream_and_fast_noise(oracle, hip):
+    n = 4 * 1000 + 3
+    cpu = oracle.philox_normal((n,), 1234567890123, 0, "cpu")
+    gpu = hip.philox_normal((n,), 1234567890123, 0, DEV)
+    torch.testing.assert_close(gpu.cpu(), cpu, rtol=0, atol=2e-5)
+    big = hip.philox_normal((1 << 22,), 42, 1, DEV)
+    assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1.0) < 3e-3
+    data = _data((2, 1, 8, 8, 64), torch.float32, 22)
+    cpu, gpu = _both(oracle, hip, "add_noise", (data, 0.0, 0.25), philox_seed=99)
+    torch.testing.assert_close(gpu.cpu(), cpu, rtol=0, atol=1e-5)
+    z = hip.philox_normal(data.shape, 99, 0, DEV)
+    torch.testing.assert_close(gpu, data.to(DEV) + 0.25 * z, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.float16])
+def test_gamma(oracle, hip, dtype):
+    data = _data((3, 2, 9, 11, 31), dtype, 23)
+    data[0, 0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -1.0]).to(dtype)
+    cpu, gpu = _both(oracle, hip, "gamma_pow", (data, torch.tensor([0.8, 1.0, 1.3])))
+    rtol = 2e-3 if dtype == torch.float16 else 2e-6
+    torch.testing.assert_close(gpu.cpu(), cpu, rtol=rtol, atol=0)
+    cpu, gpu = _both(oracle, hip, "gamma_pow", (data, 1.25))
+    torch.testing.assert_close(gpu.cpu(), cpu, rtol=rtol, atol=0)
+
+
+def test_engine_rejects_cpu_tensors(hip):
+    from torchio_amd.ops import EngineError
+
+    with pytest.raises(EngineError):
+        hip.gamma_pow(torch.rand(1, 1, 2, 2, 2), 1.5)

@@ -1,0 +1,111 @@
+"""ctypes description of the C ABI declared in ``include/tio_hip.h``.
+
+Only types and prototypes live here — no library is loaded.  ``bind(lib, prefix)``
+attaches ``argtypes``/``restype`` to every entry point of a loaded library whose
+symbols start with ``prefix`` (``"tio_"`` for ``libtio_hip.so``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+ABI_VERSION = 1
+MAX_IMAGES = 8
+
+# tio_status
+OK = 0
+
+# tio_dtype (values fixed by include/tio_hip.h)
+F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
+# tio_interp
+NEAREST, LINEAR = 0, 1
+
+
+class ResampleGeom(C.Structure):
+    """``tio_resample_geom``."""
+
+    _fields_ = [
+        ("batch", C.c_int32),
+        ("in_shape", C.c_int32 * 3),
+        ("out_shape", C.c_int32 * 3),
+        ("affine_first", C.c_int32),
+        ("mapping_dev", C.c_void_p),
+        ("mapping_batched", C.c_int32),
+        ("control_points_dev", C.c_void_p),
+        ("cp_batched", C.c_int32),
+        ("cp_shape", C.c_int32 * 3),
+        ("cp_skip_dev", C.c_void_p),
+        ("passthrough_dev", C.c_void_p),
+        ("in_spacing", C.c_float * 3),
+        ("out_spacing", C.c_float * 3),
+    ]
+
+
+class ResampleImage(C.Structure):
+    """``tio_resample_image``."""
+
+    _fields_ = [
+        ("in_", C.c_void_p),
+        ("out", C.c_void_p),
+        ("channels", C.c_int32),
+        ("dtype", C.c_int32),
+        ("interp", C.c_int32),
+        ("fill_dev", C.c_void_p),
+    ]
+
+
+_I32x3 = C.POINTER(C.c_int32)
+
+#: name -> (restype, argtypes); names are given without the library prefix.
+PROTOTYPES = {
+    "resample3d": (C.c_int, [C.POINTER(ResampleGeom), C.c_int32, C.POINTER(ResampleImage), C.c_void_p]),
+    "channel_min": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "separable_conv3d": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3,
+         C.c_void_p, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_void_p],
+    ),
+    "bias_field_apply": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_void_p, _I32x3,
+         C.c_int32, C.c_void_p, C.c_void_p],
+    ),
+    "add_noise": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_float,
+         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64,
+         C.c_void_p, C.c_void_p],
+    ),
+    "philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p]),
+    "gamma_pow": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p,
+         C.c_int32, C.c_void_p],
+    ),
+    "abi_version": (C.c_int, []),
+}
+
+#: entry points only the HIP library has (not the CPU restatement)
+HIP_ONLY_PROTOTYPES = {
+    "last_error": (C.c_char_p, []),
+    "device_count": (C.c_int, []),
+}
+
+#: every symbol include/tio_hip.h declares for libtio_hip.so
+HIP_SYMBOLS = tuple("tio_" + n for n in (*PROTOTYPES, *HIP_ONLY_PROTOTYPES))
+
+
+def bind(lib: C.CDLL, prefix: str, extra: dict | None = None) -> dict:
+    """Attach prototypes to ``lib`` and return ``{short_name: function}``.
+
+    Raises ``AttributeError`` naming the first missing symbol.
+    """
+    table = {}
+    protos = dict(PROTOTYPES)
+    if extra:
+        protos.update(extra)
+    for name, (restype, argtypes) in protos.items():
+        fn = getattr(lib, prefix + name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+        table[name] = fn
+    return table

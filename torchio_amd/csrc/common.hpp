@@ -1,0 +1,178 @@
+// common.hpp — shared device/host helpers for libtio_hip.so (gfx950 only).
+//
+// Numerics contract: this library is compiled with -ffp-contract=off.  Wherever
+// the reference's arithmetic fuses a multiply-add (MKL sgemm, ATen's AVX lerp)
+// the code calls __builtin_fmaf explicitly; everywhere else a*b+c rounds twice,
+// exactly like the ATen scalar kernels it reproduces.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tio_hip.h"
+
+namespace tio {
+
+// ---- error reporting (thread-local text, see tio_last_error) -----------------
+void set_error(const char* fmt, ...);
+int fail(int status, const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- element type conversion: `.float()` on load, `.to(dtype)` on store -------
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t h) {
+  return __uint_as_float(static_cast<uint32_t>(h) << 16);
+}
+
+__device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
+  uint32_t x = __float_as_uint(f);
+  if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;  // NaN
+  x += 0x7FFFu + ((x >> 16) & 1u);                       // round to nearest even
+  return static_cast<uint16_t>(x >> 16);
+}
+
+template <int DT>
+struct Elem;
+template <>
+struct Elem<TIO_F32> {
+  using type = float;
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { static_cast<float*>(p)[i] = v; }
+};
+template <>
+struct Elem<TIO_F64> {
+  using type = double;
+  static __device__ __forceinline__ float load(const void* p, int64_t i) {
+    return static_cast<float>(static_cast<const double*>(p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) {
+    static_cast<double*>(p)[i] = static_cast<double>(v);
+  }
+};
+template <>
+struct Elem<TIO_F16> {
+  using type = _Float16;
+  static __device__ __forceinline__ float load(const void* p, int64_t i) {
+    return static_cast<float>(static_cast<const _Float16*>(p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) {
+    static_cast<_Float16*>(p)[i] = static_cast<_Float16>(v);  // v_cvt_f16_f32: RNE
+  }
+};
+template <>
+struct Elem<TIO_BF16> {
+  using type = uint16_t;
+  static __device__ __forceinline__ float load(const void* p, int64_t i) {
+    return bf16_bits_to_float(static_cast<const uint16_t*>(p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) {
+    static_cast<uint16_t*>(p)[i] = float_to_bf16_bits(v);
+  }
+};
+#define TIO_INT_ELEM(CODE, T)                                                                  \
+  template <>                                                                                  \
+  struct Elem<CODE> {                                                                          \
+    using type = T;                                                                            \
+    static __device__ __forceinline__ float load(const void* p, int64_t i) {                   \
+      return static_cast<float>(static_cast<const T*>(p)[i]);                                  \
+    }                                                                                          \
+    static __device__ __forceinline__ void store(void* p, int64_t i, float v) {                \
+      static_cast<T*>(p)[i] = static_cast<T>(static_cast<int64_t>(v)); /* trunc toward 0 */    \
+    }                                                                                          \
+  };
+TIO_INT_ELEM(TIO_U8, uint8_t)
+TIO_INT_ELEM(TIO_I8, int8_t)
+TIO_INT_ELEM(TIO_I16, int16_t)
+TIO_INT_ELEM(TIO_I32, int32_t)
+TIO_INT_ELEM(TIO_I64, int64_t)
+#undef TIO_INT_ELEM
+
+// Run-time dtype (uniform across a launch → scalar branch).
+__device__ __forceinline__ float load_as_float(const void* p, int dtype, int64_t i) {
+  switch (dtype) {
+    case TIO_F32: return Elem<TIO_F32>::load(p, i);
+    case TIO_F64: return Elem<TIO_F64>::load(p, i);
+    case TIO_F16: return Elem<TIO_F16>::load(p, i);
+    case TIO_BF16: return Elem<TIO_BF16>::load(p, i);
+    case TIO_U8: return Elem<TIO_U8>::load(p, i);
+    case TIO_I8: return Elem<TIO_I8>::load(p, i);
+    case TIO_I16: return Elem<TIO_I16>::load(p, i);
+    case TIO_I32: return Elem<TIO_I32>::load(p, i);
+    default: return Elem<TIO_I64>::load(p, i);
+  }
+}
+
+__device__ __forceinline__ void store_from_float(void* p, int dtype, int64_t i, float v) {
+  switch (dtype) {
+    case TIO_F32: Elem<TIO_F32>::store(p, i, v); break;
+    case TIO_F64: Elem<TIO_F64>::store(p, i, v); break;
+    case TIO_F16: Elem<TIO_F16>::store(p, i, v); break;
+    case TIO_BF16: Elem<TIO_BF16>::store(p, i, v); break;
+    case TIO_U8: Elem<TIO_U8>::store(p, i, v); break;
+    case TIO_I8: Elem<TIO_I8>::store(p, i, v); break;
+    case TIO_I16: Elem<TIO_I16>::store(p, i, v); break;
+    case TIO_I32: Elem<TIO_I32>::store(p, i, v); break;
+    default: Elem<TIO_I64>::store(p, i, v); break;
+  }
+}
+
+inline __host__ __device__ int dtype_size(int dtype) {
+  switch (dtype) {
+    case TIO_F32: case TIO_I32: return 4;
+    case TIO_F64: case TIO_I64: return 8;
+    case TIO_F16: case TIO_BF16: case TIO_I16: return 2;
+    case TIO_U8: case TIO_I8: return 1;
+    default: return 0;
+  }
+}
+
+inline bool is_float_dtype(int dtype) {
+  return dtype == TIO_F32 || dtype == TIO_F64 || dtype == TIO_F16 || dtype == TIO_BF16;
+}
+
+// ---- ATen upsample_linear (align_corners=True) source index / lambdas ---------
+struct Lerp1D {
+  int i0, i1;
+  float l0, l1;
+};
+
+__device__ __forceinline__ Lerp1D lerp_index(int o, int n_in, int n_out, float scale) {
+  Lerp1D r;
+  if (n_out == n_in) {  // scale factor 1: plain copy
+    r.i0 = o; r.i1 = o; r.l0 = 1.0f; r.l1 = 0.0f;
+    return r;
+  }
+  const float real = scale * static_cast<float>(o);
+  int i0 = static_cast<int>(floorf(real));
+  i0 = min(i0, n_in - 1);
+  float l1 = real - static_cast<float>(i0);
+  l1 = fminf(fmaxf(l1, 0.0f), 1.0f);
+  r.i0 = i0;
+  r.i1 = i0 + ((i0 < n_in - 1) ? 1 : 0);
+  r.l1 = l1;
+  r.l0 = 1.0f - l1;
+  return r;
+}
+
+// area_pixel_compute_scale<float>(n_in, n_out, align_corners=true)
+inline __host__ __device__ float lerp_scale(int n_in, int n_out) {
+  return (n_out > 1) ? static_cast<float>(n_in - 1) / static_cast<float>(n_out - 1) : 0.0f;
+}
+
+// ATen Interpolate<n>::eval (`out = t0*w0; out += t1*w1`) as the AVX dispatch build
+// contracts it: fma(t0, w0, t1*w1) — pinned bit-for-bit against F.interpolate.
+__device__ __forceinline__ float lerp2(float t0, float w0, float t1, float w1) {
+  return __builtin_fmaf(t0, w0, __fmul_rn(t1, w1));
+}
+
+// Bijective XCD-aware block remap (guide §5.5 T1): the hardware dispatches
+// block b to XCD b % 8; give every XCD one contiguous chunk of the tile space so
+// neighbouring tiles share that XCD's private L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+  constexpr unsigned NX = 8;
+  const unsigned q = nblocks / NX, r = nblocks % NX;
+  const unsigned xcd = bid % NX, slot = bid / NX;
+  const unsigned start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + slot;
+}
+
+}  // namespace tio

@@ -1,0 +1,508 @@
+// intensity.hip — intensity-path kernels for gfx950:
+//   tio_separable_conv3d  (Blur / antialias stencil;  blur.py:157-252)
+//   tio_bias_field_apply  (BiasField;                 bias_field.py:201-341)
+//   tio_add_noise         (Noise;                     noise.py:98-178)
+//   tio_philox_normal     (the fast-mode normal stream of tio_add_noise)
+//   tio_gamma_pow         (Gamma;                     gamma.py:80-142)
+//   tio_channel_min       (default_pad_value="minimum"; spatial.py:2054-2095)
+// All are HBM-bound elementwise / stencil passes: one read + one write of the
+// volume per op (the separable stencil: per active axis).  No MFMA.
+#include "common.hpp"
+
+namespace tio {
+
+constexpr int kBlock = 256;
+
+// =============================================================================
+// Separable cross-correlation with replicate padding
+// =============================================================================
+// One pass = one axis.  Thread = one output voxel, lanes along K (contiguous):
+// for the I and J axes every tap is a fully coalesced row read, for the K axis
+// the wave's taps overlap in L1.
+template <int SRC_DT, int DST_DT>
+__global__ __launch_bounds__(kBlock) void conv_axis_kernel(
+    const void* __restrict__ src, void* __restrict__ dst, int64_t n_spatial, int I, int J, int K,
+    int channels, int axis, int radius, const float* __restrict__ taps, int taps_batched,
+    int tap_stride, const uint8_t* __restrict__ skip, int first_pass, const void* __restrict__ x_orig,
+    int orig_dtype, int last_pass) {
+  extern __shared__ __attribute__((aligned(16))) float s_taps[];
+  const int bc = blockIdx.y;
+  const int b = bc / channels;
+  const float* t = taps + (taps_batched ? static_cast<int64_t>(b) * 3 * tap_stride : 0) +
+                   static_cast<int64_t>(axis) * tap_stride;
+  const int ntaps = 2 * radius + 1;
+  for (int i = threadIdx.x; i < ntaps; i += blockDim.x) s_taps[i] = t[i];
+  __syncthreads();
+
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n_spatial) return;
+  const int64_t base = static_cast<int64_t>(bc) * n_spatial;
+  if (skip != nullptr && skip[b] != 0) {
+    // rows with no blur are restored bit-exactly (blur.py:249-251): carry the
+    // original element through every pass and emit it unchanged at the end
+    if (last_pass) {
+      const int es = dtype_size(orig_dtype);
+      const char* s = static_cast<const char*>(x_orig) + (base + idx) * es;
+      char* d = static_cast<char*>(dst) + (base + idx) * es;
+      for (int e = 0; e < es; e++) d[e] = s[e];
+    }
+    return;
+  }
+  const int k = static_cast<int>(idx % K);
+  const int j = static_cast<int>((idx / K) % J);
+  const int i = static_cast<int>(idx / (static_cast<int64_t>(K) * J));
+  const int p = axis == 0 ? i : (axis == 1 ? j : k);
+  const int n = axis == 0 ? I : (axis == 1 ? J : K);
+  const int64_t stride = axis == 0 ? static_cast<int64_t>(J) * K : (axis == 1 ? K : 1);
+  const int64_t line = base + idx - static_cast<int64_t>(p) * stride;
+  float acc = 0.0f;
+  for (int tt = 0; tt < ntaps; tt++) {
+    int q = p + tt - radius;  // replicate padding == clamp
+    q = min(max(q, 0), n - 1);
+    const float v = Elem<SRC_DT>::load(src, line + static_cast<int64_t>(q) * stride);
+    acc = __fadd_rn(acc, __fmul_rn(s_taps[tt], v));
+  }
+  Elem<DST_DT>::store(dst, base + idx, acc);
+  (void)first_pass;
+}
+
+template <int DT>
+static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t batch, int32_t channels,
+                       const int32_t shape[3], const float* taps, int taps_batched, int tap_stride,
+                       const int32_t radius[3], const uint8_t* skip, hipStream_t stream) {
+  const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
+  int active[3], n_active = 0;
+  for (int a = 0; a < 3; a++)
+    if (radius[a] > 0) active[n_active++] = a;
+  const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock), static_cast<unsigned>(batch * channels));
+  const void* src = x;
+  for (int s = 0; s < n_active; s++) {
+    const int axis = active[s];
+    const bool first = s == 0, last = s == n_active - 1;
+    void* dst = last ? y : static_cast<void*>((s % 2 == 0) ? tmp0 : tmp1);
+    const size_t lds = static_cast<size_t>(2 * radius[axis] + 1) * sizeof(float);
+#define TIO_CONV_LAUNCH(S, D)                                                                              \
+  hipLaunchKernelGGL((conv_axis_kernel<S, D>), grid, dim3(kBlock), lds, stream, src, dst, n, shape[0],     \
+                     shape[1], shape[2], channels, axis, radius[axis], taps, taps_batched, tap_stride,     \
+                     skip, first ? 1 : 0, x, DT, last ? 1 : 0)
+    if (first && last) TIO_CONV_LAUNCH(DT, DT);
+    else if (first) TIO_CONV_LAUNCH(DT, TIO_F32);
+    else if (last) TIO_CONV_LAUNCH(TIO_F32, DT);
+    else TIO_CONV_LAUNCH(TIO_F32, TIO_F32);
+#undef TIO_CONV_LAUNCH
+    src = dst;
+  }
+  return check_launch("tio_separable_conv3d");
+}
+
+// =============================================================================
+// BiasField
+// =============================================================================
+constexpr int kMaxCoarseLds = 8192;  // floats (32 KiB)
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void bias_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                      int channels, int I, int J, int K,
+                                                      const float* __restrict__ coarse, int ci, int cj, int ck,
+                                                      float scale_i, float scale_j, float scale_k, int divide,
+                                                      const uint8_t* __restrict__ skip) {
+  extern __shared__ __attribute__((aligned(16))) float s_coarse[];
+  const int bc = blockIdx.y;
+  const int b = bc / channels;
+  const int64_t n = static_cast<int64_t>(I) * J * K;
+  const int64_t base = static_cast<int64_t>(bc) * n;
+  const bool skipped = skip != nullptr && skip[b] != 0;
+  const int nc = ci * cj * ck;
+  const float* f = coarse + static_cast<int64_t>(bc) * nc;
+  if (!skipped && nc <= kMaxCoarseLds) {
+    for (int t = threadIdx.x; t < nc; t += blockDim.x) s_coarse[t] = f[t];
+    __syncthreads();
+    f = s_coarse;
+  }
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  using T = typename Elem<DT>::type;
+  if (skipped) {  // std == 0 rows restored bit-exactly (bias_field.py:247-253)
+    static_cast<T*>(y)[base + idx] = static_cast<const T*>(x)[base + idx];
+    return;
+  }
+  const int k = static_cast<int>(idx % K);
+  const int j = static_cast<int>((idx / K) % J);
+  const int i = static_cast<int>(idx / (static_cast<int64_t>(K) * J));
+  const Lerp1D li = lerp_index(i, ci, I, scale_i);
+  const Lerp1D lj = lerp_index(j, cj, J, scale_j);
+  const Lerp1D lk = lerp_index(k, ck, K, scale_k);
+  const int s_i = cj * ck, s_j = ck;
+  const float* p00 = f + li.i0 * s_i + lj.i0 * s_j;
+  const float* p01 = f + li.i0 * s_i + lj.i1 * s_j;
+  const float* p10 = f + li.i1 * s_i + lj.i0 * s_j;
+  const float* p11 = f + li.i1 * s_i + lj.i1 * s_j;
+  const float a00 = lerp2(p00[lk.i0], lk.l0, p00[lk.i1], lk.l1);
+  const float a01 = lerp2(p01[lk.i0], lk.l0, p01[lk.i1], lk.l1);
+  const float a10 = lerp2(p10[lk.i0], lk.l0, p10[lk.i1], lk.l1);
+  const float a11 = lerp2(p11[lk.i0], lk.l0, p11[lk.i1], lk.l1);
+  const float b0 = lerp2(a00, lj.l0, a01, lj.l1);
+  const float b1 = lerp2(a10, lj.l0, a11, lj.l1);
+  const float field = expf(lerp2(b0, li.l0, b1, li.l1));  // bias_field.py:341
+  if constexpr (DT == TIO_F64) {  // f64 data (x) f32 field promotes to f64
+    const double v = static_cast<const double*>(x)[base + idx];
+    static_cast<double*>(y)[base + idx] = divide ? v / static_cast<double>(field) : v * static_cast<double>(field);
+  } else {
+    const float v = Elem<DT>::load(x, base + idx);
+    Elem<DT>::store(y, base + idx, divide ? __fdiv_rn(v, field) : __fmul_rn(v, field));
+  }
+}
+
+// =============================================================================
+// Philox4x32-10 + Box-Muller (fast noise mode; definition in oracle/tio_oracle.c)
+// =============================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int round = 0; round < 10; round++) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c[0];
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c[2];
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = static_cast<uint32_t>(p0);
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__device__ __forceinline__ void philox_normal4(uint64_t seed, int stream_id, uint64_t q, float z[4]) {
+  uint32_t c[4] = {static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), static_cast<uint32_t>(stream_id), 0u};
+  philox4x32_10(c, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float u1 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h] >> 8), 0.5f), 1.0f / 16777216.0f);
+    const float u2 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h + 1] >> 8), 0.5f), 1.0f / 16777216.0f);
+    const float radius = sqrtf(__fmul_rn(-2.0f, logf(u1)));
+    const float theta = __fmul_rn(6.28318530717958647692f, u2);
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    z[2 * h] = __fmul_rn(radius, cs);
+    z[2 * h + 1] = __fmul_rn(radius, sn);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                               int stream_id) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (4 * q >= n) return;
+  float z[4];
+  philox_normal4(seed, stream_id, static_cast<uint64_t>(q), z);
+  if (4 * q + 3 < n) {
+    *reinterpret_cast<float4*>(out + 4 * q) = make_float4(z[0], z[1], z[2], z[3]);
+  } else {
+    for (int t = 0; t < 4; t++)
+      if (4 * q + t < n) out[4 * q + t] = z[t];
+  }
+}
+
+// =============================================================================
+// Noise: thread = 4 consecutive elements (one Philox block / one 16-B access)
+// =============================================================================
+template <int DT>
+__global__ __launch_bounds__(kBlock) void noise_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                       int64_t n_per_element, float mean, float std,
+                                                       const float* __restrict__ mean_b,
+                                                       const float* __restrict__ std_b, int params_batched,
+                                                       int rician, const float* __restrict__ base1,
+                                                       const float* __restrict__ base2, uint64_t seed,
+                                                       const uint8_t* __restrict__ keep) {
+  const int b = blockIdx.y;
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t e0 = 4 * q;
+  if (e0 >= n_per_element) return;
+  const int64_t base = static_cast<int64_t>(b) * n_per_element;
+  const float mu = params_batched ? mean_b[b] : mean;
+  const float sd = params_batched ? std_b[b] : std;
+  const bool kept = keep == nullptr || keep[b] != 0;
+  using T = typename Elem<DT>::type;
+  const int cnt = static_cast<int>(min(static_cast<int64_t>(4), n_per_element - e0));
+  if (!kept) {  // gated-out rows restored bit-exactly (noise.py:126-146)
+    for (int t = 0; t < cnt; t++) static_cast<T*>(y)[base + e0 + t] = static_cast<const T*>(x)[base + e0 + t];
+    return;
+  }
+  float z1[4], z2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (base1 != nullptr) {
+    for (int t = 0; t < cnt; t++) {
+      z1[t] = base1[base + e0 + t];
+      if (rician) z2[t] = base2[base + e0 + t];
+    }
+  } else {
+    // Philox blocks are indexed by the GLOBAL element index (base + e0) >> 2 so
+    // that the stream equals tio_philox_normal over the whole tensor; rows are
+    // 4-aligned whenever n_per_element % 4 == 0, otherwise take the slow path.
+    if (((base + e0) & 3) == 0) {
+      philox_normal4(seed, 0, static_cast<uint64_t>((base + e0) >> 2), z1);
+      if (rician) philox_normal4(seed, 1, static_cast<uint64_t>((base + e0) >> 2), z2);
+    } else {
+      for (int t = 0; t < cnt; t++) {
+        float z[4];
+        const int64_t g = base + e0 + t;
+        philox_normal4(seed, 0, static_cast<uint64_t>(g >> 2), z);
+        z1[t] = z[g & 3];
+        if (rician) {
+          philox_normal4(seed, 1, static_cast<uint64_t>(g >> 2), z);
+          z2[t] = z[g & 3];
+        }
+      }
+    }
+  }
+  for (int t = 0; t < cnt; t++) {
+    const int64_t idx = base + e0 + t;
+    const float n1 = __fadd_rn(mu, __fmul_rn(sd, z1[t]));  // noise.py:178
+    if constexpr (DT == TIO_F64) {
+      const double v = static_cast<const double*>(x)[idx];
+      if (rician) {
+        const double n2 = static_cast<double>(__fadd_rn(mu, __fmul_rn(sd, z2[t])));
+        const double s = v + static_cast<double>(n1);
+        static_cast<double*>(y)[idx] = sqrt(s * s + n2 * n2);
+      } else {
+        static_cast<double*>(y)[idx] = v + static_cast<double>(n1);
+      }
+    } else {
+      const float v = Elem<DT>::load(x, idx);
+      float r;
+      if (rician) {  // noise.py:117
+        const float n2 = __fadd_rn(mu, __fmul_rn(sd, z2[t]));
+        const float s = __fadd_rn(v, n1);
+        r = sqrtf(__fadd_rn(__fmul_rn(s, s), __fmul_rn(n2, n2)));
+      } else {
+        r = __fadd_rn(v, n1);  // noise.py:119
+      }
+      Elem<DT>::store(y, idx, r);
+    }
+  }
+}
+
+// =============================================================================
+// Gamma
+// =============================================================================
+template <int DT>
+__global__ __launch_bounds__(kBlock) void gamma_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                       int64_t n_per_element, float gamma,
+                                                       const float* __restrict__ gamma_b, int params_batched) {
+  const int b = blockIdx.y;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_per_element) return;
+  const int64_t idx = static_cast<int64_t>(b) * n_per_element + i;
+  const float gm = params_batched ? gamma_b[b] : gamma;
+  if constexpr (DT == TIO_F64) {
+    const double v = static_cast<const double*>(x)[idx];
+    const double s = static_cast<double>((v > 0) - (v < 0));
+    static_cast<double*>(y)[idx] = s * pow(fabs(v), static_cast<double>(gm));
+  } else {
+    const float v = Elem<DT>::load(x, idx);
+    const float s = static_cast<float>((v > 0.0f) - (v < 0.0f));
+    Elem<DT>::store(y, idx, __fmul_rn(s, powf(fabsf(v), gm)));  // gamma.py:90
+  }
+}
+
+// =============================================================================
+// Per-channel minimum of the first batch element (device-resident result)
+// =============================================================================
+// Floats are mapped to order-preserving unsigned keys so one atomicMin per block
+// suffices; NaN maps to key 0 so it wins, matching torch.min's NaN propagation.
+__device__ __forceinline__ uint32_t float_to_key(float f) {
+  if (f != f) return 0u;
+  const uint32_t bits = __float_as_uint(f);
+  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t key) {
+  if (key == 0u) return __uint_as_float(0x7FC00000u);
+  const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+  return __uint_as_float(bits);
+}
+
+__global__ void min_init_kernel(uint32_t* keys, int channels) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < channels) keys[c] = 0xFFFFFFFFu;
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void min_reduce_kernel(const void* __restrict__ x, int64_t n_spatial,
+                                                            uint32_t* __restrict__ keys) {
+  const int c = blockIdx.y;
+  const int64_t base = static_cast<int64_t>(c) * n_spatial;
+  uint32_t best = 0xFFFFFFFFu;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_spatial;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    best = min(best, float_to_key(Elem<DT>::load(x, base + i)));
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) best = min(best, static_cast<uint32_t>(__shfl_xor(static_cast<int>(best), s)));
+  __shared__ uint32_t s_best[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t m = s_best[0];
+    for (int w = 1; w < kBlock / 64; w++) m = min(m, s_best[w]);
+    atomicMin(&keys[c], m);
+  }
+}
+
+__global__ void min_decode_kernel(uint32_t* keys, int channels) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < channels) reinterpret_cast<float*>(keys)[c] = key_to_float(keys[c]);
+}
+
+// dtype dispatch helpers --------------------------------------------------------
+#define TIO_DISPATCH_FLOAT(DTYPE, MACRO)                \
+  switch (DTYPE) {                                      \
+    case TIO_F32: MACRO(TIO_F32); break;                \
+    case TIO_F64: MACRO(TIO_F64); break;                \
+    case TIO_F16: MACRO(TIO_F16); break;                \
+    case TIO_BF16: MACRO(TIO_BF16); break;              \
+    default: break;                                     \
+  }
+
+#define TIO_DISPATCH_ALL(DTYPE, MACRO)                  \
+  switch (DTYPE) {                                      \
+    case TIO_F32: MACRO(TIO_F32); break;                \
+    case TIO_F64: MACRO(TIO_F64); break;                \
+    case TIO_F16: MACRO(TIO_F16); break;                \
+    case TIO_BF16: MACRO(TIO_BF16); break;              \
+    case TIO_U8: MACRO(TIO_U8); break;                  \
+    case TIO_I8: MACRO(TIO_I8); break;                  \
+    case TIO_I16: MACRO(TIO_I16); break;                \
+    case TIO_I32: MACRO(TIO_I32); break;                \
+    case TIO_I64: MACRO(TIO_I64); break;                \
+    default: break;                                     \
+  }
+
+}  // namespace tio
+
+using namespace tio;
+
+extern "C" int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t dtype, int32_t batch,
+                                    int32_t channels, const int32_t shape[3], const float* taps_dev,
+                                    int32_t taps_batched, int32_t tap_stride, const int32_t radius[3],
+                                    const uint8_t* skip_dev, void* stream) {
+  if (x == nullptr || y == nullptr || shape == nullptr || radius == nullptr)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: null argument");
+  if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_separable_conv3d: dtype %d", dtype);
+  if (batch < 0 || channels < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: bad shape");
+  int n_active = 0;
+  for (int a = 0; a < 3; a++) {
+    if (radius[a] < 0 || 2 * radius[a] + 1 > tap_stride)
+      return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: radius[%d]=%d does not fit tap_stride=%d", a,
+                  radius[a], tap_stride);
+    if (radius[a] > 0) n_active++;
+  }
+  if (n_active > 0 && taps_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: null taps");
+  const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (batch == 0) return TIO_OK;
+  if (n_active == 0) {  // every sigma <= 0: identity (blur.py:144-145)
+    if (hipMemcpyAsync(y, x, static_cast<size_t>(batch) * channels * n * dtype_size(dtype), hipMemcpyDeviceToDevice, s) !=
+        hipSuccess)
+      return fail(TIO_ERR_LAUNCH, "tio_separable_conv3d: copy failed");
+    return TIO_OK;
+  }
+  if (n_active > 1 && tmp == nullptr)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: tmp is required when more than one axis is active");
+  float* tmp0 = static_cast<float*>(tmp);
+  float* tmp1 = tmp0 != nullptr ? tmp0 + static_cast<int64_t>(batch) * channels * n : nullptr;
+#define TIO_CONV(DT) \
+  return launch_conv<DT>(x, y, tmp0, tmp1, batch, channels, shape, taps_dev, taps_batched, tap_stride, radius, skip_dev, s)
+  TIO_DISPATCH_FLOAT(dtype, TIO_CONV)
+#undef TIO_CONV
+  return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_separable_conv3d: dtype %d", dtype);
+}
+
+extern "C" int tio_bias_field_apply(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels,
+                                    const int32_t shape[3], const float* coarse_dev,
+                                    const int32_t coarse_shape[3], int32_t divide, const uint8_t* skip_dev,
+                                    void* stream) {
+  if (x == nullptr || y == nullptr || shape == nullptr || coarse_dev == nullptr || coarse_shape == nullptr)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bias_field_apply: null argument");
+  if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_bias_field_apply: dtype %d", dtype);
+  for (int d = 0; d < 3; d++)
+    if (shape[d] < 1 || coarse_shape[d] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bias_field_apply: bad shape");
+  if (batch < 0 || channels < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bias_field_apply: bad batch/channels");
+  if (batch == 0) return TIO_OK;
+  const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
+  const int nc = coarse_shape[0] * coarse_shape[1] * coarse_shape[2];
+  const size_t lds = nc <= kMaxCoarseLds ? static_cast<size_t>(nc) * sizeof(float) : 0;
+  const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock), static_cast<unsigned>(batch * channels));
+#define TIO_BIAS(DT)                                                                                              \
+  hipLaunchKernelGGL((bias_kernel<DT>), grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, y, channels, \
+                     shape[0], shape[1], shape[2], coarse_dev, coarse_shape[0], coarse_shape[1], coarse_shape[2], \
+                     lerp_scale(coarse_shape[0], shape[0]), lerp_scale(coarse_shape[1], shape[1]),                \
+                     lerp_scale(coarse_shape[2], shape[2]), divide, skip_dev)
+  TIO_DISPATCH_FLOAT(dtype, TIO_BIAS)
+#undef TIO_BIAS
+  return check_launch("tio_bias_field_apply");
+}
+
+extern "C" int tio_add_noise(const void* x, void* y, int32_t dtype, int32_t batch, int64_t n_per_element,
+                             float mean, float std, const float* mean_dev, const float* std_dev,
+                             int32_t params_batched, int32_t rician, const float* base1_dev,
+                             const float* base2_dev, uint64_t philox_seed, const uint8_t* keep_dev, void* stream) {
+  if (x == nullptr || y == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_add_noise: null argument");
+  if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_add_noise: dtype %d", dtype);
+  if (batch < 0 || n_per_element < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_add_noise: negative size");
+  if (params_batched && (mean_dev == nullptr || std_dev == nullptr))
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_add_noise: params_batched needs mean_dev and std_dev");
+  if (base1_dev != nullptr && rician && base2_dev == nullptr)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_add_noise: rician with base1_dev needs base2_dev");
+  if (batch == 0 || n_per_element == 0) return TIO_OK;
+  const int64_t quads = (n_per_element + 3) / 4;
+  const dim3 grid(static_cast<unsigned>((quads + kBlock - 1) / kBlock), static_cast<unsigned>(batch));
+#define TIO_NOISE(DT)                                                                                          \
+  hipLaunchKernelGGL((noise_kernel<DT>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,        \
+                     n_per_element, mean, std, mean_dev, std_dev, params_batched, rician, base1_dev, base2_dev, \
+                     philox_seed, keep_dev)
+  TIO_DISPATCH_FLOAT(dtype, TIO_NOISE)
+#undef TIO_NOISE
+  return check_launch("tio_add_noise");
+}
+
+extern "C" int tio_philox_normal(float* out_dev, int64_t n, uint64_t philox_seed, int32_t stream_id, void* stream) {
+  if (out_dev == nullptr || n < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_philox_normal: bad argument");
+  if (n == 0) return TIO_OK;
+  const int64_t quads = (n + 3) / 4;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3(static_cast<unsigned>((quads + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), out_dev, n, philox_seed, stream_id);
+  return check_launch("tio_philox_normal");
+}
+
+extern "C" int tio_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch, int64_t n_per_element,
+                             float gamma, const float* gamma_dev, int32_t params_batched, void* stream) {
+  if (x == nullptr || y == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_gamma_pow: null argument");
+  if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_gamma_pow: dtype %d", dtype);
+  if (batch < 0 || n_per_element < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_gamma_pow: negative size");
+  if (params_batched && gamma_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_gamma_pow: null gamma_dev");
+  if (batch == 0 || n_per_element == 0) return TIO_OK;
+  const dim3 grid(static_cast<unsigned>((n_per_element + kBlock - 1) / kBlock), static_cast<unsigned>(batch));
+#define TIO_GAMMA(DT)                                                                                      \
+  hipLaunchKernelGGL((gamma_kernel<DT>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,    \
+                     n_per_element, gamma, gamma_dev, params_batched)
+  TIO_DISPATCH_FLOAT(dtype, TIO_GAMMA)
+#undef TIO_GAMMA
+  return check_launch("tio_gamma_pow");
+}
+
+extern "C" int tio_channel_min(const void* x, int32_t dtype, int32_t channels, int64_t n_spatial, float* out_dev,
+                               void* stream) {
+  if (x == nullptr || out_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_channel_min: null argument");
+  if (dtype_size(dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_channel_min: dtype %d", dtype);
+  if (channels < 1 || n_spatial < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_channel_min: empty input");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(out_dev);
+  const unsigned cb = static_cast<unsigned>((channels + 63) / 64);
+  hipLaunchKernelGGL(min_init_kernel, dim3(cb), dim3(64), 0, s, keys, channels);
+  const int64_t want = (n_spatial + kBlock - 1) / kBlock;
+  const unsigned gx = static_cast<unsigned>(want < 2048 ? want : 2048);
+#define TIO_MIN(DT) \
+  hipLaunchKernelGGL((min_reduce_kernel<DT>), dim3(gx, static_cast<unsigned>(channels)), dim3(kBlock), 0, s, x, n_spatial, keys)
+  TIO_DISPATCH_ALL(dtype, TIO_MIN)
+#undef TIO_MIN
+  hipLaunchKernelGGL(min_decode_kernel, dim3(cb), dim3(64), 0, s, keys, channels);
+  return check_launch("tio_channel_min");
+}

@@ -1,0 +1,328 @@
+"""Tensor-facing wrappers over the C ABI (``include/tio_hip.h``).
+
+PyTorch is plumbing here: it owns device memory (outputs come from the caching
+allocator), the current HIP stream and nothing else.  Every function marshals
+``torch.Tensor`` arguments into raw pointers and calls one ``tio_*`` entry point
+on the tensor's device and the current stream.  Inputs are never modified and
+outputs never alias inputs (callers with ``copy=False`` may alias user data,
+reference transform.py:220-221).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections.abc import Sequence
+
+import torch
+from torch import Tensor
+
+from . import _abi
+
+_DTYPE_CODES = {
+    torch.float32: _abi.F32,
+    torch.float64: _abi.F64,
+    torch.float16: _abi.F16,
+    torch.bfloat16: _abi.BF16,
+    torch.uint8: _abi.U8,
+    torch.int8: _abi.I8,
+    torch.int16: _abi.I16,
+    torch.int32: _abi.I32,
+    torch.int64: _abi.I64,
+}
+FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
+INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR}
+
+
+class EngineError(RuntimeError):
+    """A ``tio_*`` call returned a non-zero status."""
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODES[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported image dtype {dtype}") from None
+
+
+def _ptr(t: Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _i32x3(values) -> C.Array:
+    return (C.c_int32 * 3)(*[int(v) for v in values])
+
+
+class Engine:
+    """One loaded implementation of the C ABI bound to one device type."""
+
+    def __init__(self, functions: dict, device_type: str, name: str):
+        self._fn = functions
+        self.device_type = device_type
+        self.name = name
+
+    # -- plumbing -----------------------------------------------------------
+    def _check(self, what: str, *tensors: Tensor | None) -> None:
+        for t in tensors:
+            if t is None:
+                continue
+            if t.device.type != self.device_type:
+                raise EngineError(
+                    f"{what}: tensor on {t.device} but the {self.name} engine runs on {self.device_type} tensors"
+                )
+            if t.requires_grad:
+                raise EngineError(f"{what}: tensors that require grad are not supported by the {self.name} engine")
+
+    def _stream(self, ref: Tensor):
+        if self.device_type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+        return None
+
+    def _call(self, name: str, ref: Tensor, *args) -> None:
+        if self.device_type == "cuda" and ref.device.index != torch.cuda.current_device():
+            with torch.cuda.device(ref.device):
+                status = self._fn[name](*args)
+        else:
+            status = self._fn[name](*args)
+        if status != _abi.OK:
+            message = ""
+            if "last_error" in self._fn:
+                message = (self._fn["last_error"]() or b"").decode(errors="replace")
+            raise EngineError(f"tio_{name} failed with status {status}: {message}")
+
+    @staticmethod
+    def _flags(flags: Tensor | None, batch: int, what: str) -> Tensor | None:
+        if flags is None:
+            return None
+        if flags.dtype not in (torch.uint8, torch.bool) or flags.numel() != batch:
+            raise ValueError(f"{what} must hold {batch} uint8/bool flags")
+        return flags.to(torch.uint8).contiguous()
+
+    # -- spatial ------------------------------------------------------------
+    def resample3d(
+        self,
+        images: Sequence[Tensor],
+        *,
+        out_shape: Sequence[int],
+        mapping: Tensor,
+        control_points: Tensor | None,
+        in_spacing: Sequence[float],
+        out_spacing: Sequence[float],
+        affine_first: bool,
+        interps: Sequence[str | int],
+        fills: Sequence[Tensor | None],
+        cp_skip: Tensor | None = None,
+        passthrough: Tensor | None = None,
+    ) -> list[Tensor]:
+        """Resample every ``(B, C, I, J, K)`` tensor in *images* through one coordinate pass.
+
+        ``mapping`` is ``(1|B, 3, 4)`` float32 (output voxel → input voxel),
+        ``control_points`` ``(1|B, ni, nj, nk, 3)`` float32 in mm or ``None``;
+        ``fills[n]`` is ``None`` (zero padding, no mask) or a ``(C,)`` float32
+        tensor.  Returns new contiguous tensors ``(B, C, *out_shape)`` with the
+        input dtypes.
+        """
+        if not images:
+            return []
+        if not (len(images) == len(interps) == len(fills)):
+            raise ValueError("images, interps and fills must have the same length")
+        first = images[0]
+        if first.ndim != 5:
+            raise ValueError(f"expected (B, C, I, J, K) tensors, got {tuple(first.shape)}")
+        batch = first.shape[0]
+        in_shape = tuple(first.shape[2:])
+        out_shape = tuple(int(s) for s in out_shape)
+        mapping = mapping.to(torch.float32).contiguous()
+        if mapping.ndim != 3 or mapping.shape[1:] != (3, 4) or mapping.shape[0] not in (1, batch):
+            raise ValueError(f"mapping must be (1|B, 3, 4), got {tuple(mapping.shape)}")
+        geom = _abi.ResampleGeom()
+        geom.batch = batch
+        geom.in_shape = _i32x3(in_shape)
+        geom.out_shape = _i32x3(out_shape)
+        geom.affine_first = int(bool(affine_first))
+        geom.mapping_dev = mapping.data_ptr()
+        geom.mapping_batched = int(mapping.shape[0] == batch and batch > 1)
+        keep_alive = [mapping]
+        if control_points is not None:
+            control_points = control_points.to(torch.float32).contiguous()
+            if control_points.ndim != 5 or control_points.shape[-1] != 3 or control_points.shape[0] not in (1, batch):
+                raise ValueError(f"control_points must be (1|B, ni, nj, nk, 3), got {tuple(control_points.shape)}")
+            geom.control_points_dev = control_points.data_ptr()
+            geom.cp_batched = int(control_points.shape[0] == batch and batch > 1)
+            geom.cp_shape = _i32x3(control_points.shape[1:4])
+            keep_alive.append(control_points)
+        cp_skip = self._flags(cp_skip, batch, "cp_skip")
+        passthrough = self._flags(passthrough, batch, "passthrough")
+        geom.cp_skip_dev = None if cp_skip is None else cp_skip.data_ptr()
+        geom.passthrough_dev = None if passthrough is None else passthrough.data_ptr()
+        geom.in_spacing = (C.c_float * 3)(*[float(s) for s in in_spacing])
+        geom.out_spacing = (C.c_float * 3)(*[float(s) for s in out_spacing])
+        self._check("resample3d", mapping, control_points, cp_skip, passthrough)
+
+        outputs: list[Tensor] = []
+        for start in range(0, len(images), _abi.MAX_IMAGES):
+            chunk = range(start, min(start + _abi.MAX_IMAGES, len(images)))
+            descs = (_abi.ResampleImage * len(chunk))()
+            for slot, n in enumerate(chunk):
+                data = images[n]
+                if data.ndim != 5 or data.shape[0] != batch or tuple(data.shape[2:]) != in_shape:
+                    raise ValueError("all images must share the batch size and spatial shape")
+                data = data.contiguous()
+                fill = fills[n]
+                if fill is not None:
+                    fill = fill.to(device=data.device, dtype=torch.float32).contiguous()
+                    if fill.numel() != data.shape[1]:
+                        raise ValueError("fill must have one value per channel")
+                self._check("resample3d", data, fill)
+                out = torch.empty((batch, data.shape[1], *out_shape), dtype=data.dtype, device=data.device)
+                interp = interps[n]
+                descs[slot].in_ = data.data_ptr()
+                descs[slot].out = out.data_ptr()
+                descs[slot].channels = data.shape[1]
+                descs[slot].dtype = dtype_code(data.dtype)
+                descs[slot].interp = INTERP_CODES[interp] if isinstance(interp, str) else int(interp)
+                descs[slot].fill_dev = None if fill is None else fill.data_ptr()
+                keep_alive += [data, fill]
+                outputs.append(out)
+            self._call("resample3d", first, C.byref(geom), len(chunk), descs, self._stream(first))
+        del keep_alive
+        return outputs
+
+    def channel_min(self, data: Tensor) -> Tensor:
+        """Per-channel minimum of the first batch element as a ``(C,)`` float32 device tensor."""
+        self._check("channel_min", data)
+        first = data[0].contiguous()
+        channels = first.shape[0]
+        out = torch.empty(channels, dtype=torch.float32, device=data.device)
+        self._call(
+            "channel_min", data, _ptr(first), dtype_code(first.dtype), channels,
+            first[0].numel(), _ptr(out), self._stream(data),
+        )
+        return out
+
+    # -- intensity ----------------------------------------------------------
+    def separable_conv3d(
+        self, data: Tensor, taps: Tensor, radius: Sequence[int], skip: Tensor | None = None
+    ) -> Tensor:
+        """Per-axis cross-correlation with replicate padding; ``taps`` is ``(1|B, 3, stride)``."""
+        if data.ndim != 5:
+            raise ValueError("expected a (B, C, I, J, K) tensor")
+        if data.dtype not in FLOAT_DTYPES:
+            raise TypeError(f"separable_conv3d needs a floating dtype, got {data.dtype}")
+        batch, channels = data.shape[:2]
+        data = data.contiguous()
+        taps = taps.to(torch.float32).contiguous()
+        if taps.ndim != 3 or taps.shape[1] != 3 or taps.shape[0] not in (1, batch):
+            raise ValueError(f"taps must be (1|B, 3, stride), got {tuple(taps.shape)}")
+        skip = self._flags(skip, batch, "skip")
+        self._check("separable_conv3d", data, taps, skip)
+        out = torch.empty_like(data)
+        active = sum(1 for r in radius if int(r) > 0)
+        tmp = None
+        if active > 1:
+            tmp = torch.empty((2, *data.shape), dtype=torch.float32, device=data.device)
+        self._call(
+            "separable_conv3d", data, _ptr(data), _ptr(out), _ptr(tmp), dtype_code(data.dtype), batch, channels,
+            _i32x3(data.shape[2:]), _ptr(taps), int(taps.shape[0] == batch and batch > 1), taps.shape[2],
+            _i32x3(radius), _ptr(skip), self._stream(data),
+        )
+        return out
+
+    def bias_field_apply(
+        self, data: Tensor, coarse: Tensor, *, divide: bool = False, skip: Tensor | None = None
+    ) -> Tensor:
+        """``data * exp(trilinear_upsample(coarse))`` (or ``/``); ``coarse`` is ``(B, C, si, sj, sk)``."""
+        if data.ndim != 5 or coarse.ndim != 5 or coarse.shape[:2] != data.shape[:2]:
+            raise ValueError("data and coarse must be 5-D with the same (B, C)")
+        if data.dtype not in FLOAT_DTYPES:
+            raise TypeError(f"bias_field_apply needs a floating dtype, got {data.dtype}")
+        data = data.contiguous()
+        coarse = coarse.to(torch.float32).contiguous()
+        skip = self._flags(skip, data.shape[0], "skip")
+        self._check("bias_field_apply", data, coarse, skip)
+        out = torch.empty_like(data)
+        self._call(
+            "bias_field_apply", data, _ptr(data), _ptr(out), dtype_code(data.dtype), data.shape[0], data.shape[1],
+            _i32x3(data.shape[2:]), _ptr(coarse), _i32x3(coarse.shape[2:]), int(bool(divide)), _ptr(skip),
+            self._stream(data),
+        )
+        return out
+
+    def add_noise(
+        self,
+        data: Tensor,
+        mean: float | Tensor,
+        std: float | Tensor,
+        *,
+        rician: bool = False,
+        base1: Tensor | None = None,
+        base2: Tensor | None = None,
+        philox_seed: int = 0,
+        keep: Tensor | None = None,
+    ) -> Tensor:
+        """``data + (mean + std * z)``; ``z`` from *base1*/*base2* or in-kernel Philox when ``None``."""
+        if data.dtype not in FLOAT_DTYPES:
+            raise TypeError(f"add_noise needs a floating dtype, got {data.dtype}")
+        data = data.contiguous()
+        batch = data.shape[0]
+        batched = isinstance(mean, Tensor) or isinstance(std, Tensor)
+        mean_t = std_t = None
+        if batched:
+            mean_t = torch.as_tensor(mean, dtype=torch.float32, device=data.device).expand(batch).contiguous()
+            std_t = torch.as_tensor(std, dtype=torch.float32, device=data.device).expand(batch).contiguous()
+        for base in (base1, base2):
+            if base is not None and (base.shape != data.shape or base.dtype != torch.float32):
+                raise ValueError("base noise must be float32 and shaped like data")
+        base1 = None if base1 is None else base1.contiguous()
+        base2 = None if base2 is None else base2.contiguous()
+        keep = self._flags(keep, batch, "keep")
+        self._check("add_noise", data, mean_t, std_t, base1, base2, keep)
+        out = torch.empty_like(data)
+        n_per_element = data[0].numel() if batch else 0
+        self._call(
+            "add_noise", data, _ptr(data), _ptr(out), dtype_code(data.dtype), batch, n_per_element,
+            0.0 if batched else float(mean), 0.0 if batched else float(std), _ptr(mean_t), _ptr(std_t),
+            int(batched), int(bool(rician)), _ptr(base1), _ptr(base2), int(philox_seed) & (2**64 - 1),
+            _ptr(keep), self._stream(data),
+        )
+        return out
+
+    def philox_normal(self, shape: Sequence[int], seed: int, stream_id: int, device) -> Tensor:
+        """Standard normals of the fast noise mode (Philox4x32-10 + Box-Muller)."""
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+        self._check("philox_normal", out)
+        self._call(
+            "philox_normal", out, _ptr(out), out.numel(), int(seed) & (2**64 - 1), int(stream_id),
+            self._stream(out),
+        )
+        return out
+
+    def gamma_pow(self, data: Tensor, gamma: float | Tensor) -> Tensor:
+        """``sign(data) * |data| ** gamma`` with a scalar or per-element ``(B,)`` exponent."""
+        if data.dtype not in FLOAT_DTYPES:
+            raise TypeError(f"gamma_pow needs a floating dtype, got {data.dtype}")
+        data = data.contiguous()
+        batch = data.shape[0]
+        gamma_t = None
+        if isinstance(gamma, Tensor):
+            gamma_t = gamma.to(device=data.device, dtype=torch.float32).expand(batch).contiguous()
+        self._check("gamma_pow", data, gamma_t)
+        out = torch.empty_like(data)
+        self._call(
+            "gamma_pow", data, _ptr(data), _ptr(out), dtype_code(data.dtype), batch,
+            data[0].numel() if batch else 0, 0.0 if gamma_t is not None else float(gamma), _ptr(gamma_t),
+            int(gamma_t is not None), self._stream(data),
+        )
+        return out
+
+
+_ENGINE: Engine | None = None
+
+
+def engine() -> Engine:
+    """The HIP engine (loads ``libtio_hip.so`` on first use; raises if unavailable)."""
+    global _ENGINE
+    if _ENGINE is None:
+        from . import _lib  # noqa: PLC0415
+
+        _, functions = _lib.load()
+        _ENGINE = Engine(functions, "cuda", "hip")
+    return _ENGINE
