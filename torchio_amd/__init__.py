@@ -1,2 +1,40 @@
-"""torchio_amd — MI355X-native (gfx950) engine for TorchIO's augmentation hot path."""
+"""torchio_amd — MI355X-native (gfx950) engine for TorchIO's augmentation hot path.
+
+Drop-in for the spatial + intensity augmentation path of TorchIO 2.0
+(``Affine`` / ``ElasticDeformation`` / ``Spatial`` / ``Resample``, ``BiasField``,
+``Blur``, ``Noise``, ``Gamma``, ``Compose``, ``Subject`` / ``SubjectsBatch``):
+same class names, constructor arguments, RNG draw order, params dicts and
+history/inverse behaviour; the compute under ``apply_transform`` runs as
+hand-written HIP kernels behind the C ABI of ``include/tio_hip.h``.
+"""
+from .data import AffineMatrix
+from .data import Image
+from .data import ImagesBatch
+from .data import LabelMap
+from .data import ScalarImage
+from .data import Subject
+from .data import SubjectsBatch
+from .transforms import Affine
+from .transforms import AppliedTransform
+from .transforms import BiasField
+from .transforms import Blur
+from .transforms import Choice
+from .transforms import Compose
+from .transforms import ElasticDeformation
+from .transforms import Gamma
+from .transforms import IntensityTransform
+from .transforms import Noise
+from .transforms import Resample
+from .transforms import Spatial
+from .transforms import SpatialTransform
+from .transforms import Transform
+from .transforms import get_noise_rng
+from .transforms import set_noise_rng
+
 __version__ = "0.1.0"
+
+__all__ = [
+    "Affine", "AffineMatrix", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation",
+    "Gamma", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "Noise", "Resample", "ScalarImage",
+    "Spatial", "SpatialTransform", "Subject", "SubjectsBatch", "Transform", "get_noise_rng", "set_noise_rng",
+]

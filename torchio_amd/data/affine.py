@@ -1,0 +1,113 @@
+"""Voxel-to-world affine (mirror of reference ``src/torchio/data/affine.py:20-248``).
+
+Only what the augmentation hot path touches: a float64 4x4 on the host side,
+``spacing`` / ``origin`` / ``direction`` and conversion helpers.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import Tensor
+
+
+class AffineMatrix:
+    """4x4 float64 matrix mapping voxel indices to world (mm) coordinates."""
+
+    __slots__ = ("_matrix",)
+
+    def __init__(self, matrix=None) -> None:
+        if matrix is None:
+            value = torch.eye(4, dtype=torch.float64)
+        elif isinstance(matrix, AffineMatrix):
+            value = matrix._matrix.clone()
+        elif isinstance(matrix, Tensor):
+            value = matrix.detach().to(torch.float64).clone()
+        else:
+            value = torch.from_numpy(np.array(matrix, dtype=np.float64, copy=True))
+        if tuple(value.shape) != (4, 4):
+            raise ValueError(f"AffineMatrix must be 4x4, got {tuple(value.shape)}")
+        self._matrix = value
+
+    @classmethod
+    def from_spacing(cls, spacing, *, origin=(0.0, 0.0, 0.0), direction=None) -> "AffineMatrix":
+        matrix = torch.eye(4, dtype=torch.float64)
+        if direction is not None:
+            matrix[:3, :3] = torch.as_tensor(np.asarray(direction, dtype=np.float64))
+        matrix[:3, :3] *= torch.as_tensor(spacing, dtype=torch.float64)
+        matrix[:3, 3] = torch.as_tensor(origin, dtype=torch.float64)
+        return cls(matrix)
+
+    @property
+    def data(self) -> Tensor:
+        return self._matrix
+
+    @property
+    def device(self) -> torch.device:
+        return self._matrix.device
+
+    def _column_norms(self) -> Tensor:
+        return torch.sqrt(torch.sum(self._matrix[:3, :3] ** 2, dim=0))
+
+    @property
+    def spacing(self) -> tuple[float, float, float]:
+        norms = self._column_norms()
+        return (float(norms[0]), float(norms[1]), float(norms[2]))
+
+    @property
+    def origin(self) -> tuple[float, float, float]:
+        o = self._matrix[:3, 3]
+        return (float(o[0]), float(o[1]), float(o[2]))
+
+    @property
+    def direction(self) -> Tensor:
+        return self._matrix[:3, :3] / self._column_norms()
+
+    def to(self, *args, **kwargs) -> "AffineMatrix":
+        """Affines stay float64 and — unlike image data — on the host.
+
+        The reference moves the 4x4 along with the data (affine.py ``to``); every
+        consumer on the hot path immediately reads it back with ``float()`` /
+        ``.numpy()`` (spatial.py:1594, affine.py:104-109), i.e. one device sync
+        per access.  Keeping it on the CPU removes those syncs and changes no
+        value.
+        """
+        return self
+
+    def clone(self) -> "AffineMatrix":
+        return AffineMatrix(self._matrix)
+
+    def inverse(self) -> "AffineMatrix":
+        return AffineMatrix(torch.linalg.inv(self._matrix))
+
+    def numpy(self) -> np.ndarray:
+        return self._matrix.cpu().numpy()
+
+    def __matmul__(self, other):
+        if not isinstance(other, AffineMatrix):
+            return NotImplemented
+        return AffineMatrix(self._matrix @ other._matrix)
+
+    def __array__(self, dtype=None, copy=None):
+        array = self.numpy()
+        return array.astype(dtype) if dtype is not None else (array.copy() if copy else array)
+
+    def __eq__(self, other) -> bool:
+        if not isinstance(other, AffineMatrix):
+            return NotImplemented
+        return torch.equal(self._matrix, other._matrix)
+
+    def __hash__(self):  # pragma: no cover - identity hash like the reference's default
+        return id(self)
+
+    def __copy__(self):
+        return self.clone()
+
+    def __deepcopy__(self, memo):
+        new = self.clone()
+        memo[id(self)] = new
+        return new
+
+    def __repr__(self) -> str:
+        sp = ", ".join(f"{s:.2f}" for s in self.spacing)
+        o = ", ".join(f"{v:.2f}" for v in self.origin)
+        return f"AffineMatrix(spacing=({sp}), origin=({o}))"

@@ -1,0 +1,23 @@
+from .bias_field import BiasField
+from .blur import Blur
+from .compose import Compose
+from .gamma import Gamma
+from .inverse import get_inverse_transform
+from .noise import Noise
+from .noise import get_noise_rng
+from .noise import set_noise_rng
+from .parameter_range import Choice
+from .spatial import Affine
+from .spatial import ElasticDeformation
+from .spatial import Resample
+from .spatial import Spatial
+from .transform import AppliedTransform
+from .transform import IntensityTransform
+from .transform import SpatialTransform
+from .transform import Transform
+
+__all__ = [
+    "Affine", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Gamma",
+    "IntensityTransform", "Noise", "Resample", "Spatial", "SpatialTransform", "Transform",
+    "get_inverse_transform", "get_noise_rng", "set_noise_rng",
+]

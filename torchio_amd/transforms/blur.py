@@ -1,0 +1,126 @@
+"""``Blur`` on the HIP engine (mirror of reference ``transforms/intensity/blur.py``).
+
+The host builds the 1-D Gaussian taps with the same float32 torch expressions as
+the reference (blur.py:179-183 shared, blur.py:292-328 per element: zero-extended
+to the largest radius, delta for sigma = 0, normalised); the replicate-padded
+separable cross-correlation itself (blur.py:185-203, 234-247) is one
+``tio_separable_conv3d`` call instead of three ``F.pad`` + ``F.conv3d`` pairs.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import ops
+from ..data.batch import SubjectsBatch
+from .parameter_range import to_nonneg_range
+from .transform import IntensityTransform
+
+
+class Blur(IntensityTransform):
+    """Gaussian blur with per-axis standard deviations in mm (blur.py:19-90)."""
+
+    def __init__(self, *, std=0.0, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.std = to_nonneg_range(std)
+        self._warn_if_noop(is_noop=self.std.is_constant(0.0), hint="std=(0, 2)")
+
+    @property
+    def supports_per_instance_params(self) -> bool:
+        return True
+
+    @property
+    def supports_per_instance_p(self) -> bool:
+        return True
+
+    def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
+        n = self._resolve_n(batch)
+        if n is None:
+            return {"std": self.std.sample()}
+        keep = self._keep_mask(batch, n)
+        std = self.std.sample(n)
+        if keep is not None:
+            std[~keep] = 0.0
+        params = {"std": self._serialize_param(std)}
+        self._tag_batched(params, batch, n, keep, ["std"])
+        return params
+
+    def apply_transform(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
+        per_instance = self._is_per_instance_params(params)
+        for img_batch in self._get_images(batch).values():
+            if per_instance:
+                sigmas_mm = np.asarray(params["std"], dtype=np.float64)
+                spacings = np.asarray([affine.spacing for affine in img_batch.affines], dtype=np.float64)
+                sigmas = np.divide(sigmas_mm, spacings, out=np.zeros_like(sigmas_mm), where=spacings > 0)
+            else:
+                spacing = np.asarray(img_batch.affines[0].spacing, dtype=np.float64)
+                sigmas = [s / sp if sp > 0 else 0.0 for s, sp in zip(params["std"], spacing, strict=True)]
+            img_batch.data = _gaussian_smooth(img_batch.data, sigmas)
+        return batch
+
+
+def _gaussian_smooth(data: Tensor, sigmas) -> Tensor:
+    """Separable Gaussian smoothing of a ``(B, C, I, J, K)`` tensor (functional seam S2, blur.py:129-154).
+
+    *sigmas* is per-axis (length 3, voxels) or per-element ``(B, 3)``; zero skips
+    an axis.  Computed in float32, returned in the input dtype.
+    """
+    sigmas = np.asarray(sigmas, dtype=np.float64)
+    if np.all(sigmas <= 0):
+        return data
+    if sigmas.ndim == 2 and np.all(sigmas == sigmas[0]):
+        sigmas = sigmas[0]  # identical rows collapse to the shared kernel set (blur.py:150-153)
+    taps, radius, skip = _stacked_gaussian_taps(sigmas if sigmas.ndim == 2 else sigmas[None], per_element=sigmas.ndim == 2)
+    work = data if data.dtype in ops.FLOAT_DTYPES else data.float()
+    skip_flags = None if skip is None else torch.from_numpy(skip).to(data.device)
+    result = ops.engine().separable_conv3d(work, taps.to(data.device), radius, skip=skip_flags)
+    if result.dtype != data.dtype:
+        result = result.to(data.dtype)
+        if skip is not None:  # untouched rows keep their exact integer values
+            rows = torch.from_numpy(skip.astype(bool)).to(data.device)
+            result[rows] = data[rows]
+    return result
+
+
+def _stacked_gaussian_taps(sigmas: np.ndarray, per_element: bool = False):
+    """Normalised 1-D kernels for every (element, axis): ``(n, 3, stride)`` float32 taps.
+
+    Returns ``(taps, radius[3], skip)``; ``radius[a]`` is the largest radius on axis
+    ``a`` (0 = axis inactive for every element) and ``skip`` flags elements whose
+    three sigmas are all <= 0 (restored bit-exactly, blur.py:249-251).
+    """
+    n = sigmas.shape[0]
+    radii = np.zeros((n, 3), dtype=np.int64)
+    positive = sigmas > 0
+    radii[positive] = np.maximum(np.ceil(3 * sigmas[positive]).astype(np.int64), 1)
+    radius = [int(radii[:, axis].max()) for axis in range(3)]
+    stride = 2 * max(radius) + 1
+    taps = torch.zeros(n, 3, stride, dtype=torch.float32)
+    for axis in range(3):
+        r = radius[axis]
+        if r == 0:
+            continue
+        offsets = torch.arange(2 * r + 1, dtype=torch.float32) - r
+        if not per_element:
+            sigma = float(sigmas[0, axis])
+            kernel = torch.exp(-0.5 * (offsets / sigma) ** 2)
+            taps[0, axis, : 2 * r + 1] = kernel / kernel.sum()
+            continue
+        sigma_column = torch.as_tensor(sigmas[:, axis], dtype=torch.float32)[:, None]
+        radius_column = torch.as_tensor(radii[:, axis])[:, None]
+        safe = torch.where(sigma_column > 0, sigma_column, torch.ones_like(sigma_column))
+        kernels = torch.exp(-0.5 * (offsets[None, :] / safe) ** 2)
+        kernels = torch.where(offsets[None, :].abs() <= radius_column, kernels, torch.zeros_like(kernels))
+        delta = torch.zeros_like(kernels)
+        delta[:, r] = 1.0
+        kernels = torch.where(sigma_column > 0, kernels, delta)
+        taps[:, axis, : 2 * r + 1] = kernels / kernels.sum(dim=1, keepdim=True)
+    skip = None
+    if per_element:
+        no_blur = np.all(sigmas <= 0, axis=1)
+        if no_blur.any():
+            skip = no_blur.astype(np.uint8)
+    return taps, radius, skip

@@ -1,0 +1,113 @@
+"""``Noise`` on the HIP engine (mirror of reference ``transforms/intensity/noise.py``).
+
+Two sources for the standard-normal draws:
+
+``"reference"`` (default)
+    exactly the reference: ``torch.randn(data.shape, generator=cpu_gen)`` from ONE
+    CPU generator seeded with ``params["seed"]``, shared by the images in dict
+    order (noise.py:108-116,177), copied to the device; bit-identical output.
+``"philox"``
+    the draws are generated inside the kernel (Philox4x32-10 + Box-Muller keyed by
+    ``seed`` and the element index): no host RNG, no 64 MiB H2D per volume.  Same
+    distribution, different stream — results are NOT reference-identical.
+
+Select with :func:`set_noise_rng` (or ``TIO_NOISE_RNG``); the transform signature
+is untouched so ``repr`` / history stay compatible.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any
+
+import torch
+from torch import Tensor
+
+from .. import ops
+from ..data.batch import SubjectsBatch
+from .parameter_range import to_nonneg_range
+from .parameter_range import to_range
+from .transform import IntensityTransform
+
+_NOISE_RNG = os.environ.get("TIO_NOISE_RNG", "reference")
+
+
+def set_noise_rng(mode: str) -> None:
+    """``"reference"`` (seeded CPU mt19937 draws, parity) or ``"philox"`` (in-kernel draws)."""
+    global _NOISE_RNG
+    if mode not in ("reference", "philox"):
+        raise ValueError('noise rng must be "reference" or "philox"')
+    _NOISE_RNG = mode
+
+
+def get_noise_rng() -> str:
+    return _NOISE_RNG
+
+
+class Noise(IntensityTransform):
+    """Additive Gaussian (or Rician) noise (noise.py:18-123)."""
+
+    def __init__(self, *, mean=0.0, std=0.25, rician: bool = False, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.mean = to_range(mean)
+        self.std = to_nonneg_range(std)
+        self.rician = rician
+
+    @property
+    def supports_per_instance_params(self) -> bool:
+        return True
+
+    @property
+    def supports_per_instance_p(self) -> bool:
+        return True
+
+    def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
+        seed = int(torch.randint(0, 2**31, (1,)).item())  # seed FIRST, then mean, std (noise.py:75-80)
+        n = self._resolve_n(batch)
+        keep = self._keep_mask(batch, n)
+        mean = self._mask_identity(self.mean.sample_1d(n), keep, identity=0.0)
+        std = self._mask_identity(self.std.sample_1d(n), keep, identity=0.0)
+        params = {
+            "mean": self._serialize_param(mean),
+            "std": self._serialize_param(std),
+            "seed": seed,
+            "rician": self.rician,
+        }
+        self._tag_batched(params, batch, n, keep, ["mean", "std"])
+        return params
+
+    def apply_transform(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
+        mean, std, seed = params["mean"], params["std"], params["seed"]
+        rician = params.get("rician", False)
+        keep = params.get("_keep")
+        generator = torch.Generator(device="cpu")
+        generator.manual_seed(seed)
+        engine = ops.engine()
+        for index, img_batch in enumerate(self._get_images(batch).values()):
+            data = img_batch.data
+            # data + float32 noise promotes half / integer data to float32 (noise.py:119)
+            work = data if data.dtype in (torch.float32, torch.float64) else data.float()
+            device = data.device
+            mean_arg = torch.tensor(mean, dtype=torch.float32).to(device) if isinstance(mean, list) else mean
+            std_arg = torch.tensor(std, dtype=torch.float32).to(device) if isinstance(std, list) else std
+            keep_arg = None if keep is None else torch.tensor(keep, dtype=torch.uint8).to(device)
+            if _NOISE_RNG == "reference":
+                base1 = torch.randn(data.shape, generator=generator).to(device)
+                base2 = torch.randn(data.shape, generator=generator).to(device) if rician else None
+                img_batch.data = engine.add_noise(
+                    work, mean_arg, std_arg, rician=rician, base1=base1, base2=base2, keep=keep_arg
+                )
+            else:
+                img_batch.data = engine.add_noise(
+                    work, mean_arg, std_arg, rician=rician, philox_seed=(index << 32) | int(seed), keep=keep_arg
+                )
+        return batch
+
+
+def _sample_noise(data: Tensor, mean, std, generator: torch.Generator) -> Tensor:
+    """``mean + std * N(0, 1)`` shaped like *data* from a CPU generator (functional seam S4, noise.py:166-178).
+
+    Kept for API parity with the reference; the transform itself hands the raw
+    draws to the kernel, which applies ``mean + std * z`` in the same order.
+    """
+    base = torch.randn(data.shape, generator=generator).to(data.device)
+    return mean + std * base

@@ -1,0 +1,165 @@
+"""Scalar-or-range transform parameters (mirror of reference ``transforms/parameter_range.py``).
+
+This module fixes the ORDER in which the global CPU RNG is consumed, which is
+what makes ``torch.manual_seed(k)`` reproduce the reference's sampled parameters
+(SURVEY.md §8c "Global-RNG draw order"): one ``uniform_`` draw per
+non-degenerate axis, none for constants or ``lo == hi`` (parameter_range.py:91-137).
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import torch
+from torch.distributions import Distribution
+
+
+class Choice:
+    """A discrete set of values to sample from (parameter_range.py:27-82)."""
+
+    def __init__(self, values: Sequence[float | int], probabilities: Sequence[float] | None = None) -> None:
+        if len(values) < 1:
+            raise ValueError("Choice requires at least one value")
+        self._values = torch.tensor([float(v) for v in values])
+        if probabilities is None:
+            self._probs = torch.ones(len(values)) / len(values)
+        else:
+            if len(probabilities) != len(values):
+                raise ValueError(f"Expected {len(values)} probabilities, got {len(probabilities)}")
+            self._probs = torch.tensor([float(p) for p in probabilities])
+
+    def sample(self) -> float:
+        index = int(torch.multinomial(self._probs, 1).item())
+        return float(self._values[index])
+
+    def sample_batched(self, n: int) -> torch.Tensor:
+        return self._values[torch.multinomial(self._probs, n, replacement=True)]
+
+    def __repr__(self) -> str:
+        values = ", ".join(f"{v:.1f}" if v == int(v) else f"{v}" for v in self._values.tolist())
+        if torch.allclose(self._probs, self._probs[0].expand_as(self._probs)):
+            return f"Choice([{values}])"
+        probs = ", ".join(f"{p:.2f}" for p in self._probs.tolist())
+        return f"Choice([{values}], p=[{probs}])"
+
+
+def _is_number(x) -> bool:
+    return isinstance(x, (int, float))
+
+
+def _draw(spec, n: int | None, generator):
+    """One draw (``n is None`` → float) or ``n`` draws (→ ``(n,)`` tensor) from an axis spec."""
+    if _is_number(spec):
+        return float(spec) if n is None else torch.full((n,), float(spec))
+    if isinstance(spec, Choice):
+        return spec.sample() if n is None else spec.sample_batched(n)
+    if isinstance(spec, Distribution):
+        if n is None:
+            return spec.sample().item()
+        return spec.sample((n,)).reshape(n).to(torch.float32)
+    low, high = spec
+    if low == high:
+        return float(low) if n is None else torch.full((n,), float(low))
+    drawn = torch.empty(1 if n is None else n).uniform_(float(low), float(high), generator=generator)
+    return drawn.item() if n is None else drawn
+
+
+def _parse_axis(spec):
+    if _is_number(spec):
+        return float(spec)
+    if isinstance(spec, (Choice, Distribution)):
+        return spec
+    if isinstance(spec, tuple) and len(spec) == 2 and _is_number(spec[0]) and _is_number(spec[1]):
+        return (float(spec[0]), float(spec[1]))
+    raise TypeError(
+        f"Per-axis spec must be a float, (lo, hi) tuple, Choice, or Distribution, got {type(spec).__name__}"
+    )
+
+
+def _parse_tuple(value: tuple):
+    n = len(value)
+    if n == 3:
+        if all(_is_number(v) for v in value):
+            return tuple(float(v) for v in value)
+        return tuple(_parse_axis(v) for v in value)
+    if not all(_is_number(v) for v in value):
+        raise ValueError(f"Mixed per-axis specs require exactly 3 elements, got {n}")
+    if n == 1:
+        return (float(value[0]),) * 3
+    if n == 2:
+        return ((float(value[0]), float(value[1])),) * 3
+    if n == 6:
+        return tuple((float(value[2 * a]), float(value[2 * a + 1])) for a in range(3))
+    raise ValueError(f"Tuple must have 1, 2, 3, or 6 elements, got {n}")
+
+
+class _ParameterRange:
+    """Three per-axis specs parsed from ``float | (lo, hi) | (a, b, c) | 6-tuple | Choice | Distribution``."""
+
+    def __init__(self, value) -> None:
+        self._original = value
+        if _is_number(value):
+            self._axes = (float(value),) * 3
+        elif isinstance(value, (Choice, Distribution)):
+            self._axes = (value,) * 3
+        elif isinstance(value, tuple):
+            self._axes = _parse_tuple(value)
+        else:
+            raise TypeError(f"Expected float, tuple, Distribution, or Choice, got {type(value).__name__}")
+
+    @property
+    def is_deterministic(self) -> bool:
+        return all(_is_number(a) for a in self._axes)
+
+    def is_constant(self, value: float) -> bool:
+        for axis in self._axes:
+            if _is_number(axis):
+                if float(axis) != float(value):
+                    return False
+            elif isinstance(axis, tuple):
+                if not (axis[0] == axis[1] == value):
+                    return False
+            else:
+                return False
+        return True
+
+    @property
+    def _ranges(self):
+        out = []
+        for axis in self._axes:
+            if _is_number(axis):
+                out.append((float(axis), float(axis)))
+            elif isinstance(axis, tuple):
+                out.append(axis)
+            else:
+                out.append((0.0, 0.0))
+        return tuple(out)
+
+    @property
+    def _distribution(self):
+        return self._axes[0] if isinstance(self._axes[0], Distribution) else None
+
+    def sample(self, n: int | None = None, *, generator: torch.Generator | None = None):
+        """A 3-tuple of floats, or an ``(n, 3)`` tensor (axis 0 drawn first, then 1, then 2)."""
+        drawn = [_draw(axis, n, generator) for axis in self._axes]
+        return tuple(drawn) if n is None else torch.stack(drawn, dim=-1)
+
+    def sample_1d(self, n: int | None = None, *, generator: torch.Generator | None = None):
+        """One float (first axis spec), or an ``(n,)`` tensor."""
+        return _draw(self._axes[0], n, generator)
+
+    def __repr__(self) -> str:
+        v = self._original
+        if isinstance(v, tuple):
+            return "(" + ", ".join(repr(x) for x in v) + ")"
+        return repr(v) if isinstance(v, (Distribution, Choice)) else str(v)
+
+
+def to_range(value) -> _ParameterRange:
+    return _ParameterRange(value)
+
+
+def to_nonneg_range(value) -> _ParameterRange:
+    parsed = _ParameterRange(value)
+    if parsed._distribution is None and any(lo < 0 or hi < 0 for lo, hi in parsed._ranges):
+        raise ValueError(f"Value must be non-negative, got {value}")
+    return parsed

@@ -1,0 +1,870 @@
+"""Unified spatial transforms on the HIP engine.
+
+Host-side mirror of reference ``src/torchio/transforms/spatial/spatial.py``:
+``Spatial`` / ``Resample`` / ``Affine`` / ``ElasticDeformation`` with the same
+constructor arguments, the same ``make_params`` draw order on the global CPU RNG
+(spatial.py:382-558) and the same JSON-serialisable params dict
+(spatial.py:455-513), so seeds, history, unbatching and inversion behave like the
+reference.  What changes is everything under ``apply_transform``: instead of
+materialising an ``(I, J, K, 3)`` grid and calling ``F.grid_sample`` twice
+(spatial.py:1504-1731), ``_apply_spatial_to_batch`` hands the engine twelve
+floats per element (and the control points) and every selected image is
+resampled by ONE fused kernel launch (``tio_resample3d``).
+
+Not implemented on the engine (raise, never fall back): interpolation orders
+>= 2 (reference uses torch-interpol, spatial.py:1734-1761) and the ``"label"``
+partial-volume mode (spatial.py:1275-1389).
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass
+from numbers import Number
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.distributions import Distribution
+
+from .. import ops
+from ..data.affine import AffineMatrix
+from ..data.batch import ImagesBatch
+from ..data.batch import SubjectsBatch
+from ..data.image import Image
+from ..data.image import LabelMap
+from .blur import _stacked_gaussian_taps
+from .parameter_range import Choice
+from .parameter_range import _ParameterRange
+from .transform import SpatialTransform
+
+LABEL_INTERPOLATION = "label"
+_ORDERS = {"nearest": 0, "linear": 1, "quadratic": 2, "cubic": 3, "fourth": 4, "fifth": 5, "sixth": 6, "seventh": 7}
+_SUPPORTED_INTERPOLATIONS = (*_ORDERS, LABEL_INTERPOLATION)
+_SUPPORTED_PAD_VALUES = ("minimum", "mean", "otsu")
+_SPLINE_ORDER = 3
+
+
+@dataclass
+class _PerSampleGrids:
+    """Per-element geometry for per-instance augmentation (spatial.py:49-65)."""
+
+    affine_matrices: list[np.ndarray | None]
+    control_points: list[Tensor | None]
+    max_displacements: list[tuple[float, float, float] | None]
+
+
+class Spatial(SpatialTransform):
+    r"""Resampling, affine motion and elastic deformation in a single resampling pass.
+
+    Arguments and semantics follow reference ``Spatial`` (spatial.py:158-369).
+    """
+
+    def __init__(
+        self,
+        *,
+        target=None,
+        scales=1.0,
+        degrees=0.0,
+        translation=0.0,
+        isotropic: bool = False,
+        center: str = "image",
+        control_points=None,
+        num_control_points: int | tuple[int, int, int] = 7,
+        max_displacement=0.0,
+        locked_borders: int = 2,
+        affine_first: bool = True,
+        image_interpolation: str | int = "linear",
+        label_interpolation: str | int = "nearest",
+        one_hot_label_interpolation: str | int = "linear",
+        antialias: bool = False,
+        default_pad_value: str | float = "minimum",
+        default_pad_label: int | float = 0,
+        **kwargs: Any,
+    ) -> None:
+        super().__init__(**kwargs)
+        self.target = target
+        if isotropic and not isinstance(scales, Distribution) and isinstance(scales, tuple) and len(scales) in (3, 6):
+            raise ValueError("If isotropic=True, scales must be a single value or a 2-value range")
+        self.scales = _positive_range(scales)
+        self.degrees = _parameter_range(degrees)
+        self.translation = _parameter_range(translation)
+        self.isotropic = isotropic
+        if center not in ("image", "origin"):
+            raise ValueError(f'center must be "image" or "origin", got "{center}"')
+        self.center = center
+        self.control_points = None if control_points is None else _parse_control_points(control_points)
+        self.num_control_points = _parse_num_control_points(num_control_points)
+        self.max_displacement = _nonnegative_range(max_displacement)
+        if locked_borders not in (0, 1, 2):
+            raise ValueError(f"locked_borders must be 0, 1, or 2, got {locked_borders}")
+        self.locked_borders = locked_borders
+        if self.locked_borders == 2 and 4 in self.num_control_points:
+            raise ValueError("locked_borders=2 with 4 control points along any axis yields an identity elastic field")
+        self.affine_first = affine_first
+        parsed = _parse_interpolation(image_interpolation)
+        if parsed == LABEL_INTERPOLATION:
+            raise ValueError(
+                f'image_interpolation cannot be "{LABEL_INTERPOLATION}"; that mode is only valid for label_interpolation'
+            )
+        self.image_interpolation = parsed
+        self.label_interpolation = _parse_interpolation(label_interpolation)
+        one_hot = _parse_interpolation(one_hot_label_interpolation)
+        if one_hot == LABEL_INTERPOLATION:
+            raise ValueError(f'one_hot_label_interpolation cannot be "{LABEL_INTERPOLATION}"')
+        self.one_hot_label_interpolation = one_hot
+        self.antialias = antialias
+        self.default_pad_value = _parse_default_pad_value(default_pad_value)
+        if not isinstance(default_pad_label, Number):
+            raise TypeError(f"default_pad_label must be numeric, got {type(default_pad_label)}")
+        self.default_pad_label = float(default_pad_label)
+
+    @property
+    def supports_per_instance_params(self) -> bool:
+        return True
+
+    @property
+    def supports_per_instance_p(self) -> bool:
+        # per-element gating needs a shape-preserving transform (spatial.py:375-380)
+        return self.target is None
+
+    # -- sampling: global-RNG order is scales, degrees, translation, max_displacement,
+    #    control points (spatial.py:382-434) ----------------------------------
+    def _sample_one(self, shape, affine):
+        if self.isotropic:
+            value = self.scales.sample_1d()
+            scales = (value, value, value)
+        else:
+            scales = self.scales.sample()
+        degrees = self.degrees.sample()
+        translation = self.translation.sample()
+        has_affine = not (
+            np.allclose(scales, (1.0, 1.0, 1.0))
+            and np.allclose(degrees, (0.0, 0.0, 0.0))
+            and np.allclose(translation, (0.0, 0.0, 0.0))
+        )
+        if self.control_points is not None:
+            field = self.control_points.clone()
+            displacement = _max_abs_displacement(field)
+        else:
+            displacement = self.max_displacement.sample()
+            if all(value == 0.0 for value in displacement):
+                field, displacement = None, None
+            else:
+                field = _sample_control_points(self.num_control_points, displacement, self.locked_borders)
+        forward = None
+        if has_affine:
+            forward = _build_forward_affine(
+                scales=scales, degrees=degrees, translation=translation, center=self.center, shape=shape, affine=affine
+            )
+        return forward, field, displacement, (has_affine or field is not None)
+
+    def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
+        images = self._get_images(batch)
+        if not images:
+            return {"selected_images": []}
+        first = next(iter(images.values()))
+        shape, affine = _spatial_shape(first), first.affines[0]
+        params: dict[str, Any] = {
+            "selected_images": list(images),
+            "original": _serialize_space((shape, affine)),
+            "affine_first": self.affine_first,
+            "image_interpolation": self.image_interpolation,
+            "label_interpolation": self.label_interpolation,
+            "one_hot_label_interpolation": self.one_hot_label_interpolation,
+            "antialias": self.antialias,
+            "default_pad_value": self.default_pad_value,
+            "default_pad_label": self.default_pad_label,
+        }
+        n = self._resolve_n(batch)
+        if n is None:
+            forward, field, displacement, has_geometry = self._sample_one(shape, affine)
+            if has_geometry:
+                _check_shared_space(images, shape, affine)
+            # the (possibly random) target is resolved AFTER the geometry (spatial.py:474-481)
+            params["target"] = _serialize_space(_resolve_target_space(self.target, batch, shape, affine))
+            params["affine_matrix"] = None if forward is None else forward.tolist()
+            params["control_points"] = None if field is None else field.cpu().tolist()
+            params["max_displacement"] = list(displacement) if displacement else None
+            return params
+
+        keep = self._keep_mask(batch, n)
+        matrices, fields, displacements, any_geometry = [], [], [], False
+        for index in range(n):
+            if keep is not None and not bool(keep[index]):
+                matrices.append(None), fields.append(None), displacements.append(None)
+                continue
+            forward, field, displacement, has_geometry = self._sample_one(shape, affine)
+            any_geometry = any_geometry or has_geometry
+            matrices.append(None if forward is None else forward.tolist())
+            fields.append(None if field is None else field.cpu().tolist())
+            displacements.append(list(displacement) if displacement else None)
+        if any_geometry:
+            _check_shared_space(images, shape, affine)
+        params["target"] = _serialize_space(_resolve_target_space(self.target, batch, shape, affine))
+        params["affine_matrix"] = matrices
+        params["control_points"] = fields
+        params["max_displacement"] = displacements
+        self._tag_batched(params, batch, n, keep, ["affine_matrix", "control_points", "max_displacement"])
+        return params
+
+    def apply_transform(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
+        selected = params.get("selected_images", [])
+        if not selected:
+            return batch
+        target_space = _deserialize_space(params["target"])
+        matrix, field, displacement, per_sample = _resolve_spatial_params(params)
+        if target_space is None and matrix is None and field is None and displacement is None and per_sample is None:
+            return batch  # exact no-op: nothing sampled / every element gated out (spatial.py:579-590)
+        _apply_spatial_to_batch(
+            batch=batch,
+            image_names=selected,
+            target_space=target_space,
+            affine_matrix=matrix,
+            control_points=field,
+            max_displacement=displacement,
+            affine_first=params["affine_first"],
+            image_interpolation=params["image_interpolation"],
+            label_interpolation=params["label_interpolation"],
+            one_hot_label_interpolation=params.get("one_hot_label_interpolation", "linear"),
+            antialias=params.get("antialias", False),
+            default_pad_value=params["default_pad_value"],
+            default_pad_label=float(params["default_pad_label"]),
+            per_sample=per_sample,
+        )
+        return batch
+
+    @property
+    def invertible(self) -> bool:
+        return True
+
+    def inverse(self, params: dict[str, Any]) -> "_SpatialInverse":
+        """Exact inverse affine, negated elastic field, flipped order, back to the original grid."""
+        original = _deserialize_space(params["original"])
+        if original is None:
+            raise RuntimeError("Spatial inverse needs the original output space")
+        common: dict[str, Any] = {
+            "target": original,
+            "affine_first": not params["affine_first"],
+            "image_interpolation": params["image_interpolation"],
+            "label_interpolation": params["label_interpolation"],
+            "one_hot_label_interpolation": params.get("one_hot_label_interpolation", "linear"),
+            "default_pad_value": params["default_pad_value"],
+            "default_pad_label": float(params["default_pad_label"]),
+            "copy": False,
+            "include": params["selected_images"],
+        }
+        if "affine_matrix" in (params.get("_batched_keys") or []):
+            matrices, fields, displacements = [], [], []
+            for matrix, field in zip(params["affine_matrix"], params["control_points"], strict=True):
+                matrices.append(None if matrix is None else np.linalg.inv(np.asarray(matrix, dtype=np.float64)))
+                negated = None if field is None else -torch.as_tensor(field, dtype=torch.float32)
+                fields.append(negated)
+                displacements.append(None if negated is None else _max_abs_displacement(negated))
+            per_sample = _PerSampleGrids(matrices, fields, displacements)
+            return _SpatialInverse(affine_matrix=None, control_points=None, per_sample=per_sample, **common)
+        matrix = params["affine_matrix"]
+        field = params["control_points"]
+        return _SpatialInverse(
+            affine_matrix=None if matrix is None else np.linalg.inv(np.asarray(matrix, dtype=np.float64)),
+            control_points=None if field is None else -torch.as_tensor(field, dtype=torch.float32),
+            **common,
+        )
+
+
+class _SpatialInverse(SpatialTransform):
+    """Concrete inverse of ``Spatial`` used by history replay (spatial.py:679-756)."""
+
+    def __init__(
+        self,
+        *,
+        target,
+        affine_matrix,
+        control_points,
+        affine_first: bool,
+        image_interpolation: str,
+        label_interpolation: str,
+        one_hot_label_interpolation: str = "linear",
+        default_pad_value,
+        default_pad_label: float,
+        per_sample: _PerSampleGrids | None = None,
+        **kwargs: Any,
+    ) -> None:
+        super().__init__(**kwargs)
+        self.target = target
+        self.affine_matrix = None if affine_matrix is None else np.array(affine_matrix, dtype=np.float64)
+        self.control_points = None if control_points is None else _parse_control_points(control_points)
+        self.per_sample = per_sample
+        self.affine_first = affine_first
+        self.image_interpolation = _parse_interpolation(image_interpolation)
+        self.label_interpolation = _parse_interpolation(label_interpolation)
+        self.one_hot_label_interpolation = _parse_interpolation(one_hot_label_interpolation)
+        self.default_pad_value = _parse_default_pad_value(default_pad_value)
+        self.default_pad_label = float(default_pad_label)
+
+    def apply_transform(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
+        displacement = None
+        if self.per_sample is None and self.control_points is not None:
+            displacement = _max_abs_displacement(self.control_points)
+        _apply_spatial_to_batch(
+            batch=batch,
+            image_names=list(self._get_images(batch)),
+            target_space=self.target,
+            affine_matrix=self.affine_matrix,
+            control_points=self.control_points,
+            max_displacement=displacement,
+            affine_first=self.affine_first,
+            image_interpolation=self.image_interpolation,
+            label_interpolation=self.label_interpolation,
+            one_hot_label_interpolation=self.one_hot_label_interpolation,
+            antialias=False,
+            default_pad_value=self.default_pad_value,
+            default_pad_label=self.default_pad_label,
+            per_sample=self.per_sample,
+        )
+        return batch
+
+
+class Resample(Spatial):
+    """Resampling-only convenience wrapper (spatial.py:759-803); default target 1 mm isotropic."""
+
+    def __init__(
+        self,
+        target=1,
+        image_interpolation: str | int = "linear",
+        label_interpolation: str | int = "nearest",
+        one_hot_label_interpolation: str | int = "linear",
+        antialias: bool = False,
+        **kwargs: Any,
+    ) -> None:
+        super().__init__(
+            target=target,
+            image_interpolation=image_interpolation,
+            label_interpolation=label_interpolation,
+            one_hot_label_interpolation=one_hot_label_interpolation,
+            antialias=antialias,
+            **kwargs,
+        )
+
+
+class Affine(Spatial):
+    """Affine-only convenience wrapper (spatial.py:806-869)."""
+
+    def __init__(
+        self,
+        *,
+        scales=1.0,
+        degrees=0.0,
+        translation=0.0,
+        isotropic: bool = False,
+        center: str = "image",
+        default_pad_value: str | float = "minimum",
+        default_pad_label: int | float = 0,
+        image_interpolation: str | int = "linear",
+        label_interpolation: str | int = "nearest",
+        one_hot_label_interpolation: str | int = "linear",
+        **kwargs: Any,
+    ) -> None:
+        super().__init__(
+            scales=scales,
+            degrees=degrees,
+            translation=translation,
+            isotropic=isotropic,
+            center=center,
+            default_pad_value=default_pad_value,
+            default_pad_label=default_pad_label,
+            image_interpolation=image_interpolation,
+            label_interpolation=label_interpolation,
+            one_hot_label_interpolation=one_hot_label_interpolation,
+            **kwargs,
+        )
+        self._warn_if_noop(
+            is_noop=self.scales.is_constant(1.0) and self.degrees.is_constant(0.0) and self.translation.is_constant(0.0),
+            hint="degrees=(-15, 15)",
+        )
+
+
+class ElasticDeformation(Spatial):
+    """Elastic-only convenience wrapper (spatial.py:872-922); default 7.5 mm on 7^3 control points."""
+
+    def __init__(
+        self,
+        *,
+        control_points=None,
+        num_control_points: int | tuple[int, int, int] = 7,
+        max_displacement=7.5,
+        locked_borders: int = 2,
+        image_interpolation: str | int = "linear",
+        label_interpolation: str | int = "nearest",
+        one_hot_label_interpolation: str | int = "linear",
+        **kwargs: Any,
+    ) -> None:
+        super().__init__(
+            control_points=control_points,
+            num_control_points=num_control_points,
+            max_displacement=max_displacement,
+            locked_borders=locked_borders,
+            image_interpolation=image_interpolation,
+            label_interpolation=label_interpolation,
+            one_hot_label_interpolation=one_hot_label_interpolation,
+            **kwargs,
+        )
+
+
+# =============================================================================
+# functional seam S1: _apply_spatial_to_batch on the engine
+# =============================================================================
+def _apply_spatial_to_batch(
+    *,
+    batch: SubjectsBatch,
+    image_names: list[str],
+    target_space,
+    affine_matrix: np.ndarray | None,
+    control_points: Tensor | None,
+    max_displacement,
+    affine_first: bool,
+    image_interpolation: str,
+    label_interpolation: str,
+    one_hot_label_interpolation: str = "linear",
+    antialias: bool,
+    default_pad_value,
+    default_pad_label: float,
+    per_sample: _PerSampleGrids | None = None,
+) -> None:
+    """Resample every selected image of *batch* with one fused launch (spatial.py:1110-1272).
+
+    Same keyword signature as the reference function.  The geometry comes from the
+    first image (shape, affine); all selected images share it (checked in
+    ``make_params``).  With *per_sample* every batch element gets its own 3x4
+    mapping / control-point field; elements with no geometry and no target are
+    passed through bit-exactly (spatial.py:1167-1174).
+    """
+    if not image_names:
+        return
+    first = batch.images[image_names[0]]
+    device = first.data.device
+    batch_size = first.batch_size
+    in_shape, in_affine = _spatial_shape(first), first.affines[0]
+    out_shape, out_affine = target_space if target_space is not None else (in_shape, in_affine)
+
+    if per_sample is None:
+        matrices = [affine_matrix]
+        fields = [control_points]
+        displacements = [max_displacement]
+    else:
+        if len(per_sample.affine_matrices) != batch_size:
+            raise RuntimeError(
+                f"Per-instance spatial parameters were recorded for {len(per_sample.affine_matrices)}"
+                f" elements but the batch has {batch_size}"
+            )
+        matrices, fields, displacements = per_sample.affine_matrices, per_sample.control_points, per_sample.max_displacements
+
+    # output voxel -> input voxel: inv(A_in) @ inv(T) @ A_out in float64, cast to float32 (spatial.py:1582-1601)
+    in_inverse = np.linalg.inv(in_affine.numpy())
+    out_matrix = out_affine.numpy()
+    mapping = np.empty((len(matrices), 3, 4), dtype=np.float32)
+    for index, matrix in enumerate(matrices):
+        transform_inverse = np.eye(4) if matrix is None else np.linalg.inv(np.asarray(matrix, dtype=np.float64))
+        mapping[index] = (in_inverse @ transform_inverse @ out_matrix)[:3].astype(np.float32)
+
+    out_spacing = np.asarray(out_affine.spacing, dtype=np.float64)
+    field_tensor = None
+    cp_skip = None
+    present = [f for f in fields if f is not None]
+    if present:
+        shapes = {tuple(f.shape) for f in present}
+        if len(shapes) != 1:
+            raise RuntimeError(f"All control-point fields of a batch must share one shape, got {sorted(shapes)}")
+        stacked = []
+        for f, displacement in zip(fields, displacements, strict=True):
+            if f is None:
+                stacked.append(torch.zeros(present[0].shape, dtype=torch.float32))
+                continue
+            f = f.detach().to(device="cpu", dtype=torch.float32)
+            if displacement is None:
+                displacement = _max_abs_displacement(f)
+            _check_folding(f.numpy(), displacement, out_shape, out_spacing)
+            stacked.append(f)
+        field_tensor = torch.stack(stacked).to(device)
+        if len(present) != len(fields):
+            cp_skip = torch.tensor([f is None for f in fields], dtype=torch.uint8).to(device)
+
+    passthrough = None
+    if per_sample is not None and target_space is None:
+        flags = [m is None and f is None for m, f in zip(matrices, fields, strict=True)]
+        if any(flags):
+            passthrough = torch.tensor(flags, dtype=torch.uint8).to(device)
+    else:
+        flags = [False] * batch_size
+
+    engine = ops.engine()
+    tensors, interps, fills = [], [], []
+    for name in image_names:
+        img_batch = batch.images[name]
+        is_label = issubclass(img_batch._image_class, LabelMap)
+        interpolation = label_interpolation if is_label else image_interpolation
+        if interpolation == LABEL_INTERPOLATION or _ORDERS[interpolation] > 1:
+            raise NotImplementedError(
+                f'interpolation "{interpolation}" is not implemented by the HIP engine (supported: "nearest", "linear")'
+            )
+        data = img_batch.data
+        fill = _fill_value(engine, img_batch, default_pad_value=default_pad_value, default_pad_label=default_pad_label)
+        if antialias and not is_label:
+            data = _antialias(engine, data, in_affine, out_affine)
+        tensors.append(data)
+        interps.append(interpolation)
+        fills.append(fill)
+
+    outputs = engine.resample3d(
+        tensors,
+        out_shape=out_shape,
+        mapping=torch.from_numpy(mapping).to(device),
+        control_points=field_tensor,
+        in_spacing=in_affine.spacing,
+        out_spacing=out_affine.spacing,
+        affine_first=affine_first,
+        interps=interps,
+        fills=fills,
+        cp_skip=cp_skip,
+        passthrough=passthrough,
+    )
+    for name, output in zip(image_names, outputs, strict=True):
+        img_batch = batch.images[name]
+        originals = list(img_batch.affines)
+        img_batch.data = output
+        img_batch.affines[:] = [
+            originals[index] if flags[index] else out_affine.clone() for index in range(len(originals))
+        ]
+
+
+def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pad_label: float) -> Tensor | None:
+    """Per-channel fill tensor, or ``None`` for the reference's "scalar 0 → no mask" branch.
+
+    spatial.py:2034-2086: label maps use ``default_pad_label``; a numeric pad value
+    is used as is; ``"minimum"`` / ``"mean"`` / ``"otsu"`` come from the FIRST batch
+    element and always take the mask path, even when they evaluate to 0.
+    """
+    data = img_batch.data
+    channels = data.shape[1]
+    if issubclass(img_batch._image_class, LabelMap):
+        value: Any = float(default_pad_label)
+    elif isinstance(default_pad_value, Number):
+        value = float(default_pad_value)
+    elif not isinstance(default_pad_value, str):
+        raise TypeError(f"default_pad_value must be a string or number, got {type(default_pad_value)}")
+    elif default_pad_value == "minimum":
+        return engine.channel_min(data)  # stays on the device: no .item() sync
+    elif default_pad_value in ("mean", "otsu"):
+        values = [_border_mean(channel, filter_otsu=default_pad_value == "otsu") for channel in data[0]]
+        return torch.tensor(values, dtype=torch.float32).to(data.device)
+    else:
+        raise ValueError(f'Unknown default_pad_value "{default_pad_value}"')
+    if value == 0.0:
+        return None
+    return torch.full((channels,), value, dtype=torch.float32).to(data.device)
+
+
+def _border_mean(channel: Tensor, *, filter_otsu: bool) -> float:
+    """Mean of the six boundary faces, optionally of the voxels under their Otsu threshold.
+
+    Rare, non-default pad modes (spatial.py:2104-2168): the faces (6 S^2 values)
+    are brought to the host and reduced in float32/float64 numpy.
+    """
+    faces = [channel[0], channel[-1], channel[:, 0], channel[:, -1], channel[:, :, 0], channel[:, :, -1]]
+    borders = torch.cat([f.reshape(-1) for f in faces]).float().cpu().numpy()
+    if not filter_otsu:
+        return float(torch.from_numpy(borders).mean().item())
+    ordered = np.sort(borders)
+    count = ordered.size
+    if count == 0:
+        return 0.0
+    # Otsu sweep over sorted values: maximise w_b * w_f * (mean_b - mean_f)^2 (spatial.py:2133-2168),
+    # vectorised; accumulations run in float64 like the reference's Python floats.
+    values = ordered.astype(np.float64)
+    total = float(torch.from_numpy(ordered).sum().item())
+    background_sum = np.cumsum(values[:-1])
+    background_count = np.arange(1, count, dtype=np.float64)
+    foreground_count = count - background_count
+    mean_background = background_sum / background_count
+    mean_foreground = (total - background_sum) / foreground_count
+    variance = (background_count / count) * (foreground_count / count) * (mean_background - mean_foreground) ** 2
+    threshold = float(values[0])
+    if variance.size:
+        best = int(np.argmax(variance))  # first maximum, like the strict `>` sweep
+        if variance[best] > 0.0:
+            threshold = float(values[best])
+    below = borders[borders < threshold]
+    if below.size:
+        return float(torch.from_numpy(below).mean().item())
+    return float(torch.from_numpy(borders).mean().item())
+
+
+def _antialias(engine, data: Tensor, in_affine: AffineMatrix, out_affine: AffineMatrix) -> Tensor:
+    """Gaussian pre-filter along down-sampled axes (Cardoso et al. 2015; spatial.py:1921-2031)."""
+    in_spacing = np.asarray(in_affine.spacing, dtype=np.float64)
+    factors = np.asarray(out_affine.spacing, dtype=np.float64) / in_spacing
+    sigmas = np.zeros(3, dtype=np.float64)
+    for axis in range(3):
+        k = factors[axis]
+        if k > 1.0:
+            variance = (k**2 - 1) * (2 * np.sqrt(2 * np.log(2))) ** (-2)
+            sigmas[axis] = in_spacing[axis] * np.sqrt(variance) / in_spacing[axis]
+    if np.all(sigmas == 0):
+        return data
+    taps, radius, _ = _stacked_gaussian_taps(sigmas[None])
+    work = data if data.dtype in ops.FLOAT_DTYPES else data.float()
+    return engine.separable_conv3d(work, taps.to(data.device), radius).to(data.dtype)
+
+
+# =============================================================================
+# geometry helpers (float64 on the host, exactly like the reference)
+# =============================================================================
+def _spatial_shape(img_batch: ImagesBatch) -> tuple[int, int, int]:
+    return tuple(int(s) for s in img_batch.data.shape[-3:])  # type: ignore[return-value]
+
+
+def _euler_to_rotation_matrix(degrees: np.ndarray) -> np.ndarray:
+    """``R = Rz @ Ry @ Rx`` from XYZ Euler angles in degrees (spatial.py:2328-2365)."""
+    (cx, cy, cz), (sx, sy, sz) = np.cos(np.radians(degrees)), np.sin(np.radians(degrees))
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=np.float64)
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float64)
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=np.float64)
+    return rz @ ry @ rx
+
+
+def _build_forward_affine(*, scales, degrees, translation, center, shape, affine: AffineMatrix) -> np.ndarray:
+    """World-space 4x4: ``A = R @ diag(s)``, pivot at the image centre, plus translation (spatial.py:2269-2325)."""
+    scaling = np.asarray(scales, dtype=np.float64).copy()
+    rotation = np.asarray(degrees, dtype=np.float64).copy()
+    shift = np.asarray(translation, dtype=np.float64).copy()
+    if shape[-1] == 1:  # 2-D slice: suppress out-of-plane components
+        scaling[2] = 1.0
+        rotation[0] = rotation[1] = 0.0
+        shift[2] = 0.0
+    rotation_scale = _euler_to_rotation_matrix(rotation) @ np.diag(scaling)
+    transform = np.eye(4, dtype=np.float64)
+    transform[:3, :3] = rotation_scale
+    if center == "image":
+        matrix = affine.numpy()
+        center_world = matrix[:3, 3] + matrix[:3, :3] @ ((np.asarray(shape, dtype=np.float64) - 1) / 2)
+        transform[:3, 3] = center_world - rotation_scale @ center_world
+    transform[:3, 3] += shift
+    return transform
+
+
+def _sample_control_points(grid_shape, max_displacement, locked_borders: int) -> Tensor:
+    """``U(-max, +max)`` per axis from ONE ``torch.rand(ni, nj, nk, 3)`` draw; outer layers zeroed."""
+    field = torch.rand(*grid_shape, 3, dtype=torch.float32)
+    field -= 0.5
+    field *= 2
+    for axis in range(3):
+        field[..., axis] *= max_displacement[axis]
+    for border in range(locked_borders):
+        for dim in range(3):
+            index = [slice(None)] * 3
+            index[dim] = border
+            field[tuple(index)] = 0
+            index[dim] = -1 - border
+            field[tuple(index)] = 0
+    return field
+
+
+def _max_abs_displacement(control_points: Tensor) -> tuple[float, float, float]:
+    absolute = control_points.abs()
+    return tuple(float(absolute[..., axis].max().item()) for axis in range(3))  # type: ignore[return-value]
+
+
+def _check_folding(control_points: np.ndarray, max_displacement, shape, spacing: np.ndarray) -> None:
+    """Warn when the displacement exceeds half the coarse-grid spacing (spatial.py:2192-2216)."""
+    mesh = np.array(control_points.shape[:-1], dtype=np.float64) - _SPLINE_ORDER
+    grid_spacing = np.array(shape, dtype=np.float64) * spacing / mesh
+    conflicts = np.array(max_displacement, dtype=np.float64) > grid_spacing / 2
+    if np.any(conflicts):
+        (where,) = np.where(conflicts)
+        warnings.warn(
+            "The maximum displacement is larger than half the coarse-grid"
+            f" spacing for dimensions {where.tolist()}, so folding may occur",
+            RuntimeWarning,
+            stacklevel=4,
+        )
+
+
+def _check_shared_space(images: dict[str, ImagesBatch], reference_shape, reference_affine: AffineMatrix) -> None:
+    for name, img_batch in images.items():
+        shape = _spatial_shape(img_batch)
+        if shape != reference_shape:
+            raise RuntimeError(f'Image "{name}" has shape {shape}, expected {reference_shape}')
+        for affine in img_batch.affines:
+            if not torch.allclose(affine.data, reference_affine.data, rtol=1e-6, atol=1e-6):
+                raise RuntimeError(
+                    "Spatial transforms with affine or elastic components require"
+                    " selected images to share the same affine"
+                )
+
+
+def _resolve_spatial_params(params: dict[str, Any]):
+    """``(matrix, field, max_displacement, per_sample)`` from a params dict (spatial.py:962-1008)."""
+    def matrix_of(value):
+        return None if value is None else np.asarray(value, dtype=np.float64)
+
+    def field_of(value):
+        return None if value is None else torch.as_tensor(value, dtype=torch.float32)
+
+    def displacement_of(value):
+        return None if value is None else (float(value[0]), float(value[1]), float(value[2]))
+
+    if "affine_matrix" not in (params.get("_batched_keys") or []):
+        return (
+            matrix_of(params["affine_matrix"]),
+            field_of(params["control_points"]),
+            displacement_of(params["max_displacement"]),
+            None,
+        )
+    matrices = [matrix_of(m) for m in params["affine_matrix"]]
+    fields = [field_of(c) for c in params["control_points"]]
+    displacements = [displacement_of(d) for d in params["max_displacement"]]
+    if all(m is None for m in matrices) and all(f is None for f in fields):
+        return None, None, None, None
+    return None, None, None, _PerSampleGrids(matrices, fields, displacements)
+
+
+# -- target space -----------------------------------------------------------------
+def _serialize_space(space):
+    if space is None:
+        return None
+    shape, affine = space
+    return {"shape": list(shape), "affine": affine.numpy().tolist()}
+
+
+def _deserialize_space(data):
+    if data is None:
+        return None
+    shape = tuple(int(s) for s in data["shape"][:3])
+    return shape, AffineMatrix(np.asarray(data["affine"], dtype=np.float64))
+
+
+def _resolve_target_space(target, batch: SubjectsBatch, first_shape, first_affine: AffineMatrix):
+    """User-facing *target* → ``(shape, affine)`` or ``None`` (spatial.py:1392-1422)."""
+    if target is None:
+        return None
+    if isinstance(target, Image):
+        return target.spatial_shape, target.affine.clone()
+    if isinstance(target, (str, Path)):
+        if isinstance(target, str) and target in batch.images:
+            reference = batch.images[target]
+            return _spatial_shape(reference), reference.affines[0].clone()
+        raise ValueError(
+            f'Unknown target "{target}". Pass an image name in the subject, an Image, a (shape, affine) pair'
+            " or a spacing specification (reading a target image from a file path is not supported here)"
+        )
+    if isinstance(target, tuple) and len(target) == 2 and not isinstance(target[0], Number):
+        shape, affine = target
+        if len(shape) != 3:
+            raise ValueError(f"Target shape must have length 3, got {len(shape)}")
+        return tuple(int(s) for s in shape), AffineMatrix(affine)
+    if not isinstance(target, (int, float, tuple, list, np.ndarray, Choice, Distribution)):
+        raise ValueError(f'Target not understood: "{target}"')
+    return _new_shape_affine(first_shape, first_affine, _resolve_target_spacing(target))
+
+
+def _resolve_target_spacing(value) -> tuple[float, float, float]:
+    """Deterministic or random spacing spec → positive 3-tuple (spatial.py:1446-1469)."""
+    if isinstance(value, np.ndarray):
+        spacing = tuple(float(v) for v in value.flat)
+    elif isinstance(value, (int, float)):
+        spacing = (float(value),) * 3
+    else:
+        spacing = _ParameterRange(tuple(value) if isinstance(value, list) else value).sample()
+    if len(spacing) != 3:
+        raise ValueError(f"Spacing must have 3 values, got {len(spacing)}")
+    spacing = tuple(float(v) for v in spacing)
+    if any(v <= 0 for v in spacing):
+        raise ValueError(f"Spacing must be strictly positive, got {spacing}")
+    return spacing  # type: ignore[return-value]
+
+
+def _new_shape_affine(shape, affine: AffineMatrix, spacing):
+    """Output grid for a new spacing, same physical centre (spatial.py:1472-1501)."""
+    old_spacing = np.asarray(affine.spacing, dtype=np.float64)
+    new_spacing = np.asarray(spacing, dtype=np.float64)
+    old_shape = np.asarray(shape, dtype=np.float64)
+    new_shape = np.floor(old_shape * old_spacing / new_spacing)
+    new_shape[old_shape == 1] = 1
+    rotation = affine.direction.cpu().numpy()
+    old_center = np.asarray(affine.origin, dtype=np.float64) + rotation @ (((old_shape - 1) / 2) * old_spacing)
+    new_affine = np.eye(4, dtype=np.float64)
+    new_affine[:3, :3] = rotation * new_spacing
+    new_affine[:3, 3] = old_center - rotation @ (((new_shape - 1) / 2) * new_spacing)
+    return tuple(int(s) for s in new_shape), AffineMatrix(new_affine)
+
+
+# -- argument parsing -------------------------------------------------------------
+def _parse_interpolation(interpolation) -> str:
+    if isinstance(interpolation, int) and not isinstance(interpolation, bool):
+        names = {order: name for name, order in _ORDERS.items()}
+        if interpolation not in names:
+            raise ValueError(f"Interpolation order {interpolation} is not supported. Must be 0-7.")
+        return names[interpolation]
+    if not isinstance(interpolation, str):
+        raise TypeError(f"Interpolation must be a string or int, got {type(interpolation)}")
+    lowered = interpolation.lower()
+    if lowered not in _SUPPORTED_INTERPOLATIONS:
+        raise ValueError(
+            f'Interpolation "{lowered}" is not supported. Supported values are {_SUPPORTED_INTERPOLATIONS}'
+        )
+    return lowered
+
+
+def _parse_default_pad_value(value):
+    if isinstance(value, Number):
+        return float(value)
+    if value in _SUPPORTED_PAD_VALUES:
+        return value
+    raise ValueError('default_pad_value must be "minimum", "mean", "otsu", or a numeric value')
+
+
+def _parse_num_control_points(value) -> tuple[int, int, int]:
+    parsed = (value, value, value) if isinstance(value, int) else tuple(value)
+    for axis, number in enumerate(parsed):
+        if not isinstance(number, int) or number < 4:
+            raise ValueError(
+                f"Each num_control_points value must be an integer greater than 3; axis {axis} got {number}"
+            )
+    return parsed  # type: ignore[return-value]
+
+
+def _parse_control_points(control_points) -> Tensor:
+    if isinstance(control_points, Tensor):
+        tensor = control_points.clone().detach().to(torch.float32)
+    else:
+        tensor = torch.as_tensor(np.asarray(control_points), dtype=torch.float32)
+    if tensor.ndim != 4 or tensor.shape[-1] != 3:
+        raise ValueError(f"control_points must have shape (n_i, n_j, n_k, 3), got {tuple(tensor.shape)}")
+    for axis, size in enumerate(tensor.shape[:-1]):
+        if size < 4:
+            raise ValueError(f"Each control-point axis must have at least 4 elements; axis {axis} got {size}")
+    return tensor.contiguous()
+
+
+def _parameter_range(value) -> _ParameterRange:
+    """Ints become floats so ``_ParameterRange`` always receives floats (spatial.py:2732-2751)."""
+    if isinstance(value, (int, float)):
+        value = float(value)
+    elif isinstance(value, tuple) and all(isinstance(v, (int, float)) for v in value):
+        value = tuple(float(v) for v in value)
+    return _ParameterRange(value)
+
+
+def _positive_range(value) -> _ParameterRange:
+    parsed = _parameter_range(value)
+    if parsed._distribution is None and any(lo <= 0 or hi <= 0 for lo, hi in parsed._ranges):
+        raise ValueError(f"Scale factors must be strictly positive, got {value}")
+    return parsed
+
+
+def _nonnegative_range(value) -> _ParameterRange:
+    parsed = _parameter_range(value)
+    if parsed._distribution is None and any(lo < 0 or hi < 0 for lo, hi in parsed._ranges):
+        raise ValueError(f"Value must be non-negative, got {value}")
+    return parsed
