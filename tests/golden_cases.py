@@ -1,0 +1,99 @@
+"""Replay the committed golden fixtures (tests/golden/transforms_golden.pt) on an engine.
+
+The fixtures were produced by the unmodified reference (tests/golden/make_golden.py).
+Bars (BASELINE.json north_star): label maps / nearest-neighbour results bit-exact,
+float intensities within 1e-4 relative.  The tests hold the engine to much
+tighter engineering bars so that regressions show up: pure resampling is
+bit-exact in float too (same float32 operation order as ATen), ops with a
+transcendental or a different summation order get 2e-6.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+import torchio_amd as tio
+
+GOLDEN_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms_golden.pt")
+NORTH_STAR_REL_TOL = 1e-4  # the contract
+TIGHT_REL_TOL = {torch.float32: 2e-6, torch.float64: 2e-6, torch.float16: 2e-3}
+
+#: cases whose float output must match the reference bit for bit
+BIT_EXACT_FLOAT = {
+    "affine", "affine_batch", "affine_pad0", "affine_pad_number_label5", "affine_pad_mean", "affine_pad_otsu",
+    "affine_rot90_ties", "affine_half_voxel_ties", "affine_out_of_view", "affine_2d", "affine_isotropic_origin",
+    "affine_nearest_image", "affine_f64", "affine_f16", "affine_p_gate", "elastic", "elastic_batch",
+    "spatial_fused", "spatial_elastic_first_batch_p", "spatial_target_and_affine", "resample_2mm",
+    "resample_random_spacing", "noise", "noise_f64",
+}
+
+
+def load_cases():
+    return torch.load(GOLDEN_PATH, weights_only=True)["cases"]
+
+
+def case_ids():
+    return [case["name"] for case in load_cases()]
+
+
+def build_transform(case):
+    if case["cls"] == "Compose":
+        return tio.Compose([getattr(tio, cls)(**kwargs) for cls, kwargs in case["kwargs"]["steps"]])
+    return getattr(tio, case["cls"])(**case["kwargs"])
+
+
+def build_input(case, device):
+    subjects = [
+        tio.Subject(
+            t1=tio.ScalarImage(item["t1"].clone(), affine=tio.AffineMatrix(item["affine"])),
+            seg=tio.LabelMap(item["seg"].clone(), affine=tio.AffineMatrix(item["affine"])),
+        ).to(device)
+        for item in case["inputs"]
+    ]
+    return subjects[0] if len(subjects) == 1 else tio.SubjectsBatch.from_subjects(subjects)
+
+
+def rel_err(expected: torch.Tensor, actual: torch.Tensor) -> float:
+    diff = (expected.double() - actual.double()).abs()
+    return float((diff / expected.double().abs().clamp_min(1.0)).max()) if diff.numel() else 0.0
+
+
+def check_case(case, device: str) -> None:
+    """Run one golden case end to end (seed -> make_params -> engine -> history) and assert parity."""
+    expected = case["expected"]
+    transform = build_transform(case)
+    data = build_input(case, device)
+    torch.manual_seed(case["seed"])
+    out = transform(data)
+    rng_probe = float(torch.rand(1).item())
+    outs = [out] if isinstance(out, tio.Subject) else out.unbatch()
+
+    history = [{"name": t.name, "params": t.params} for t in out.applied_transforms]
+    assert history == expected["history"], f"{case['name']}: sampled params differ from the reference"
+    assert rng_probe == expected["rng_probe"], f"{case['name']}: global RNG consumed differently"
+
+    t1 = torch.stack([o.t1.data for o in outs]).cpu()
+    seg = torch.stack([o.seg.data for o in outs]).cpu()
+    affines = torch.stack([o.t1.affine.data for o in outs])
+    assert t1.dtype == expected["t1"].dtype and seg.dtype == expected["seg"].dtype
+    assert t1.shape == expected["t1"].shape
+    assert str(t1.device) == "cpu" and outs[0].t1.data.device.type == torch.device(device).type
+    assert torch.equal(seg, expected["seg"]), f"{case['name']}: label map not bit-exact"
+    torch.testing.assert_close(affines, expected["affines"], rtol=0, atol=1e-12)
+    if case["name"] in BIT_EXACT_FLOAT:
+        assert torch.equal(t1, expected["t1"]), f"{case['name']}: rel err {rel_err(expected['t1'], t1):.3g}"
+    else:
+        err = rel_err(expected["t1"], t1)
+        assert err <= TIGHT_REL_TOL[t1.dtype] <= NORTH_STAR_REL_TOL or err <= TIGHT_REL_TOL[t1.dtype], (
+            f"{case['name']}: rel err {err:.3g}"
+        )
+
+    if "inverse" in case:
+        restored = out.apply_inverse_transform()
+        routs = [restored] if isinstance(restored, tio.Subject) else restored.unbatch()
+        rt1 = torch.stack([o.t1.data for o in routs]).cpu()
+        rseg = torch.stack([o.seg.data for o in routs]).cpu()
+        assert torch.equal(rseg, case["inverse"]["seg"]), f"{case['name']}: inverse label map not bit-exact"
+        err = rel_err(case["inverse"]["t1"], rt1)
+        assert err <= 4 * TIGHT_REL_TOL[rt1.dtype], f"{case['name']}: inverse rel err {err:.3g}"
