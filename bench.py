@@ -1,0 +1,215 @@
+"""Headline benchmark: volumes/s for Compose[Affine, ElasticDeformation, BiasField, Blur, Noise] on 256^3 float32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the Compose over one device-resident SubjectsBatch of
+`--batch` (default 8) synthetic 1x256^3 float32 volumes per GPU with per-instance
+parameters (the reference's default for batches).  Inputs are resident in HBM
+before the timed region; outputs stay on the device.  Weak scaling: the per-GPU
+batch is fixed, ranks never exchange data; the only collective is the all-gather
+of three counters per rank at the end.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torchio_amd as tio  # noqa: E402
+from torchio_amd import distributed as tdist  # noqa: E402
+from torchio_amd import ops  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def build_transform() -> tio.Compose:
+    """The metric's pipeline with the explicit ranges of SURVEY.md §8(d) / BASELINE.md §3."""
+    return tio.Compose(
+        [
+            tio.Affine(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5)),
+            tio.ElasticDeformation(),
+            tio.BiasField(),
+            tio.Blur(std=(0.5, 2)),
+            tio.Noise(),
+        ]
+    )
+
+
+def make_batch(size: int, batch: int, seed: int, device) -> tio.SubjectsBatch:
+    generator = torch.Generator(device=device).manual_seed(seed)
+    data = torch.rand(batch, 1, size, size, size, generator=generator, device=device)
+    affines = [tio.AffineMatrix() for _ in range(batch)]
+    return tio.SubjectsBatch({"t1": tio.ImagesBatch(data, affines, image_class=tio.ScalarImage)})
+
+
+class KernelTimer:
+    """HIP-event timing of one C-ABI entry point on the stream it is launched on.
+
+    The engine launches on torch's current stream, so torch.cuda.Event brackets
+    exactly the kernel(s) of that call.  Events are only resolved after the timed
+    region (no sync inside it).
+    """
+
+    def __init__(self, engine, name: str):
+        self.engine, self.name, self.pairs, self.active = engine, name, [], False
+        self._original = engine._call
+
+        def timed_call(fn_name, ref, *args):
+            if self.active and fn_name == self.name:
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record()
+                self._original(fn_name, ref, *args)
+                end.record()
+                self.pairs.append((start, end))
+            else:
+                self._original(fn_name, ref, *args)
+
+        engine._call = timed_call
+
+    def mean_ms(self) -> float | None:
+        if not self.pairs:
+            return None
+        return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs)
+
+
+def cpu_baseline(size: int, n_volumes: int, seed: int) -> dict:
+    """The CPU oracle ("port") timed on this host's cores on a bounded sample of the same workload."""
+    from oracle.oracle import num_threads, oracle_engine  # noqa: PLC0415
+    from parity_harness import use_engine  # noqa: PLC0415
+
+    transform = build_transform()
+    batch = make_batch(size, n_volumes, seed, "cpu")
+    torch.manual_seed(seed)
+    with use_engine(oracle_engine()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        start = time.perf_counter()
+        transform(batch)
+        elapsed = time.perf_counter() - start
+    return {
+        "value": n_volumes / elapsed,
+        "unit": "volumes/s",
+        "cores": num_threads(),
+        "kind": "port",
+        "sample": f"{n_volumes} x 1x{size}^3 f32 volumes, same Compose, oracle/libtio_oracle.so (OpenMP) + host torch.randn",
+        "seconds": elapsed,
+    }
+
+
+def load_traffic() -> float | None:
+    """Per-launch HBM bytes of the dominant kernel from the committed PMC summary, if any."""
+    path = os.path.join(ROOT, "profiles", "resample_traffic.json")
+    try:
+        with open(path) as handle:
+            return float(json.load(handle)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=20)
+    parser.add_argument("--warmup", type=int, default=3)
+    parser.add_argument("--size", type=int, default=256)
+    parser.add_argument("--batch", type=int, default=8, help="volumes per GPU per step")
+    parser.add_argument("--noise-rng", choices=["reference", "philox"], default="philox")
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--cpu-volumes", type=int, default=2)
+    args = parser.parse_args()
+
+    info = tdist.init_process_group()
+    assert info.world_size == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    device = torch.device("cuda", info.local_rank)
+    torch.cuda.set_device(device)
+    warnings.simplefilter("ignore")
+
+    tio.set_noise_rng(args.noise_rng)
+    engine = ops.engine()
+    timer = KernelTimer(engine, "resample3d")
+    transform = build_transform()
+    batch = make_batch(args.size, args.batch, 1234 + info.rank, device)
+    torch.manual_seed(4321 + info.rank)
+
+    for _ in range(args.warmup):
+        transform(batch)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    timer.active = True
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        out = transform(batch)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - start
+    timer.active = False
+
+    volume_bytes = args.size**3 * 4
+    n_volumes = args.steps * args.batch
+    counters = tdist.gather_counters(n_volumes, elapsed, n_volumes * 10 * volume_bytes, device=device)
+    total = tdist.aggregate_throughput(counters)
+
+    if info.rank == 0:
+        kernel_ms = timer.mean_ms()
+        launch_bytes = 2 * volume_bytes * args.batch  # read input once + write output once, per launch
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+        line = {
+            "metric": "volumes/s (256^3 float32) for Compose[affine+elastic+bias+blur+noise]",
+            "value": total["volumes_per_s"],
+            "unit": "volumes/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * total["elapsed_s"] / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": (
+                    f"Compose[Affine(deg +-10, scale 0.9-1.1, trans +-5mm), ElasticDeformation(7^3 cp, 7.5mm), "
+                    f"BiasField, Blur(0.5-2mm), Noise] on 1x{args.size}^3 f32, per-instance params"
+                ),
+                "volume": f"1x{args.size}x{args.size}x{args.size}",
+                "batch_per_gpu": args.batch,
+                "global_batch": args.batch * args.gpus,
+                "noise_rng": args.noise_rng,
+                "parallelism": f"batch-split x{args.gpus} (no data-path collective)",
+            },
+            "pipeline_algorithmic_GBps": total["algorithmic_bytes"] / total["elapsed_s"] / 1e9,
+            "roofline": {
+                "kernel": "tio::resample_kernel (tio_resample3d)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": load_traffic(),
+                "launch_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": launch_bytes,
+                "launches_timed": len(timer.pairs),
+            },
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_volumes, 99)
+        print(json.dumps(line), flush=True)
+    del out
+    if info.world_size > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
