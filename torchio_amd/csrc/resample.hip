@@ -10,7 +10,14 @@
 // applies `mask > 0.5 ? value : fill`.  No (I,J,K,3) grid ever reaches HBM.
 //
 // HBM-bound by design (algorithmic traffic = read input once + write output
-// once); no MFMA: this is a gather/stencil op.
+// once); no MFMA: this is a gather/stencil op.  What actually limits it is the
+// per-voxel float32 instruction count needed to stay bit-identical with the
+// reference, so the kernel is organised around (1) latency hiding — one block
+// walks kTileI output slabs so the control points are staged once per 2048
+// voxels and many independent gathers are in flight, (2) a wave-uniform
+// "interior" path (all 8 taps of all 64 lanes in bounds: no predication, no
+// mask arithmetic — the mask is exactly > 0.5 there), (3) IEEE-exact division
+// by reciprocal + two FMA refinements instead of the 12-instruction expansion.
 #include "common.hpp"
 
 namespace tio {
@@ -36,205 +43,343 @@ struct ResampleArgs {
   int ni, nj, nk;
   const uint8_t* cp_skip;
   const uint8_t* passthrough;
-  float sp0, sp1, sp2;           // spacing that converts mm → voxels
+  float sp[3], rsp[3];              // mm → voxel spacing and its float32 reciprocal
+  int unit_spacing;                 // all three spacings == 1.0f: d / 1 is the identity
   float scale_i, scale_j, scale_k;  // ATen lerp scales of the control grid
+  float den[3], rden[3];            // max(S-1,1) per input axis and reciprocal
+  float size_m1[3];                 // S-1 per input axis
+  int any_linear, any_nearest;      // which coordinate products are needed at all
   int n_images;
   ImgArgs img[TIO_MAX_IMAGES];
-  // tiling
-  int tiles_k, tiles_j;          // tiles per row / per slab
+  int tiles_k, tiles_j, tiles_i;
 };
 
-constexpr int kRowsPerBlock = 4;   // one wave per output row (jo), 4 rows per block
+constexpr int kTileI = 8;          // output slabs walked by one block
+constexpr int kRowsPerBlock = 4;   // one wave per output row (jo)
 constexpr int kLanes = 64;         // contiguous ko per wave → coalesced stores
 constexpr int kMaxCpLds = 6144;    // floats of control points staged in LDS (24 KiB)
 
-// [c,1] @ M^T for one row of M: the rounding sequence of MKL sgemm (K = 4),
-// pinned against the reference in tests/golden.
-__device__ __forceinline__ float affine_row(const float* __restrict__ m, float a, float b, float c) {
-  float t = a * m[0];
-  t = __builtin_fmaf(b, m[1], t);
-  t = __builtin_fmaf(c, m[2], t);
-  t = __builtin_fmaf(1.0f, m[3], t);
-  return t;
+// IEEE-754 correctly rounded n / d from r = RN(1/d): q0 = RN(n r), two Markstein
+// refinements (each: exact remainder by FMA, correction by FMA).  Checked
+// bit-for-bit against the hardware division on 1.9e9 operands (integer
+// divisors 1..2100, spacings in [0.05, 20], exact-multiple neighbourhoods).
+__device__ __forceinline__ float exact_div(float n, float d, float r) {
+  float q = __fmul_rn(n, r);
+  float e = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e, r, q);
 }
 
 // g = 2 v / max(S-1,1) - 1 (spatial.py:1638-1646) followed by ATen's
 // grid_sampler_unnormalize(align_corners=True): ((g + 1) / 2) * (S - 1).
-__device__ __forceinline__ float normalise_roundtrip(float v, int size) {
-  const float denom = static_cast<float>(max(size - 1, 1));
-  const float g = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, v), denom), 1.0f);
-  return __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), static_cast<float>(size - 1));
+__device__ __forceinline__ float normalise_roundtrip(float v, float den, float rden, float size_m1) {
+  const float g = __fsub_rn(exact_div(__fmul_rn(2.0f, v), den, rden), 1.0f);
+  return __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), size_m1);
 }
 
-__device__ __forceinline__ bool in_bounds(float f, int n) {
-  return f >= 0.0f && f <= static_cast<float>(n - 1);
-}
+// trilinear lookup of the three displacement components from the (ni,nj,nk,3)
+// field; nesting and rounding exactly as ATen's upsample_trilinear3d (K innermost)
+struct Disp {
+  float i, j, k;
+};
 
-// trilinear lookup of one displacement component from the (ni,nj,nk,3) field
-__device__ __forceinline__ float cp_trilerp(const float* v, int s_i, int s_j, const Lerp1D& li,
+__device__ __forceinline__ Disp cp_trilerp3(const float* __restrict__ cp, int s_i, int s_j, const Lerp1D& li,
                                             const Lerp1D& lj, const Lerp1D& lk) {
-  const float* p00 = v + li.i0 * s_i + lj.i0 * s_j;
-  const float* p01 = v + li.i0 * s_i + lj.i1 * s_j;
-  const float* p10 = v + li.i1 * s_i + lj.i0 * s_j;
-  const float* p11 = v + li.i1 * s_i + lj.i1 * s_j;
-  const float a00 = lerp2(p00[lk.i0 * 3], lk.l0, p00[lk.i1 * 3], lk.l1);
-  const float a01 = lerp2(p01[lk.i0 * 3], lk.l0, p01[lk.i1 * 3], lk.l1);
-  const float a10 = lerp2(p10[lk.i0 * 3], lk.l0, p10[lk.i1 * 3], lk.l1);
-  const float a11 = lerp2(p11[lk.i0 * 3], lk.l0, p11[lk.i1 * 3], lk.l1);
-  const float b0 = lerp2(a00, lj.l0, a01, lj.l1);
-  const float b1 = lerp2(a10, lj.l0, a11, lj.l1);
-  return lerp2(b0, li.l0, b1, li.l1);
+  const float* p00 = cp + li.i0 * s_i + lj.i0 * s_j;
+  const float* p01 = cp + li.i0 * s_i + lj.i1 * s_j;
+  const float* p10 = cp + li.i1 * s_i + lj.i0 * s_j;
+  const float* p11 = cp + li.i1 * s_i + lj.i1 * s_j;
+  const int k0 = lk.i0 * 3, k1 = lk.i1 * 3;
+  float r[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float a00 = lerp2(p00[k0 + c], lk.l0, p00[k1 + c], lk.l1);
+    const float a01 = lerp2(p01[k0 + c], lk.l0, p01[k1 + c], lk.l1);
+    const float a10 = lerp2(p10[k0 + c], lk.l0, p10[k1 + c], lk.l1);
+    const float a11 = lerp2(p11[k0 + c], lk.l0, p11[k1 + c], lk.l1);
+    const float b0 = lerp2(a00, lj.l0, a01, lj.l1);
+    const float b1 = lerp2(a10, lj.l0, a11, lj.l1);
+    r[c] = lerp2(b0, li.l0, b1, li.l1);
+  }
+  return Disp{r[0], r[1], r[2]};
 }
 
+// ---- sampling --------------------------------------------------------------------
+// Interior path: every tap of every lane of the wave is in bounds, so there is no
+// predication, no mask arithmetic (the in-bounds weight sum is 1 up to rounding,
+// always > 0.5) and the 8 offsets are base + launch constants.
+template <int DT>
+__device__ __forceinline__ void sample_interior(const ImgArgs& g, int b, int64_t n_in, int64_t n_out, int64_t o_idx,
+                                                const float (&w)[8], int base, int dJK, int dK, int offn) {
+  for (int c = 0; c < g.channels; c++) {
+    const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
+    const typename Elem<DT>::type* p = static_cast<const typename Elem<DT>::type*>(g.in) + bc * n_in;
+    float val;
+    if (g.interp == TIO_LINEAR) {
+      const typename Elem<DT>::type* q = p + base;
+      const float v0 = Elem<DT>::load(q, 0), v1 = Elem<DT>::load(q, dJK);
+      const float v2 = Elem<DT>::load(q, dK), v3 = Elem<DT>::load(q, dJK + dK);
+      const float v4 = Elem<DT>::load(q, 1), v5 = Elem<DT>::load(q, dJK + 1);
+      const float v6 = Elem<DT>::load(q, dK + 1), v7 = Elem<DT>::load(q, dJK + dK + 1);
+      val = __fadd_rn(0.0f, __fmul_rn(v0, w[0]));  // keep ATen's `0 + v*w` (sign of zero)
+      val = __fadd_rn(val, __fmul_rn(v1, w[1]));
+      val = __fadd_rn(val, __fmul_rn(v2, w[2]));
+      val = __fadd_rn(val, __fmul_rn(v3, w[3]));
+      val = __fadd_rn(val, __fmul_rn(v4, w[4]));
+      val = __fadd_rn(val, __fmul_rn(v5, w[5]));
+      val = __fadd_rn(val, __fmul_rn(v6, w[6]));
+      val = __fadd_rn(val, __fmul_rn(v7, w[7]));
+    } else {
+      val = Elem<DT>::load(p, offn);
+    }
+    Elem<DT>::store(g.out, bc * n_out + o_idx, val);
+  }
+}
+
+// Boundary path: per-tap bounds, zero padding, in-bounds weight mask and fill, in
+// exactly ATen's accumulation order (tnw,tne,tsw,tse,bnw,bne,bsw,bse).
+template <int DT>
+__device__ __forceinline__ void sample_boundary(const ImgArgs& g, int b, int64_t n_in, int64_t n_out, int64_t o_idx,
+                                                const float (&w)[8], const int (&off)[8], unsigned okbits, float mask,
+                                                int offn, bool okn) {
+  for (int c = 0; c < g.channels; c++) {
+    const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
+    const typename Elem<DT>::type* p = static_cast<const typename Elem<DT>::type*>(g.in) + bc * n_in;
+    float val;
+    if (g.interp == TIO_LINEAR) {
+      val = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float v = Elem<DT>::load(p, off[k]);
+        const float next = __fadd_rn(val, __fmul_rn(v, w[k]));
+        val = ((okbits >> k) & 1u) ? next : val;
+      }
+    } else {
+      const float v = Elem<DT>::load(p, offn);
+      val = okn ? v : 0.0f;
+    }
+    if (g.fill != nullptr) val = (mask > 0.5f) ? val : g.fill[c];
+    Elem<DT>::store(g.out, bc * n_out + o_idx, val);
+  }
+}
+
+// DTMODE selects which element types a kernel instantiation can sample, so that the
+// common launches do not pay registers for the rare ones: 0 = float32 only,
+// 1 = float32 + {int16, uint8, int32} (intensity + label maps), 2 = every tio_dtype.
+#define TIO_DISPATCH_IMAGE(DTMODE, DTYPE, CALL)                 \
+  if constexpr (DTMODE == 0) {                                  \
+    CALL(TIO_F32);                                              \
+  } else {                                                      \
+    switch (DTYPE) { /* uniform → scalar branch */              \
+      case TIO_F32: CALL(TIO_F32); break;                       \
+      case TIO_I16: CALL(TIO_I16); break;                       \
+      case TIO_U8: CALL(TIO_U8); break;                         \
+      case TIO_I32: CALL(TIO_I32); break;                       \
+      default:                                                  \
+        if constexpr (DTMODE == 2) {                            \
+          switch (DTYPE) {                                      \
+            case TIO_I64: CALL(TIO_I64); break;                 \
+            case TIO_F16: CALL(TIO_F16); break;                 \
+            case TIO_BF16: CALL(TIO_BF16); break;               \
+            case TIO_F64: CALL(TIO_F64); break;                 \
+            default: CALL(TIO_I8); break;                       \
+          }                                                     \
+        }                                                       \
+        break;                                                  \
+    }                                                           \
+  }
+
+template <bool ELASTIC_POSSIBLE, int DTMODE>
 __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const ResampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_cp[];
 
-  // tile decode: XCD-contiguous chunks of (b, io, jt, kt), kt fastest
+  // tile decode: XCD-contiguous chunks of (b, it, jt, kt), kt fastest
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
   const int kt = tile % a.tiles_k;
   const unsigned t1 = tile / a.tiles_k;
   const int jt = t1 % a.tiles_j;
   const unsigned t2 = t1 / a.tiles_j;
-  const int io = t2 % a.Io;
-  const int b = t2 / a.Io;
+  const int it = t2 % a.tiles_i;
+  const int b = t2 / a.tiles_i;
 
   const int lane = threadIdx.x & (kLanes - 1);
-  const int wave = threadIdx.x / kLanes;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);
   const int jo = jt * kRowsPerBlock + wave;
   const int ko = kt * kLanes + lane;
+  const int i_begin = it * kTileI;
+  const int i_end = min(i_begin + kTileI, a.Io);
 
-  const bool elastic = a.cp != nullptr && !(a.cp_skip != nullptr && a.cp_skip[b] != 0);
   const bool pass = a.passthrough != nullptr && a.passthrough[b] != 0;
-  const int n_cp = a.ni * a.nj * a.nk * 3;
-  const float* cp = nullptr;
-  if (elastic && !pass) {
-    const float* src = a.cp + (a.cp_batched ? static_cast<int64_t>(b) * n_cp : 0);
-    if (n_cp <= kMaxCpLds) {
-      for (int t = threadIdx.x; t < n_cp; t += blockDim.x) s_cp[t] = src[t];
-      __syncthreads();
-      cp = s_cp;
-    } else {
-      cp = src;  // oversized control grid: read through the cache
+  bool elastic = false;
+  bool cp_in_lds = false;
+  const float* cp_global = nullptr;
+  if constexpr (ELASTIC_POSSIBLE) {
+    elastic = !(a.cp_skip != nullptr && a.cp_skip[b] != 0);
+    if (elastic && !pass) {
+      const int n_cp = a.ni * a.nj * a.nk * 3;
+      cp_global = a.cp + (a.cp_batched ? static_cast<int64_t>(b) * n_cp : 0);
+      if (n_cp <= kMaxCpLds) {
+        for (int t = threadIdx.x; t < n_cp; t += blockDim.x) s_cp[t] = cp_global[t];
+        __syncthreads();
+        cp_in_lds = true;
+      }
     }
   }
   if (jo >= a.Jo || ko >= a.Ko) return;
 
   const int64_t n_in = static_cast<int64_t>(a.I) * a.J * a.K;
   const int64_t n_out = static_cast<int64_t>(a.Io) * a.Jo * a.Ko;
-  const int64_t o_idx = (static_cast<int64_t>(io) * a.Jo + jo) * a.Ko + ko;
+  const int64_t row = static_cast<int64_t>(jo) * a.Ko + ko;
+  const int64_t slab = static_cast<int64_t>(a.Jo) * a.Ko;
 
   if (pass) {  // gated-out element: bit-exact copy (spatial.py:1101-1106)
-    for (int im = 0; im < a.n_images; im++) {
-      const ImgArgs& g = a.img[im];
-      const int es = dtype_size(g.dtype);
-      for (int c = 0; c < g.channels; c++) {
-        const int64_t off = (static_cast<int64_t>(b) * g.channels + c) * n_out + o_idx;
-        const char* s = static_cast<const char*>(g.in) + off * es;
-        char* d = static_cast<char*>(g.out) + off * es;
-        for (int e = 0; e < es; e++) d[e] = s[e];
+    for (int io = i_begin; io < i_end; io++) {
+      const int64_t o_idx = io * slab + row;
+      for (int im = 0; im < a.n_images; im++) {
+        const ImgArgs& g = a.img[im];
+        const int es = dtype_size(g.dtype);
+        for (int c = 0; c < g.channels; c++) {
+          const int64_t off = (static_cast<int64_t>(b) * g.channels + c) * n_out + o_idx;
+          const char* s = static_cast<const char*>(g.in) + off * es;
+          char* d = static_cast<char*>(g.out) + off * es;
+          for (int e = 0; e < es; e++) d[e] = s[e];
+        }
       }
     }
     return;
   }
 
   const float* m = a.mapping + (a.mapping_batched ? b * 12 : 0);
-  const float ci = static_cast<float>(io), cj = static_cast<float>(jo), ck = static_cast<float>(ko);
-  float vi, vj, vk;
-  if (elastic) {
-    const Lerp1D li = lerp_index(io, a.ni, a.Io, a.scale_i);
-    const Lerp1D lj = lerp_index(jo, a.nj, a.Jo, a.scale_j);
-    const Lerp1D lk = lerp_index(ko, a.nk, a.Ko, a.scale_k);
-    const int s_i = a.nj * a.nk * 3, s_j = a.nk * 3;
-    const float di = cp_trilerp(cp + 0, s_i, s_j, li, lj, lk);
-    const float dj = cp_trilerp(cp + 1, s_i, s_j, li, lj, lk);
-    const float dk = cp_trilerp(cp + 2, s_i, s_j, li, lj, lk);
-    if (a.affine_first) {  // spatial.py:1570-1573
-      vi = __fadd_rn(affine_row(m + 0, ci, cj, ck), __fdiv_rn(di, a.sp0));
-      vj = __fadd_rn(affine_row(m + 4, ci, cj, ck), __fdiv_rn(dj, a.sp1));
-      vk = __fadd_rn(affine_row(m + 8, ci, cj, ck), __fdiv_rn(dk, a.sp2));
-    } else {  // spatial.py:1574-1577
-      const float ei = __fadd_rn(ci, __fdiv_rn(di, a.sp0));
-      const float ej = __fadd_rn(cj, __fdiv_rn(dj, a.sp1));
-      const float ek = __fadd_rn(ck, __fdiv_rn(dk, a.sp2));
-      vi = affine_row(m + 0, ei, ej, ek);
-      vj = affine_row(m + 4, ei, ej, ek);
-      vk = affine_row(m + 8, ei, ej, ek);
+  const float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
+  const float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+  const float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
+  const float cj = static_cast<float>(jo), ck = static_cast<float>(ko);
+
+  // k- and j-dependent control-grid lerp terms are loop invariants
+  Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
+  int s_i = 0, s_j = 0;
+  if constexpr (ELASTIC_POSSIBLE) {
+    if (elastic) {
+      lj = lerp_index(jo, a.nj, a.Jo, a.scale_j);
+      lk = lerp_index(ko, a.nk, a.Ko, a.scale_k);
+      s_i = a.nj * a.nk * 3;
+      s_j = a.nk * 3;
     }
-  } else {  // spatial.py:1542-1543
-    vi = affine_row(m + 0, ci, cj, ck);
-    vj = affine_row(m + 4, ci, cj, ck);
-    vk = affine_row(m + 8, ci, cj, ck);
   }
-  // torchio axis i ≡ grid x ≡ ATen W ; j ≡ y ≡ H ; k ≡ z ≡ D
-  const float x = normalise_roundtrip(vi, a.I);
-  const float y = normalise_roundtrip(vj, a.J);
-  const float z = normalise_roundtrip(vk, a.K);
+  const int dJK = a.J * a.K, dK = a.K;
+  const float hx = a.size_m1[0], hy = a.size_m1[1], hz = a.size_m1[2];
 
-  // ATen grid_sampler_3d corner weights, order tnw,tne,tsw,tse,bnw,bne,bsw,bse
-  const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
-  const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
-  const float wx0 = x1 - x, wx1 = x - x0;
-  const float wy0 = y1 - y, wy1 = y - y0;
-  const float wz0 = z1 - z, wz1 = z - z0;
-  float w[8];
-  w[0] = __fmul_rn(__fmul_rn(wx0, wy0), wz0);
-  w[1] = __fmul_rn(__fmul_rn(wx1, wy0), wz0);
-  w[2] = __fmul_rn(__fmul_rn(wx0, wy1), wz0);
-  w[3] = __fmul_rn(__fmul_rn(wx1, wy1), wz0);
-  w[4] = __fmul_rn(__fmul_rn(wx0, wy0), wz1);
-  w[5] = __fmul_rn(__fmul_rn(wx1, wy0), wz1);
-  w[6] = __fmul_rn(__fmul_rn(wx0, wy1), wz1);
-  w[7] = __fmul_rn(__fmul_rn(wx1, wy1), wz1);
-
-  const bool bx0 = in_bounds(x0, a.I), bx1 = in_bounds(x1, a.I);
-  const bool by0 = in_bounds(y0, a.J), by1 = in_bounds(y1, a.J);
-  const bool bz0 = in_bounds(z0, a.K), bz1 = in_bounds(z1, a.K);
-  bool ok[8];
-  int off[8];
-#pragma unroll
-  for (int t = 0; t < 8; t++) {
-    const bool bx = (t & 1) ? bx1 : bx0, by = (t & 2) ? by1 : by0, bz = (t & 4) ? bz1 : bz0;
-    ok[t] = bx && by && bz;
-    const float fx = (t & 1) ? x1 : x0, fy = (t & 2) ? y1 : y0, fz = (t & 4) ? z1 : z0;
-    off[t] = ok[t] ? (static_cast<int>(fx) * a.J + static_cast<int>(fy)) * a.K + static_cast<int>(fz) : 0;
-  }
-  float mask = 0.0f;  // == F.grid_sample(ones) (spatial.py:1721-1727)
-#pragma unroll
-  for (int t = 0; t < 8; t++) mask = ok[t] ? __fadd_rn(mask, w[t]) : mask;
-
-  // nearest: nearbyint = round half to even (v_rndne_f32)
-  const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
-  const bool okn = in_bounds(xn, a.I) && in_bounds(yn, a.J) && in_bounds(zn, a.K);
-  const int offn = okn ? (static_cast<int>(xn) * a.J + static_cast<int>(yn)) * a.K + static_cast<int>(zn) : 0;
-
-  for (int im = 0; im < a.n_images; im++) {
-    const ImgArgs& g = a.img[im];
-    for (int c = 0; c < g.channels; c++) {
-      const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
-      const int64_t base_in = bc * n_in;
-      float val;
-      if (g.interp == TIO_LINEAR) {
-        val = 0.0f;
-        if (g.dtype == TIO_F32) {
-          const float* p = static_cast<const float*>(g.in) + base_in;
-#pragma unroll
-          for (int t = 0; t < 8; t++) {
-            const float v = p[off[t]];
-            val = ok[t] ? __fadd_rn(val, __fmul_rn(v, w[t])) : val;
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; t++) {
-            const float v = load_as_float(g.in, g.dtype, base_in + off[t]);
-            val = ok[t] ? __fadd_rn(val, __fmul_rn(v, w[t])) : val;
-          }
+  for (int io = i_begin; io < i_end; io++) {
+    const float ci = static_cast<float>(io);
+    float vi, vj, vk;
+    // [c,1] @ M^T per row: a*m0, then fma(b,m1,.), fma(c,m2,.), fma(1,m3,.) — the
+    // rounding sequence of MKL sgemm (K = 4), pinned against the reference.
+#define TIO_AFFINE_ROW(M0, M1, M2, M3, A, B, C) \
+  __builtin_fmaf(1.0f, M3, __builtin_fmaf(C, M2, __builtin_fmaf(B, M1, __fmul_rn(A, M0))))
+    bool done = false;
+    if constexpr (ELASTIC_POSSIBLE) {
+      if (elastic) {
+        const Lerp1D li = lerp_index(io, a.ni, a.Io, a.scale_i);
+        const Disp d = cp_in_lds ? cp_trilerp3(s_cp, s_i, s_j, li, lj, lk) : cp_trilerp3(cp_global, s_i, s_j, li, lj, lk);
+        float di = d.i, dj = d.j, dk = d.k;
+        if (!a.unit_spacing) {  // mm → voxels: true division by the spacing
+          di = exact_div(di, a.sp[0], a.rsp[0]);
+          dj = exact_div(dj, a.sp[1], a.rsp[1]);
+          dk = exact_div(dk, a.sp[2], a.rsp[2]);
         }
-      } else {
-        const float v = load_as_float(g.in, g.dtype, base_in + offn);
-        val = okn ? v : 0.0f;
+        if (a.affine_first) {  // spatial.py:1570-1573
+          vi = __fadd_rn(TIO_AFFINE_ROW(m00, m01, m02, m03, ci, cj, ck), di);
+          vj = __fadd_rn(TIO_AFFINE_ROW(m10, m11, m12, m13, ci, cj, ck), dj);
+          vk = __fadd_rn(TIO_AFFINE_ROW(m20, m21, m22, m23, ci, cj, ck), dk);
+        } else {  // spatial.py:1574-1577
+          const float ei = __fadd_rn(ci, di), ej = __fadd_rn(cj, dj), ek = __fadd_rn(ck, dk);
+          vi = TIO_AFFINE_ROW(m00, m01, m02, m03, ei, ej, ek);
+          vj = TIO_AFFINE_ROW(m10, m11, m12, m13, ei, ej, ek);
+          vk = TIO_AFFINE_ROW(m20, m21, m22, m23, ei, ej, ek);
+        }
+        done = true;
       }
-      if (g.fill != nullptr) val = (mask > 0.5f) ? val : g.fill[c];
-      store_from_float(g.out, g.dtype, bc * n_out + o_idx, val);
+    }
+    if (!done) {  // spatial.py:1542-1543
+      vi = TIO_AFFINE_ROW(m00, m01, m02, m03, ci, cj, ck);
+      vj = TIO_AFFINE_ROW(m10, m11, m12, m13, ci, cj, ck);
+      vk = TIO_AFFINE_ROW(m20, m21, m22, m23, ci, cj, ck);
+    }
+#undef TIO_AFFINE_ROW
+    // torchio axis i ≡ grid x ≡ ATen W ; j ≡ y ≡ H ; k ≡ z ≡ D
+    const float x = normalise_roundtrip(vi, a.den[0], a.rden[0], hx);
+    const float y = normalise_roundtrip(vj, a.den[1], a.rden[1], hy);
+    const float z = normalise_roundtrip(vk, a.den[2], a.rden[2], hz);
+
+    // ATen grid_sampler_3d corner weights (computed even for nearest data when a fill
+    // mask is needed: the mask is always trilinear, spatial.py:1722-1727)
+    const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+    float w[8];
+    bool interior = true;
+    if (a.any_linear) {
+      const float wx0 = x1 - x, wx1 = x - x0;
+      const float wy0 = y1 - y, wy1 = y - y0;
+      const float wz0 = z1 - z, wz1 = z - z0;
+      w[0] = __fmul_rn(__fmul_rn(wx0, wy0), wz0);
+      w[1] = __fmul_rn(__fmul_rn(wx1, wy0), wz0);
+      w[2] = __fmul_rn(__fmul_rn(wx0, wy1), wz0);
+      w[3] = __fmul_rn(__fmul_rn(wx1, wy1), wz0);
+      w[4] = __fmul_rn(__fmul_rn(wx0, wy0), wz1);
+      w[5] = __fmul_rn(__fmul_rn(wx1, wy0), wz1);
+      w[6] = __fmul_rn(__fmul_rn(wx0, wy1), wz1);
+      w[7] = __fmul_rn(__fmul_rn(wx1, wy1), wz1);
+      // x0 ∈ [0, S-2] ⇔ x0 and x1 both in bounds (integral floats; NaN fails)
+      interior = (x0 >= 0.0f) & (x0 <= hx - 1.0f) & (y0 >= 0.0f) & (y0 <= hy - 1.0f) & (z0 >= 0.0f) & (z0 <= hz - 1.0f);
+    }
+    // nearest: nearbyint = round half to even (v_rndne_f32)
+    const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
+    bool okn = true;
+    if (a.any_nearest) {
+      okn = (xn >= 0.0f) & (xn <= hx) & (yn >= 0.0f) & (yn <= hy) & (zn >= 0.0f) & (zn <= hz);
+      interior = interior & okn;
+    }
+    const int64_t o_idx = io * slab + row;
+
+    if (__builtin_amdgcn_ballot_w64(!interior) == 0) {  // wave-uniform: whole wave interior
+      const int base = (static_cast<int>(x0) * a.J + static_cast<int>(y0)) * a.K + static_cast<int>(z0);
+      const int offn = (static_cast<int>(xn) * a.J + static_cast<int>(yn)) * a.K + static_cast<int>(zn);
+      for (int im = 0; im < a.n_images; im++) {
+        const ImgArgs& g = a.img[im];
+#define TIO_CALL(DT) sample_interior<DT>(g, b, n_in, n_out, o_idx, w, base, dJK, dK, offn)
+        TIO_DISPATCH_IMAGE(DTMODE, g.dtype, TIO_CALL)
+#undef TIO_CALL
+      }
+    } else {
+      const bool bx0 = (x0 >= 0.0f) & (x0 <= hx), bx1 = (x1 >= 0.0f) & (x1 <= hx);
+      const bool by0 = (y0 >= 0.0f) & (y0 <= hy), by1 = (y1 >= 0.0f) & (y1 <= hy);
+      const bool bz0 = (z0 >= 0.0f) & (z0 <= hz), bz1 = (z1 >= 0.0f) & (z1 <= hz);
+      // clamp before the int conversion so that far-away coordinates stay defined
+      const int ix0 = static_cast<int>(fminf(fmaxf(x0, 0.0f), hx)), ix1 = static_cast<int>(fminf(fmaxf(x1, 0.0f), hx));
+      const int iy0 = static_cast<int>(fminf(fmaxf(y0, 0.0f), hy)), iy1 = static_cast<int>(fminf(fmaxf(y1, 0.0f), hy));
+      const int iz0 = static_cast<int>(fminf(fmaxf(z0, 0.0f), hz)), iz1 = static_cast<int>(fminf(fmaxf(z1, 0.0f), hz));
+      int off[8];
+      unsigned okbits = 0;
+      float mask = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool ok = ((k & 1) ? bx1 : bx0) & ((k & 2) ? by1 : by0) & ((k & 4) ? bz1 : bz0);
+        off[k] = (((k & 1) ? ix1 : ix0) * a.J + ((k & 2) ? iy1 : iy0)) * a.K + ((k & 4) ? iz1 : iz0);
+        okbits |= ok ? (1u << k) : 0u;
+        if (a.any_linear) {
+          const float next = __fadd_rn(mask, w[k]);  // same order as ATen's accumulation
+          mask = ok ? next : mask;
+        }
+      }
+      const int offn = (static_cast<int>(fminf(fmaxf(xn, 0.0f), hx)) * a.J + static_cast<int>(fminf(fmaxf(yn, 0.0f), hy))) * a.K +
+                       static_cast<int>(fminf(fmaxf(zn, 0.0f), hz));
+      for (int im = 0; im < a.n_images; im++) {
+        const ImgArgs& g = a.img[im];
+#define TIO_CALL(DT) sample_boundary<DT>(g, b, n_in, n_out, o_idx, w, off, okbits, mask, offn, okn)
+        TIO_DISPATCH_IMAGE(DTMODE, g.dtype, TIO_CALL)
+#undef TIO_CALL
+      }
     }
   }
 }
@@ -277,8 +422,19 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
   a.cp_skip = geom->cp_skip_dev;
   a.passthrough = geom->passthrough_dev;
   const float* sp = geom->affine_first ? geom->in_spacing : geom->out_spacing;
-  a.sp0 = sp[0]; a.sp1 = sp[1]; a.sp2 = sp[2];
+  a.unit_spacing = 1;
+  for (int d = 0; d < 3; d++) {
+    a.sp[d] = sp[d];
+    a.rsp[d] = 1.0f / sp[d];
+    if (sp[d] != 1.0f) a.unit_spacing = 0;
+    const int size = geom->in_shape[d];
+    a.den[d] = static_cast<float>(size - 1 > 1 ? size - 1 : 1);
+    a.rden[d] = 1.0f / a.den[d];
+    a.size_m1[d] = static_cast<float>(size - 1);
+  }
   if (a.cp != nullptr) {
+    if (geom->control_points_dev != nullptr && !(sp[0] > 0.0f && sp[1] > 0.0f && sp[2] > 0.0f))
+      return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: spacing must be positive");
     a.scale_i = lerp_scale(a.ni, a.Io);
     a.scale_j = lerp_scale(a.nj, a.Jo);
     a.scale_k = lerp_scale(a.nk, a.Ko);
@@ -292,19 +448,36 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d interp %d", i, s.interp);
     a.img[i] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp};
+    // the in-bounds weight mask needs the trilinear weights even for nearest data (spatial.py:1722-1727)
+    if (s.interp == TIO_LINEAR || s.fill_dev != nullptr) a.any_linear = 1;
+    if (s.interp == TIO_NEAREST) a.any_nearest = 1;
   }
   if (a.B == 0) return TIO_OK;
 
   a.tiles_k = (a.Ko + kLanes - 1) / kLanes;
   a.tiles_j = (a.Jo + kRowsPerBlock - 1) / kRowsPerBlock;
-  const int64_t blocks = static_cast<int64_t>(a.B) * a.Io * a.tiles_j * a.tiles_k;
+  a.tiles_i = (a.Io + kTileI - 1) / kTileI;
+  const int64_t blocks = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
   if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kRowsPerBlock * kLanes);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int dtmode = 0;
+  for (int i = 0; i < n_images; i++) {
+    const int dt = images[i].dtype;
+    const int need = dt == TIO_F32 ? 0 : ((dt == TIO_I16 || dt == TIO_U8 || dt == TIO_I32) ? 1 : 2);
+    dtmode = need > dtmode ? need : dtmode;
+  }
   size_t lds = 0;
   if (a.cp != nullptr) {
     const int n_cp = a.ni * a.nj * a.nk * 3;
-    if (n_cp <= kMaxCpLds) lds = static_cast<size_t>(n_cp) * sizeof(float);
+    lds = n_cp <= kMaxCpLds ? static_cast<size_t>(n_cp) * sizeof(float) : 0;
   }
-  hipLaunchKernelGGL(resample_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kRowsPerBlock * kLanes), lds,
-                     static_cast<hipStream_t>(stream), a);
+#define TIO_LAUNCH(EL, DM) hipLaunchKernelGGL((resample_kernel<EL, DM>), grid, block, lds, s, a)
+  if (a.cp != nullptr) {
+    if (dtmode == 0) TIO_LAUNCH(true, 0); else if (dtmode == 1) TIO_LAUNCH(true, 1); else TIO_LAUNCH(true, 2);
+  } else {
+    if (dtmode == 0) TIO_LAUNCH(false, 0); else if (dtmode == 1) TIO_LAUNCH(false, 1); else TIO_LAUNCH(false, 2);
+  }
+#undef TIO_LAUNCH
   return check_launch("tio_resample3d");
 }
