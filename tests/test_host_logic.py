@@ -1,0 +1,318 @@
+"""CPU tests of the host-side mirror (sampling, gating, history, inverse, wrapping, errors).
+
+Modelled on the reference's own behavioural tests (identity,
+gated-out rows are bit-exact no-ops, seeded reproducibility, label values stay in
+the input set, inverse restores geometry, dtype preservation).  The compute runs
+on the CPU oracle through the test-only engine hook.
+"""
+from __future__ import annotations
+
+import copy
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import torchio_amd as tio
+from parity_harness import make_subjects
+from parity_harness import use_engine
+from torchio_amd.transforms.parameter_range import _ParameterRange
+from torchio_amd.transforms.parameter_range import to_nonneg_range
+
+
+@pytest.fixture(autouse=True)
+def _oracle_engine(oracle):
+    with use_engine(oracle), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield
+
+
+def subject(size=12, seed=0):
+    return make_subjects(size, 1, seed)[0]
+
+
+def batch(n=4, size=10, seed=0):
+    return tio.SubjectsBatch.from_subjects(make_subjects(size, n, seed))
+
+
+# -- parameter ranges ---------------------------------------------------------------
+def test_parameter_range_forms_and_draw_order():
+    assert _ParameterRange(2.0).sample() == (2.0, 2.0, 2.0)
+    assert _ParameterRange((1.0, 2.0, 3.0)).sample() == (1.0, 2.0, 3.0)
+    torch.manual_seed(0)
+    a = _ParameterRange((0.0, 1.0)).sample()
+    torch.manual_seed(0)
+    b = tuple(torch.empty(1).uniform_(0.0, 1.0).item() for _ in range(3))
+    assert a == b  # one uniform_ draw per axis, in axis order
+    torch.manual_seed(0)
+    state = torch.get_rng_state()
+    _ParameterRange((5.0, 5.0)).sample()  # degenerate range draws nothing
+    assert torch.equal(state, torch.get_rng_state())
+    six = _ParameterRange((0, 1, 2, 3, 4, 5))._ranges
+    assert six == ((0.0, 1.0), (2.0, 3.0), (4.0, 5.0))
+    assert _ParameterRange((0.0, 1.0)).sample(5).shape == (5, 3)
+    assert _ParameterRange(tio.Choice([1, 2, 3])).sample_1d(7).shape == (7,)
+    with pytest.raises(ValueError):
+        to_nonneg_range((-1.0, 1.0))
+    with pytest.raises(ValueError):
+        _ParameterRange((1.0, 2.0, 3.0, 4.0))
+    with pytest.raises(TypeError):
+        _ParameterRange("x")
+
+
+def test_constructor_validation_matches_reference_errors():
+    with pytest.raises(ValueError, match="Probability"):
+        tio.Affine(p=1.5)
+    with pytest.raises(ValueError, match="strictly positive"):
+        tio.Affine(scales=(0.0, 1.0))
+    with pytest.raises(ValueError, match="isotropic"):
+        tio.Affine(scales=(0.9, 1.1, 0.9, 1.1, 0.9, 1.1), isotropic=True)
+    with pytest.raises(ValueError, match="not supported"):
+        tio.Spatial(image_interpolation="bicubic")
+    with pytest.raises(ValueError, match="image_interpolation cannot"):
+        tio.Spatial(image_interpolation="label")
+    with pytest.raises(ValueError, match="locked_borders"):
+        tio.ElasticDeformation(locked_borders=3)
+    with pytest.raises(ValueError, match="identity elastic field"):
+        tio.ElasticDeformation(num_control_points=4)
+    with pytest.raises(ValueError, match="greater than 3"):
+        tio.ElasticDeformation(num_control_points=3)
+    with pytest.raises(ValueError, match="scale must be"):
+        tio.BiasField(scale=0.0)
+    with pytest.raises(ValueError, match="non-negative"):
+        tio.Noise(std=(-1.0, 1.0))
+    with pytest.raises(ValueError, match="default_pad_value"):
+        tio.Affine(default_pad_value="median")
+    with pytest.warns(UserWarning, match="no-op"):
+        tio.Affine()
+    with pytest.warns(UserWarning, match="no-op"):
+        tio.Gamma()
+
+
+def test_unsupported_modes_raise_instead_of_falling_back():
+    s = subject()
+    with pytest.raises(NotImplementedError, match="not implemented by the HIP engine"):
+        tio.Affine(degrees=(5, 5), image_interpolation="cubic")(s)
+    with pytest.raises(NotImplementedError):
+        tio.Affine(degrees=(5, 5), label_interpolation="label")(s)
+
+
+# -- envelope: copy, wrapping, scope ------------------------------------------------
+def test_copy_semantics_and_output_types():
+    s = subject()
+    before = s.t1.data.clone()
+    out = tio.Noise(std=0.5)(s)
+    assert torch.equal(s.t1.data, before) and not torch.equal(out.t1.data, before)
+    assert isinstance(out, tio.Subject) and [t.name for t in out.applied_transforms] == ["Noise"]
+    tensor = torch.rand(1, 8, 8, 8)
+    assert isinstance(tio.Gamma(log_gamma=0.3)(tensor), torch.Tensor)
+    array = np.random.rand(1, 8, 8, 8).astype(np.float32)
+    assert isinstance(tio.Gamma(log_gamma=0.3)(array), np.ndarray)
+    image = tio.ScalarImage(tensor)
+    result = tio.Gamma(log_gamma=0.3)(image)
+    assert isinstance(result, tio.ScalarImage) and result.applied_transforms[0].name == "Gamma"
+    as_dict = tio.Gamma(log_gamma=0.3)({"a": tensor, "meta": 3})
+    assert isinstance(as_dict["a"], torch.Tensor) and as_dict["meta"] == 3
+    images = tio.ImagesBatch(torch.rand(2, 1, 6, 6, 6), [tio.AffineMatrix(), tio.AffineMatrix()])
+    assert isinstance(tio.Gamma(log_gamma=0.3)(images), tio.ImagesBatch)
+    with pytest.raises(TypeError, match="Expected Subject"):
+        tio.Gamma(log_gamma=0.3)("not data")
+
+
+def test_intensity_transforms_skip_label_maps_and_honour_include_exclude():
+    s = make_subjects(10, 1, 3, second_modality=True)[0]
+    seg = s.seg.data.clone()
+    out = tio.Compose([tio.BiasField(), tio.Blur(std=1.0), tio.Noise(), tio.Gamma(log_gamma=0.2)])(s)
+    assert torch.equal(out.seg.data, seg)
+    out = tio.Noise(include=["t2"])(s)
+    assert torch.equal(out.t1.data, s.t1.data) and not torch.equal(out.t2.data, s.t2.data)
+    out = tio.Affine(degrees=(10, 10), exclude=["seg"])(s)
+    assert torch.equal(out.seg.data, seg) and not torch.equal(out.t1.data, s.t1.data)
+    assert out.applied_transforms[0].exclude == ["seg"]
+
+
+def test_p_zero_and_p_one():
+    s = subject()
+    assert torch.equal(tio.Noise(p=0.0)(s).t1.data, s.t1.data)
+    assert tio.Noise(p=0.0)(s).applied_transforms == []
+    assert not torch.equal(tio.Noise(p=1.0)(s).t1.data, s.t1.data)
+
+
+# -- spatial ------------------------------------------------------------------------
+def test_noop_spatial_is_exact_identity():
+    s = subject()
+    with pytest.warns(UserWarning):
+        transform = tio.Affine()
+    out = transform(s)
+    assert torch.equal(out.t1.data, s.t1.data) and out.t1.affine == s.t1.affine
+
+
+def test_label_values_stay_in_input_set_and_seeded_reproducibility():
+    s = subject(size=16)
+    transform = tio.Spatial(degrees=(-20, 20), scales=(0.8, 1.2), max_displacement=4.0)
+    torch.manual_seed(7)
+    a = transform(s)
+    torch.manual_seed(7)
+    b = transform(s)
+    assert torch.equal(a.t1.data, b.t1.data) and torch.equal(a.seg.data, b.seg.data)
+    assert set(a.seg.data.unique().tolist()) <= set(s.seg.data.unique().tolist())
+    torch.manual_seed(8)
+    assert not torch.equal(transform(s).t1.data, a.t1.data)
+
+
+def test_resample_bookkeeping():
+    s = subject(size=12)
+    out = tio.Resample(2)(s)
+    assert out.t1.spatial_shape == (6, 6, 6) and out.t1.spacing == (2.0, 2.0, 2.0)
+    assert out.seg.spatial_shape == (6, 6, 6)
+    target = tio.ScalarImage(torch.zeros(1, 5, 7, 9), affine=tio.AffineMatrix.from_spacing((1.5, 1.0, 0.75)))
+    out = tio.Resample(target)(s)
+    assert out.t1.spatial_shape == (5, 7, 9) and np.allclose(out.t1.spacing, (1.5, 1.0, 0.75))
+    out = tio.Resample("seg")(s)
+    assert out.t1.spatial_shape == s.seg.spatial_shape
+    with pytest.raises(ValueError, match="Unknown target"):
+        tio.Resample("nope")(s)
+
+
+def test_pad_value_semantics():
+    s = subject(size=10)
+    s.t1.set_data(s.t1.data + 5.0)  # minimum > 0
+    far = tio.Affine(translation=(100.0, 0.0, 0.0))
+    out = far(s)
+    assert torch.all(out.t1.data == s.t1.data.min())  # "minimum" fill
+    assert torch.all(out.seg.data == 0)  # default_pad_label
+    out = tio.Affine(translation=(100.0, 0.0, 0.0), default_pad_value=-2.0, default_pad_label=9)(s)
+    assert torch.all(out.t1.data == -2.0) and torch.all(out.seg.data == 9)
+
+
+def test_shared_space_is_enforced():
+    a = tio.ScalarImage(torch.rand(1, 8, 8, 8))
+    b = tio.ScalarImage(torch.rand(1, 8, 8, 8), affine=tio.AffineMatrix.from_spacing((2, 2, 2)))
+    with pytest.raises(RuntimeError, match="share the same affine"):
+        tio.Affine(degrees=(10, 10))(tio.Subject(a=a, b=b))
+    c = tio.ScalarImage(torch.rand(1, 8, 8, 6))
+    with pytest.raises(RuntimeError, match="has shape"):
+        tio.Affine(degrees=(10, 10))(tio.Subject(a=a, c=c))
+
+
+# -- per-instance / per-element gating ----------------------------------------------
+@pytest.mark.parametrize(
+    "make",
+    [
+        lambda: tio.Affine(degrees=(-15, 15), p=0.5),
+        lambda: tio.ElasticDeformation(p=0.5),
+        lambda: tio.BiasField(p=0.5),
+        lambda: tio.Blur(std=(0.5, 1.5), p=0.5),
+        lambda: tio.Noise(rician=True, p=0.5),
+        lambda: tio.Gamma(log_gamma=(-0.4, 0.4), p=0.5),
+    ],
+)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_gated_out_rows_are_bit_exact_noops(make, dtype):
+    data = batch(n=6, size=8, seed=11)
+    data.t1.data = data.t1.data.to(dtype)
+    original = data.t1.data.clone()
+    for seed in range(50):  # first seed whose per-element gate keeps some rows and drops others
+        torch.manual_seed(seed)
+        out = make()(data)
+        keep = out.applied_transforms[-1].params.get("_keep") if out.applied_transforms else None
+        if keep is not None and any(keep) and not all(keep):
+            break
+    else:
+        pytest.fail("no seed produced a mixed keep mask")
+    for index, kept in enumerate(keep):
+        same = torch.equal(out.t1.data[index], original[index])
+        assert same == (not kept), f"element {index} kept={kept}"
+    assert out.t1.data.dtype == dtype
+
+
+def test_per_instance_equals_element_by_element():
+    """The reference's `assert_vectorized` idea: batched result == each element with its sliced params."""
+    data = batch(n=3, size=10, seed=5)
+    for transform in (tio.Blur(std=(0.3, 1.5)), tio.BiasField(), tio.Gamma(log_gamma=(-0.3, 0.3)),
+                      # numeric pad: the "minimum" fill is taken from the FIRST batch element (spatial.py:2054-2055)
+                      tio.Spatial(degrees=(-10, 10), max_displacement=3.0, default_pad_value=0.25)):
+        torch.manual_seed(1)
+        out = transform(data)
+        subjects = out.unbatch()
+        for index, original in enumerate(data.unbatch()):
+            params = subjects[index].applied_transforms[-1].params
+            assert "_batched_keys" not in params
+            single = tio.SubjectsBatch.from_subjects([copy.deepcopy(original)])
+            redone = transform.apply_transform(single, params)
+            torch.testing.assert_close(redone.t1.data[0], out.t1.data[index], rtol=1e-5, atol=1e-6)
+            assert torch.equal(redone.seg.data[0], out.seg.data[index])
+
+
+def test_per_instance_false_shares_parameters():
+    data = batch(n=3, size=8, seed=2)
+    data.t1.data = data.t1.data[:1].repeat(3, 1, 1, 1, 1)
+    torch.manual_seed(0)
+    out = tio.Affine(degrees=(-20, 20), per_instance=False)(data)
+    assert "_batched_keys" not in out.applied_transforms[-1].params
+    assert torch.equal(out.t1.data[0], out.t1.data[1]) and torch.equal(out.t1.data[1], out.t1.data[2])
+    torch.manual_seed(0)
+    out = tio.Affine(degrees=(-20, 20))(data)
+    assert not torch.equal(out.t1.data[0], out.t1.data[1])
+
+
+def test_dtype_promotion_follows_the_reference():
+    half = tio.SubjectsBatch.from_subjects(make_subjects(8, 2, 0))
+    half.t1.data = half.t1.data.half()
+    assert tio.Affine(degrees=(5, 5))(half).t1.data.dtype == torch.float16  # resample casts back
+    assert tio.Blur(std=1.0)(half).t1.data.dtype == torch.float16
+    assert tio.Noise()(half).t1.data.dtype == torch.float32  # data + float32 noise promotes
+    assert tio.BiasField()(half).t1.data.dtype == torch.float16  # per-instance path casts back
+    assert tio.BiasField(per_instance=False)(half).t1.data.dtype == torch.float32  # shared path promotes
+    assert tio.Gamma(log_gamma=(0.1, 0.2))(half).t1.data.dtype == torch.float32  # per-element exponent tensor
+    assert tio.Gamma(log_gamma=0.2, per_instance=False)(half).t1.data.dtype == torch.float16
+
+
+# -- history / inverse ---------------------------------------------------------------
+def test_history_params_are_json_serialisable_and_replayable():
+    import json
+
+    s = subject(size=12)
+    torch.manual_seed(0)
+    out = tio.Compose([tio.Spatial(degrees=(-10, 10), max_displacement=3.0), tio.BiasField(), tio.Gamma(log_gamma=(-0.2, 0.2))])(s)
+    for trace in out.applied_transforms:
+        restored = json.loads(json.dumps(trace.params))
+        assert restored == trace.params
+    replay = tio.Spatial(degrees=0.0)
+    redone = replay.apply_transform(tio.SubjectsBatch.from_subjects([copy.deepcopy(s)]), out.applied_transforms[0].params)
+    again = tio.Spatial().apply_transform(tio.SubjectsBatch.from_subjects([copy.deepcopy(s)]), out.applied_transforms[0].params)
+    assert torch.equal(redone.seg.data, again.seg.data)
+
+
+def test_inverse_restores_geometry_and_intensity():
+    s = subject(size=16)
+    torch.manual_seed(0)
+    out = tio.Compose([tio.Affine(degrees=(-10, 10), translation=(-2, 2)), tio.Gamma(log_gamma=(-0.3, 0.3)), tio.BiasField(), tio.Noise()])(s)
+    with pytest.warns(UserWarning, match="Noise is not invertible"):
+        restored = out.apply_inverse_transform()
+    assert restored.applied_transforms == []
+    assert restored.t1.spatial_shape == s.t1.spatial_shape and restored.t1.affine == s.t1.affine
+    restored = out.apply_inverse_transform(warn=False, ignore_intensity=True)
+    assert restored.t1.spatial_shape == s.t1.spatial_shape
+    only = tio.Compose([tio.Gamma(log_gamma=0.4), tio.BiasField()])(s)
+    back = only.apply_inverse_transform()
+    torch.testing.assert_close(back.t1.data, s.t1.data, rtol=1e-4, atol=1e-5)
+
+
+def test_batch_inverse_after_per_instance_transform():
+    data = batch(n=3, size=10, seed=9)
+    torch.manual_seed(4)
+    out = tio.Compose([tio.Gamma(log_gamma=(-0.3, 0.3)), tio.BiasField()])(data)
+    back = out.apply_inverse_transform()
+    torch.testing.assert_close(back.t1.data, data.t1.data, rtol=1e-4, atol=1e-5)
+    subjects = out.unbatch()
+    back0 = subjects[0].apply_inverse_transform()
+    torch.testing.assert_close(back0.t1.data, data.t1.data[0], rtol=1e-4, atol=1e-5)
+
+
+def test_compose_operators_and_repr():
+    pipeline = tio.Affine(degrees=(1, 2)) + tio.Noise(std=0.1)
+    assert isinstance(pipeline, tio.Compose) and len(pipeline) == 2
+    assert "Noise(std=0.1)" in repr(pipeline)
+    assert repr(tio.Blur(std=(0.5, 2))) == "Blur(std=(0.5, 2))"

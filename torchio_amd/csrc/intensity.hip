@@ -16,75 +16,170 @@ constexpr int kBlock = 256;
 // =============================================================================
 // Separable cross-correlation with replicate padding
 // =============================================================================
-// One pass = one axis.  Thread = one output voxel, lanes along K (contiguous):
-// for the I and J axes every tap is a fully coalesced row read, for the K axis
-// the wave's taps overlap in L1.
-template <int SRC_DT, int DST_DT>
-__global__ __launch_bounds__(kBlock) void conv_axis_kernel(
-    const void* __restrict__ src, void* __restrict__ dst, int64_t n_spatial, int I, int J, int K,
-    int channels, int axis, int radius, const float* __restrict__ taps, int taps_batched,
-    int tap_stride, const uint8_t* __restrict__ skip, int first_pass, const void* __restrict__ x_orig,
-    int orig_dtype, int last_pass) {
-  extern __shared__ __attribute__((aligned(16))) float s_taps[];
-  const int bc = blockIdx.y;
-  const int b = bc / channels;
-  const float* t = taps + (taps_batched ? static_cast<int64_t>(b) * 3 * tap_stride : 0) +
-                   static_cast<int64_t>(axis) * tap_stride;
-  const int ntaps = 2 * radius + 1;
-  for (int i = threadIdx.x; i < ntaps; i += blockDim.x) s_taps[i] = t[i];
-  __syncthreads();
+// One pass = one axis.  Lanes always run along K (contiguous), so every global
+// access is a coalesced row segment.  A block stages the line segment it needs
+// (+ replicate-clamped halo) in LDS once and every thread then reads its
+// 2r+1 taps from LDS in tap order — the accumulation order of the oracle — so
+// each input element is fetched from HBM/L2 ~once per pass instead of 2r+1 times.
+//   axis I / J : tile = kConvLine outputs along the axis x 64 lanes along K
+//   axis K     : tile = 4 rows x 256 outputs along K (one wave per row)
+constexpr int kConvLine = 32;   // outputs along the stencil axis per block (axes I, J)
+constexpr int kConvKSpan = 256; // outputs along K per wave (axis K)
+constexpr int kMaxRadius = 48;  // LDS budget: (32 + 96) * 64 * 4 B = 32 KiB
 
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= n_spatial) return;
+struct ConvArgs {
+  const void* src;
+  void* dst;
+  const void* x_orig;  // the original input (skip rows are copied from it bit-exactly)
+  const float* taps;
+  const uint8_t* skip;
+  int I, J, K;
+  int channels;
+  int axis, radius;
+  int taps_batched, tap_stride;
+  int orig_dtype;
+  int last_pass;
+  int tiles_a;  // tiles along the stencil axis (axes I, J) / row groups (axis K)
+};
+
+template <int SRC_DT, int DST_DT>
+__global__ __launch_bounds__(kBlock) void conv_line_kernel(const ConvArgs a) {
+  // axes I and J.  grid: x = K tiles (64), y = tiles along the axis, z = other axis * (B*C)
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int r = a.radius, ntaps = 2 * r + 1;
+  float* s_taps = s_mem;                 // ntaps
+  float* s_tile = s_mem + ((ntaps + 3) & ~3);  // (kConvLine + 2r) x 64
+  const int n_other = a.axis == 0 ? a.J : a.I;  // size of the non-stencil, non-K axis
+  const int other = blockIdx.z % n_other;
+  const int bc = blockIdx.z / n_other;
+  const int b = bc / a.channels;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int n = a.axis == 0 ? a.I : a.J;        // length of the stencil axis
+  const int p0 = blockIdx.y * kConvLine;         // first output position along the axis
+  const int64_t n_spatial = static_cast<int64_t>(a.I) * a.J * a.K;
   const int64_t base = static_cast<int64_t>(bc) * n_spatial;
-  if (skip != nullptr && skip[b] != 0) {
-    // rows with no blur are restored bit-exactly (blur.py:249-251): carry the
-    // original element through every pass and emit it unchanged at the end
-    if (last_pass) {
-      const int es = dtype_size(orig_dtype);
-      const char* s = static_cast<const char*>(x_orig) + (base + idx) * es;
-      char* d = static_cast<char*>(dst) + (base + idx) * es;
-      for (int e = 0; e < es; e++) d[e] = s[e];
+  const int64_t stride = a.axis == 0 ? static_cast<int64_t>(a.J) * a.K : a.K;
+  const int64_t other_stride = a.axis == 0 ? a.K : static_cast<int64_t>(a.J) * a.K;
+  const int64_t line = base + other * other_stride + k;  // element (axis pos 0, other, k)
+  const bool active = k < a.K;
+
+  if (a.skip != nullptr && a.skip[b] != 0) {
+    // rows with no blur are restored bit-exactly (blur.py:249-251): emitted unchanged by the last pass
+    if (a.last_pass && active) {
+      const int es = dtype_size(a.orig_dtype);
+      for (int q = wave; q < kConvLine && p0 + q < n; q += kBlock / 64) {
+        const int64_t e = line + static_cast<int64_t>(p0 + q) * stride;
+        const char* s = static_cast<const char*>(a.x_orig) + e * es;
+        char* d = static_cast<char*>(a.dst) + e * es;
+        for (int c = 0; c < es; c++) d[c] = s[c];
+      }
     }
     return;
   }
-  const int k = static_cast<int>(idx % K);
-  const int j = static_cast<int>((idx / K) % J);
-  const int i = static_cast<int>(idx / (static_cast<int64_t>(K) * J));
-  const int p = axis == 0 ? i : (axis == 1 ? j : k);
-  const int n = axis == 0 ? I : (axis == 1 ? J : K);
-  const int64_t stride = axis == 0 ? static_cast<int64_t>(J) * K : (axis == 1 ? K : 1);
-  const int64_t line = base + idx - static_cast<int64_t>(p) * stride;
-  float acc = 0.0f;
-  for (int tt = 0; tt < ntaps; tt++) {
-    int q = p + tt - radius;  // replicate padding == clamp
-    q = min(max(q, 0), n - 1);
-    const float v = Elem<SRC_DT>::load(src, line + static_cast<int64_t>(q) * stride);
-    acc = __fadd_rn(acc, __fmul_rn(s_taps[tt], v));
+  const float* t = a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) +
+                   static_cast<int64_t>(a.axis) * a.tap_stride;
+  for (int i = threadIdx.x; i < ntaps; i += kBlock) s_taps[i] = t[i];
+  const int rows = min(kConvLine, n - p0) + 2 * r;
+  if (active) {
+    for (int q = wave; q < rows; q += kBlock / 64) {
+      const int pos = min(max(p0 + q - r, 0), n - 1);  // replicate padding == clamp
+      s_tile[q * 64 + lane] = Elem<SRC_DT>::load(a.src, line + static_cast<int64_t>(pos) * stride);
+    }
   }
-  Elem<DST_DT>::store(dst, base + idx, acc);
-  (void)first_pass;
+  __syncthreads();
+  if (!active) return;
+  for (int q = wave; q < kConvLine && p0 + q < n; q += kBlock / 64) {
+    float acc = 0.0f;
+    const float* col = s_tile + q * 64 + lane;
+    for (int tt = 0; tt < ntaps; tt++) acc = __fadd_rn(acc, __fmul_rn(s_taps[tt], col[tt * 64]));
+    Elem<DST_DT>::store(a.dst, line + static_cast<int64_t>(p0 + q) * stride, acc);
+  }
+}
+
+template <int SRC_DT, int DST_DT>
+__global__ __launch_bounds__(kBlock) void conv_k_kernel(const ConvArgs a) {
+  // axis K.  grid: x = K tiles (256), y = J tiles (4 rows, one per wave), z = I * (B*C)
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int r = a.radius, ntaps = 2 * r + 1;
+  float* s_taps = s_mem;
+  const int pitch = kConvKSpan + 2 * r;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* s_row = s_mem + ((ntaps + 3) & ~3) + wave * pitch;
+  const int i = blockIdx.z % a.I;
+  const int bc = blockIdx.z / a.I;
+  const int b = bc / a.channels;
+  const int j = blockIdx.y * (kBlock / 64) + wave;
+  const int k0 = blockIdx.x * kConvKSpan;
+  const int64_t n_spatial = static_cast<int64_t>(a.I) * a.J * a.K;
+  const int64_t row = static_cast<int64_t>(bc) * n_spatial + (static_cast<int64_t>(i) * a.J + j) * a.K;
+  const bool active = j < a.J;
+
+  if (a.skip != nullptr && a.skip[b] != 0) {
+    if (a.last_pass && active) {
+      const int es = dtype_size(a.orig_dtype);
+      for (int q = lane; q < kConvKSpan && k0 + q < a.K; q += 64) {
+        const int64_t e = row + k0 + q;
+        const char* s = static_cast<const char*>(a.x_orig) + e * es;
+        char* d = static_cast<char*>(a.dst) + e * es;
+        for (int c = 0; c < es; c++) d[c] = s[c];
+      }
+    }
+    return;
+  }
+  const float* t = a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride;
+  for (int q = threadIdx.x; q < ntaps; q += kBlock) s_taps[q] = t[q];
+  const int span = min(kConvKSpan, a.K - k0);
+  if (active) {
+    for (int q = lane; q < span + 2 * r; q += 64) {
+      const int pos = min(max(k0 + q - r, 0), a.K - 1);
+      s_row[q] = Elem<SRC_DT>::load(a.src, row + pos);
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  for (int q = lane; q < span; q += 64) {
+    float acc = 0.0f;
+    for (int tt = 0; tt < ntaps; tt++) acc = __fadd_rn(acc, __fmul_rn(s_taps[tt], s_row[q + tt]));
+    Elem<DST_DT>::store(a.dst, row + k0 + q, acc);
+  }
 }
 
 template <int DT>
 static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t batch, int32_t channels,
                        const int32_t shape[3], const float* taps, int taps_batched, int tap_stride,
                        const int32_t radius[3], const uint8_t* skip, hipStream_t stream) {
-  const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
   int active[3], n_active = 0;
-  for (int a = 0; a < 3; a++)
-    if (radius[a] > 0) active[n_active++] = a;
-  const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock), static_cast<unsigned>(batch * channels));
+  for (int ax = 0; ax < 3; ax++)
+    if (radius[ax] > 0) active[n_active++] = ax;
   const void* src = x;
   for (int s = 0; s < n_active; s++) {
     const int axis = active[s];
     const bool first = s == 0, last = s == n_active - 1;
     void* dst = last ? y : static_cast<void*>((s % 2 == 0) ? tmp0 : tmp1);
-    const size_t lds = static_cast<size_t>(2 * radius[axis] + 1) * sizeof(float);
-#define TIO_CONV_LAUNCH(S, D)                                                                              \
-  hipLaunchKernelGGL((conv_axis_kernel<S, D>), grid, dim3(kBlock), lds, stream, src, dst, n, shape[0],     \
-                     shape[1], shape[2], channels, axis, radius[axis], taps, taps_batched, tap_stride,     \
-                     skip, first ? 1 : 0, x, DT, last ? 1 : 0)
+    ConvArgs a{};
+    a.src = src; a.dst = dst; a.x_orig = x; a.taps = taps; a.skip = skip;
+    a.I = shape[0]; a.J = shape[1]; a.K = shape[2];
+    a.channels = channels; a.axis = axis; a.radius = radius[axis];
+    a.taps_batched = taps_batched; a.tap_stride = tap_stride; a.orig_dtype = DT; a.last_pass = last ? 1 : 0;
+    const int ntaps = 2 * radius[axis] + 1;
+    const int bcs = batch * channels;
+    dim3 grid;
+    size_t lds;
+    if (axis == 2) {
+      grid = dim3((shape[2] + kConvKSpan - 1) / kConvKSpan, (shape[1] + 3) / 4, static_cast<unsigned>(shape[0]) * bcs);
+      lds = (((ntaps + 3) & ~3) + 4 * (kConvKSpan + 2 * radius[axis])) * sizeof(float);
+    } else {
+      const int n = shape[axis], other = axis == 0 ? shape[1] : shape[0];
+      grid = dim3((shape[2] + 63) / 64, (n + kConvLine - 1) / kConvLine, static_cast<unsigned>(other) * bcs);
+      lds = (((ntaps + 3) & ~3) + (kConvLine + 2 * radius[axis]) * 64) * sizeof(float);
+    }
+    if (grid.z > 65535u || grid.y > 65535u) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: volume too large for one launch");
+#define TIO_CONV_LAUNCH(S, D)                                                                      \
+  do {                                                                                             \
+    if (axis == 2) hipLaunchKernelGGL((conv_k_kernel<S, D>), grid, dim3(kBlock), lds, stream, a);  \
+    else hipLaunchKernelGGL((conv_line_kernel<S, D>), grid, dim3(kBlock), lds, stream, a);         \
+  } while (0)
     if (first && last) TIO_CONV_LAUNCH(DT, DT);
     else if (first) TIO_CONV_LAUNCH(DT, TIO_F32);
     else if (last) TIO_CONV_LAUNCH(TIO_F32, DT);
@@ -100,56 +195,83 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
 // =============================================================================
 constexpr int kMaxCoarseLds = 8192;  // floats (32 KiB)
 
+// grid: x = K tiles (64 lanes), y = J tiles (4 rows, one per wave), z = I tiles * (B*C);
+// each thread walks kBiasTileI slabs so the j/k lerp terms are computed once.
+constexpr int kBiasTileI = 8;
+
 template <int DT>
 __global__ __launch_bounds__(kBlock) void bias_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                       int channels, int I, int J, int K,
                                                       const float* __restrict__ coarse, int ci, int cj, int ck,
                                                       float scale_i, float scale_j, float scale_k, int divide,
-                                                      const uint8_t* __restrict__ skip) {
+                                                      const uint8_t* __restrict__ skip, int tiles_i) {
   extern __shared__ __attribute__((aligned(16))) float s_coarse[];
-  const int bc = blockIdx.y;
+  const int it = blockIdx.z % tiles_i;
+  const int bc = blockIdx.z / tiles_i;
   const int b = bc / channels;
   const int64_t n = static_cast<int64_t>(I) * J * K;
   const int64_t base = static_cast<int64_t>(bc) * n;
   const bool skipped = skip != nullptr && skip[b] != 0;
   const int nc = ci * cj * ck;
-  const float* f = coarse + static_cast<int64_t>(bc) * nc;
-  if (!skipped && nc <= kMaxCoarseLds) {
-    for (int t = threadIdx.x; t < nc; t += blockDim.x) s_coarse[t] = f[t];
+  const float* fg = coarse + static_cast<int64_t>(bc) * nc;
+  const bool in_lds = !skipped && nc <= kMaxCoarseLds;
+  if (in_lds) {
+    for (int t = threadIdx.x; t < nc; t += blockDim.x) s_coarse[t] = fg[t];
     __syncthreads();
-    f = s_coarse;
   }
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
+  const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * (kBlock / 64) + (threadIdx.x >> 6);
+  if (k >= K || j >= J) return;
+  const int i_begin = it * kBiasTileI, i_end = min(i_begin + kBiasTileI, I);
   using T = typename Elem<DT>::type;
+  const int64_t row = base + static_cast<int64_t>(j) * K + k;
+  const int64_t slab = static_cast<int64_t>(J) * K;
   if (skipped) {  // std == 0 rows restored bit-exactly (bias_field.py:247-253)
-    static_cast<T*>(y)[base + idx] = static_cast<const T*>(x)[base + idx];
+    for (int i = i_begin; i < i_end; i++) static_cast<T*>(y)[row + i * slab] = static_cast<const T*>(x)[row + i * slab];
     return;
   }
-  const int k = static_cast<int>(idx % K);
-  const int j = static_cast<int>((idx / K) % J);
-  const int i = static_cast<int>(idx / (static_cast<int64_t>(K) * J));
-  const Lerp1D li = lerp_index(i, ci, I, scale_i);
   const Lerp1D lj = lerp_index(j, cj, J, scale_j);
   const Lerp1D lk = lerp_index(k, ck, K, scale_k);
   const int s_i = cj * ck, s_j = ck;
-  const float* p00 = f + li.i0 * s_i + lj.i0 * s_j;
-  const float* p01 = f + li.i0 * s_i + lj.i1 * s_j;
-  const float* p10 = f + li.i1 * s_i + lj.i0 * s_j;
-  const float* p11 = f + li.i1 * s_i + lj.i1 * s_j;
-  const float a00 = lerp2(p00[lk.i0], lk.l0, p00[lk.i1], lk.l1);
-  const float a01 = lerp2(p01[lk.i0], lk.l0, p01[lk.i1], lk.l1);
-  const float a10 = lerp2(p10[lk.i0], lk.l0, p10[lk.i1], lk.l1);
-  const float a11 = lerp2(p11[lk.i0], lk.l0, p11[lk.i1], lk.l1);
-  const float b0 = lerp2(a00, lj.l0, a01, lj.l1);
-  const float b1 = lerp2(a10, lj.l0, a11, lj.l1);
-  const float field = expf(lerp2(b0, li.l0, b1, li.l1));  // bias_field.py:341
-  if constexpr (DT == TIO_F64) {  // f64 data (x) f32 field promotes to f64
-    const double v = static_cast<const double*>(x)[base + idx];
-    static_cast<double*>(y)[base + idx] = divide ? v / static_cast<double>(field) : v * static_cast<double>(field);
-  } else {
-    const float v = Elem<DT>::load(x, base + idx);
-    Elem<DT>::store(y, base + idx, divide ? __fdiv_rn(v, field) : __fmul_rn(v, field));
+  // all loads of the i-tile are issued before the first use: 8 independent HBM requests in flight per lane
+  float v[kBiasTileI];
+  double vd[DT == TIO_F64 ? kBiasTileI : 1];
+#pragma unroll
+  for (int u = 0; u < kBiasTileI; u++) {
+    const int i = i_begin + u;
+    if (i < i_end) {
+      if constexpr (DT == TIO_F64) vd[u] = static_cast<const double*>(x)[row + i * slab];
+      else v[u] = Elem<DT>::load(x, row + i * slab);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kBiasTileI; u++) {
+    const int i = i_begin + u;
+    if (i >= i_end) break;
+    const Lerp1D li = lerp_index(i, ci, I, scale_i);
+    const int o00 = li.i0 * s_i + lj.i0 * s_j, o01 = li.i0 * s_i + lj.i1 * s_j;
+    const int o10 = li.i1 * s_i + lj.i0 * s_j, o11 = li.i1 * s_i + lj.i1 * s_j;
+    float c[8];
+    if (in_lds) {
+      c[0] = s_coarse[o00 + lk.i0]; c[1] = s_coarse[o00 + lk.i1]; c[2] = s_coarse[o01 + lk.i0]; c[3] = s_coarse[o01 + lk.i1];
+      c[4] = s_coarse[o10 + lk.i0]; c[5] = s_coarse[o10 + lk.i1]; c[6] = s_coarse[o11 + lk.i0]; c[7] = s_coarse[o11 + lk.i1];
+    } else {
+      c[0] = fg[o00 + lk.i0]; c[1] = fg[o00 + lk.i1]; c[2] = fg[o01 + lk.i0]; c[3] = fg[o01 + lk.i1];
+      c[4] = fg[o10 + lk.i0]; c[5] = fg[o10 + lk.i1]; c[6] = fg[o11 + lk.i0]; c[7] = fg[o11 + lk.i1];
+    }
+    const float a00 = lerp2(c[0], lk.l0, c[1], lk.l1);
+    const float a01 = lerp2(c[2], lk.l0, c[3], lk.l1);
+    const float a10 = lerp2(c[4], lk.l0, c[5], lk.l1);
+    const float a11 = lerp2(c[6], lk.l0, c[7], lk.l1);
+    const float b0 = lerp2(a00, lj.l0, a01, lj.l1);
+    const float b1 = lerp2(a10, lj.l0, a11, lj.l1);
+    const float field = expf(lerp2(b0, li.l0, b1, li.l1));  // bias_field.py:341
+    const int64_t idx = row + i * slab;
+    if constexpr (DT == TIO_F64) {  // f64 data (x) f32 field promotes to f64
+      static_cast<double*>(y)[idx] = divide ? vd[u] / static_cast<double>(field) : vd[u] * static_cast<double>(field);
+    } else {
+      Elem<DT>::store(y, idx, divide ? __fdiv_rn(v[u], field) : __fmul_rn(v[u], field));
+    }
   }
 }
 
@@ -392,6 +514,7 @@ extern "C" int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t d
     if (radius[a] < 0 || 2 * radius[a] + 1 > tap_stride)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: radius[%d]=%d does not fit tap_stride=%d", a,
                   radius[a], tap_stride);
+    if (radius[a] > kMaxRadius) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: radius[%d]=%d exceeds %d", a, radius[a], kMaxRadius);
     if (radius[a] > 0) n_active++;
   }
   if (n_active > 0 && taps_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: null taps");
@@ -426,15 +549,17 @@ extern "C" int tio_bias_field_apply(const void* x, void* y, int32_t dtype, int32
     if (shape[d] < 1 || coarse_shape[d] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bias_field_apply: bad shape");
   if (batch < 0 || channels < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bias_field_apply: bad batch/channels");
   if (batch == 0) return TIO_OK;
-  const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
   const int nc = coarse_shape[0] * coarse_shape[1] * coarse_shape[2];
   const size_t lds = nc <= kMaxCoarseLds ? static_cast<size_t>(nc) * sizeof(float) : 0;
-  const dim3 grid(static_cast<unsigned>((n + kBlock - 1) / kBlock), static_cast<unsigned>(batch * channels));
+  const int tiles_i = (shape[0] + kBiasTileI - 1) / kBiasTileI;
+  const dim3 grid(static_cast<unsigned>((shape[2] + 63) / 64), static_cast<unsigned>((shape[1] + 3) / 4),
+                  static_cast<unsigned>(tiles_i) * batch * channels);
+  if (grid.z > 65535u || grid.y > 65535u) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bias_field_apply: volume too large for one launch");
 #define TIO_BIAS(DT)                                                                                              \
   hipLaunchKernelGGL((bias_kernel<DT>), grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, y, channels, \
                      shape[0], shape[1], shape[2], coarse_dev, coarse_shape[0], coarse_shape[1], coarse_shape[2], \
                      lerp_scale(coarse_shape[0], shape[0]), lerp_scale(coarse_shape[1], shape[1]),                \
-                     lerp_scale(coarse_shape[2], shape[2]), divide, skip_dev)
+                     lerp_scale(coarse_shape[2], shape[2]), divide, skip_dev, tiles_i)
   TIO_DISPATCH_FLOAT(dtype, TIO_BIAS)
 #undef TIO_BIAS
   return check_launch("tio_bias_field_apply");
