@@ -1,0 +1,392 @@
+// resample_bench.cpp — stand-alone driver of tio_resample3d through the C ABI (no Python,
+// no torch): times the resampling paths with HIP events, compares them bit for bit with
+// each other and with the CPU oracle.  Build: scripts/build_resample_bench.sh.
+//
+//   resample_bench [--size 256] [--batch 8] [--reps 20] [--cases perf|parity|all]
+//
+// perf   : 256^3-class float32 volumes, per-element affine (±10°, 0.9-1.1, ±5 vox) and
+//          7^3 elastic control points (±7.5 mm), the bench.py workload geometry;
+//          every path (gather, tile variants) timed and checked against gather.
+// parity : awkward shapes / dtypes / fills / flags, every path vs the CPU oracle.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/tio_hip.h"
+
+extern "C" int tio_oracle_resample3d(const tio_resample_geom*, int32_t, const tio_resample_image*, void*);
+
+#define HIP_CHECK(x)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+static std::mt19937_64 rng(12345);
+static std::string g_case_filter, g_path_filter;
+static double uni(double lo, double hi) { return std::uniform_real_distribution<double>(lo, hi)(rng); }
+
+struct Mat3 { double m[3][3]; };
+static Mat3 mul(const Mat3& a, const Mat3& b) {
+  Mat3 r{};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) r.m[i][j] += a.m[i][k] * b.m[k][j];
+  return r;
+}
+static Mat3 inv3(const Mat3& a) {
+  const double (*m)[3] = a.m;
+  const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                     m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+  Mat3 r;
+  r.m[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; r.m[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
+  r.m[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det; r.m[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det;
+  r.m[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; r.m[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+  r.m[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; r.m[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
+  r.m[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+  return r;
+}
+
+// output-voxel → input-voxel 3x4 of a random forward affine about the volume centre
+static void random_mapping(float* out12, const int shape[3], double max_deg, double max_scale_dev, double max_shift) {
+  const double d2r = M_PI / 180.0;
+  const double ax = uni(-max_deg, max_deg) * d2r, ay = uni(-max_deg, max_deg) * d2r, az = uni(-max_deg, max_deg) * d2r;
+  Mat3 Rx{{{1, 0, 0}, {0, cos(ax), -sin(ax)}, {0, sin(ax), cos(ax)}}};
+  Mat3 Ry{{{cos(ay), 0, sin(ay)}, {0, 1, 0}, {-sin(ay), 0, cos(ay)}}};
+  Mat3 Rz{{{cos(az), -sin(az), 0}, {sin(az), cos(az), 0}, {0, 0, 1}}};
+  Mat3 S{{{uni(1 - max_scale_dev, 1 + max_scale_dev), 0, 0}, {0, uni(1 - max_scale_dev, 1 + max_scale_dev), 0},
+          {0, 0, uni(1 - max_scale_dev, 1 + max_scale_dev)}}};
+  const Mat3 A = mul(mul(mul(Rz, Ry), Rx), S);
+  double c[3] = {(shape[0] - 1) / 2.0, (shape[1] - 1) / 2.0, (shape[2] - 1) / 2.0};
+  double t[3];
+  for (int i = 0; i < 3; i++) t[i] = c[i] - (A.m[i][0] * c[0] + A.m[i][1] * c[1] + A.m[i][2] * c[2]) + uni(-max_shift, max_shift);
+  const Mat3 Ai = inv3(A);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) out12[i * 4 + j] = static_cast<float>(Ai.m[i][j]);
+    out12[i * 4 + 3] = static_cast<float>(-(Ai.m[i][0] * t[0] + Ai.m[i][1] * t[1] + Ai.m[i][2] * t[2]));
+  }
+}
+
+static void identity_mapping(float* out12) {
+  for (int i = 0; i < 12; i++) out12[i] = 0.0f;
+  out12[0] = out12[5] = out12[10] = 1.0f;
+}
+
+static void random_cp(float* cp, const int n[3], double amp, int locked) {
+  for (int i = 0; i < n[0]; i++)
+    for (int j = 0; j < n[1]; j++)
+      for (int k = 0; k < n[2]; k++) {
+        const bool border = i < locked || j < locked || k < locked || i >= n[0] - locked || j >= n[1] - locked || k >= n[2] - locked;
+        for (int c = 0; c < 3; c++) cp[((i * n[1] + j) * n[2] + k) * 3 + c] = border ? 0.0f : static_cast<float>(uni(-amp, amp));
+      }
+}
+
+static size_t dtype_bytes(int dt) {
+  switch (dt) {
+    case TIO_F32: case TIO_I32: return 4;
+    case TIO_F64: case TIO_I64: return 8;
+    case TIO_F16: case TIO_BF16: case TIO_I16: return 2;
+    default: return 1;
+  }
+}
+
+struct Image {
+  int channels, dtype, interp;
+  bool with_fill;
+  std::vector<uint8_t> host_in;
+  std::vector<float> fill;
+  void* d_in = nullptr;
+  void* d_out = nullptr;
+  float* d_fill = nullptr;
+};
+
+struct Case {
+  std::string name;
+  int batch;
+  int in_shape[3], out_shape[3];
+  bool affine, elastic, affine_first, batched;
+  int cp_shape[3] = {7, 7, 7};
+  float in_spacing[3] = {1, 1, 1}, out_spacing[3] = {1, 1, 1};
+  double max_deg = 10, scale_dev = 0.1, shift = 5, amp = 7.5;
+  std::vector<Image> images;
+  std::vector<uint8_t> cp_skip, passthrough;
+};
+
+static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
+  buf.resize(n * dtype_bytes(dtype));
+  std::mt19937 g(static_cast<unsigned>(n * 31 + dtype));
+  for (size_t i = 0; i < n; i++) {
+    const float f = static_cast<float>(g() & 0xFFFFFF) / 16777216.0f;
+    switch (dtype) {
+      case TIO_F32: reinterpret_cast<float*>(buf.data())[i] = f * 4.0f - 1.0f; break;
+      case TIO_F64: reinterpret_cast<double*>(buf.data())[i] = f * 4.0 - 1.0; break;
+      case TIO_I16: reinterpret_cast<int16_t*>(buf.data())[i] = static_cast<int16_t>(g() % 7); break;
+      case TIO_I32: reinterpret_cast<int32_t*>(buf.data())[i] = static_cast<int32_t>(g() % 7); break;
+      case TIO_I64: reinterpret_cast<int64_t*>(buf.data())[i] = static_cast<int64_t>(g() % 7); break;
+      case TIO_U8: buf[i] = static_cast<uint8_t>(g() % 7); break;
+      case TIO_I8: reinterpret_cast<int8_t*>(buf.data())[i] = static_cast<int8_t>(g() % 7) - 3; break;
+      default: reinterpret_cast<uint16_t*>(buf.data())[i] = static_cast<uint16_t>(0x3C00 + (g() % 512)); break;  // f16/bf16 bits
+    }
+  }
+}
+
+struct Paths { const char* name; const char* path; const char* variant; };
+static const Paths kPaths[] = {
+    {"gather", "gather", "0"}, {"tile16x16x16", "tile", "0"}, {"tile16x8x32", "tile", "1"}, {"tile8x8x32", "tile", "2"}};
+
+static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
+  if (!g_case_filter.empty() && cs.name.find(g_case_filter) == std::string::npos) return 0;
+  const int B = cs.batch;
+  const size_t n_in = static_cast<size_t>(cs.in_shape[0]) * cs.in_shape[1] * cs.in_shape[2];
+  const size_t n_out = static_cast<size_t>(cs.out_shape[0]) * cs.out_shape[1] * cs.out_shape[2];
+  const int nm = cs.batched ? B : 1;
+  std::vector<float> mapping(12 * nm);
+  for (int b = 0; b < nm; b++) {
+    if (cs.affine) random_mapping(&mapping[12 * b], cs.in_shape, cs.max_deg, cs.scale_dev, cs.shift);
+    else identity_mapping(&mapping[12 * b]);
+    if (cs.out_shape[0] != cs.in_shape[0])  // resampling case: scale the mapping to the output grid
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) mapping[12 * b + r * 4 + c] *= static_cast<float>(cs.in_shape[c]) / cs.out_shape[c];
+  }
+  const int n_cp = cs.cp_shape[0] * cs.cp_shape[1] * cs.cp_shape[2] * 3;
+  std::vector<float> cp(static_cast<size_t>(n_cp) * nm);
+  for (int b = 0; b < nm; b++) random_cp(&cp[static_cast<size_t>(n_cp) * b], cs.cp_shape, cs.amp, 2);
+
+  float *d_map = nullptr, *d_cp = nullptr;
+  uint8_t *d_skip = nullptr, *d_pass = nullptr;
+  HIP_CHECK(hipMalloc(&d_map, mapping.size() * 4));
+  HIP_CHECK(hipMemcpy(d_map, mapping.data(), mapping.size() * 4, hipMemcpyHostToDevice));
+  if (cs.elastic) {
+    HIP_CHECK(hipMalloc(&d_cp, cp.size() * 4));
+    HIP_CHECK(hipMemcpy(d_cp, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (!cs.cp_skip.empty()) {
+    HIP_CHECK(hipMalloc(&d_skip, B));
+    HIP_CHECK(hipMemcpy(d_skip, cs.cp_skip.data(), B, hipMemcpyHostToDevice));
+  }
+  if (!cs.passthrough.empty()) {
+    HIP_CHECK(hipMalloc(&d_pass, B));
+    HIP_CHECK(hipMemcpy(d_pass, cs.passthrough.data(), B, hipMemcpyHostToDevice));
+  }
+
+  tio_resample_geom geom{};
+  geom.batch = B;
+  for (int d = 0; d < 3; d++) {
+    geom.in_shape[d] = cs.in_shape[d]; geom.out_shape[d] = cs.out_shape[d]; geom.cp_shape[d] = cs.cp_shape[d];
+    geom.in_spacing[d] = cs.in_spacing[d]; geom.out_spacing[d] = cs.out_spacing[d];
+  }
+  geom.affine_first = cs.affine_first;
+  geom.mapping_dev = d_map; geom.mapping_batched = cs.batched && B > 1;
+  geom.control_points_dev = d_cp; geom.cp_batched = cs.batched && B > 1;
+  geom.cp_skip_dev = d_skip; geom.passthrough_dev = d_pass;
+
+  std::vector<tio_resample_image> descs(cs.images.size());
+  size_t algorithmic = 0;
+  for (size_t i = 0; i < cs.images.size(); i++) {
+    Image& im = cs.images[i];
+    const size_t es = dtype_bytes(im.dtype);
+    fill_random(im.host_in, im.dtype, static_cast<size_t>(B) * im.channels * n_in);
+    HIP_CHECK(hipMalloc(&im.d_in, im.host_in.size()));
+    HIP_CHECK(hipMemcpy(im.d_in, im.host_in.data(), im.host_in.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&im.d_out, static_cast<size_t>(B) * im.channels * n_out * es));
+    if (im.with_fill) {
+      im.fill.resize(im.channels);
+      for (int c = 0; c < im.channels; c++) im.fill[c] = -1.0f + 0.75f * c;
+      HIP_CHECK(hipMalloc(&im.d_fill, im.channels * 4));
+      HIP_CHECK(hipMemcpy(im.d_fill, im.fill.data(), im.channels * 4, hipMemcpyHostToDevice));
+    }
+    descs[i] = tio_resample_image{im.d_in, im.d_out, im.channels, im.dtype, im.interp, im.d_fill};
+    algorithmic += static_cast<size_t>(B) * im.channels * (n_in + n_out) * es;
+  }
+
+  // oracle (host pointers)
+  std::vector<std::vector<uint8_t>> expect(cs.images.size());
+  if (check_oracle) {
+    tio_resample_geom hg = geom;
+    hg.mapping_dev = mapping.data();
+    hg.control_points_dev = cs.elastic ? cp.data() : nullptr;
+    hg.cp_skip_dev = cs.cp_skip.empty() ? nullptr : cs.cp_skip.data();
+    hg.passthrough_dev = cs.passthrough.empty() ? nullptr : cs.passthrough.data();
+    std::vector<tio_resample_image> hd(cs.images.size());
+    for (size_t i = 0; i < cs.images.size(); i++) {
+      Image& im = cs.images[i];
+      expect[i].resize(static_cast<size_t>(B) * im.channels * n_out * dtype_bytes(im.dtype));
+      hd[i] = tio_resample_image{im.host_in.data(), expect[i].data(), im.channels, im.dtype, im.interp,
+                                 im.with_fill ? im.fill.data() : nullptr};
+    }
+    const int st = tio_oracle_resample3d(&hg, static_cast<int>(hd.size()), hd.data(), nullptr);
+    if (st != 0) { fprintf(stderr, "oracle failed %d\n", st); return 1; }
+  }
+
+  int failures = 0;
+  std::vector<std::vector<uint8_t>> first(cs.images.size());
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  for (size_t p = 0; p < sizeof(kPaths) / sizeof(kPaths[0]); p++) {
+    if (p != 0 && !g_path_filter.empty() && std::string(kPaths[p].name).find(g_path_filter) == std::string::npos) continue;
+    setenv("TIO_RESAMPLE_PATH", kPaths[p].path, 1);
+    setenv("TIO_TILE_VARIANT", kPaths[p].variant, 1);
+    for (Image& im : cs.images) HIP_CHECK(hipMemset(im.d_out, 0xCD, static_cast<size_t>(B) * im.channels * n_out * dtype_bytes(im.dtype)));
+    int st = tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
+    if (st != 0) { fprintf(stderr, "%s/%s: tio_resample3d failed %d: %s\n", cs.name.c_str(), kPaths[p].name, st, tio_last_error()); return 1; }
+    HIP_CHECK(hipDeviceSynchronize());
+    float ms = 0.0f;
+    if (time_it) {
+      for (int w = 0; w < 2; w++) tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
+      HIP_CHECK(hipEventRecord(e0, nullptr));
+      for (int r = 0; r < reps; r++) tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
+      HIP_CHECK(hipEventRecord(e1, nullptr));
+      HIP_CHECK(hipEventSynchronize(e1));
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+    }
+    size_t diff_first = 0, diff_oracle = 0;
+    for (size_t i = 0; i < cs.images.size(); i++) {
+      Image& im = cs.images[i];
+      const size_t es = dtype_bytes(im.dtype);
+      std::vector<uint8_t> got(static_cast<size_t>(B) * im.channels * n_out * es);
+      HIP_CHECK(hipMemcpy(got.data(), im.d_out, got.size(), hipMemcpyDeviceToHost));
+      if (p == 0) first[i] = got;
+      for (size_t e = 0; e < got.size() / es; e++) {
+        if (memcmp(&got[e * es], &first[i][e * es], es) != 0) diff_first++;
+        if (check_oracle && memcmp(&got[e * es], &expect[i][e * es], es) != 0) diff_oracle++;
+      }
+    }
+    printf("%-34s %-13s", cs.name.c_str(), kPaths[p].name);
+    if (time_it) printf(" %8.3f ms  %8.1f GB/s algorithmic (%5.1f%% of 8 TB/s)", ms, algorithmic / (ms * 1e6), algorithmic / (ms * 1e6) / 80.0);
+    printf("  mismatch vs gather: %zu", diff_first);
+    if (check_oracle) printf("  vs oracle: %zu", diff_oracle);
+    printf("\n");
+    fflush(stdout);
+    if (diff_first != 0 || diff_oracle != 0) failures++;
+  }
+  for (Image& im : cs.images) { hipFree(im.d_in); hipFree(im.d_out); hipFree(im.d_fill); }
+  hipFree(d_map); hipFree(d_cp); hipFree(d_skip); hipFree(d_pass);
+  return failures;
+}
+
+static Case make_case(const char* name, int batch, int si, int sj, int sk, bool affine, bool elastic) {
+  Case c;
+  c.name = name; c.batch = batch;
+  c.in_shape[0] = c.out_shape[0] = si; c.in_shape[1] = c.out_shape[1] = sj; c.in_shape[2] = c.out_shape[2] = sk;
+  c.affine = affine; c.elastic = elastic; c.affine_first = true; c.batched = true;
+  return c;
+}
+
+int main(int argc, char** argv) {
+  int size = 256, batch = 8, reps = 20;
+  std::string cases = "all";
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "--size") && i + 1 < argc) size = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--cases") && i + 1 < argc) cases = argv[++i];
+    else if (!strcmp(argv[i], "--case") && i + 1 < argc) g_case_filter = argv[++i];
+    else if (!strcmp(argv[i], "--path") && i + 1 < argc) g_path_filter = argv[++i];
+    else if (!strcmp(argv[i], "--ablate") && i + 1 < argc) setenv("TIO_TILE_ABLATE", argv[++i], 1);
+    else if (!strcmp(argv[i], "--lds") && i + 1 < argc) setenv("TIO_TILE_LDS_FLOATS", argv[++i], 1);
+  }
+  if (tio_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
+  int failures = 0;
+  if (cases == "parity" || cases == "all") {
+    {  // odd shapes (K % 4 != 0 → scalar staging), fill, shared geometry
+      Case c = make_case("odd-shape f32 linear+fill", 2, 50, 37, 75, true, true);
+      c.batched = false; c.max_deg = 25; c.shift = 9;
+      c.images.push_back(Image{2, TIO_F32, TIO_LINEAR, true});
+      failures += run_case(c, 1, true, false);
+    }
+    {  // K % 4 == 0, strong rotation + zoom out: many boundary / outside bricks
+      Case c = make_case("far-out f32 linear+fill", 2, 64, 48, 96, true, true);
+      c.max_deg = 40; c.shift = 30; c.scale_dev = 0.4;
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      failures += run_case(c, 1, true, false);
+    }
+    {
+      Case c = make_case("far-out f32 linear nofill", 2, 64, 48, 96, true, false);
+      c.max_deg = 40; c.shift = 30; c.scale_dev = 0.4;
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, false});
+      failures += run_case(c, 1, true, false);
+    }
+    {  // multi-modal subject: 2 x f32 linear + int16 labels nearest, per-instance, flags
+      Case c = make_case("subject t1,t2 f32 + seg i16", 4, 48, 56, 64, true, true);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      c.images.push_back(Image{2, TIO_F32, TIO_LINEAR, false});
+      c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+      c.cp_skip = {0, 1, 0, 0}; c.passthrough = {0, 0, 1, 0};
+      failures += run_case(c, 1, true, false);
+    }
+    {  // downsampling by 2 (oversize bricks → per-voxel fallback) with anisotropic spacing
+      Case c = make_case("downsample x2 aniso", 1, 96, 96, 96, true, true);
+      c.out_shape[0] = c.out_shape[1] = c.out_shape[2] = 48;
+      c.out_spacing[0] = 2.0f; c.out_spacing[1] = 2.5f; c.out_spacing[2] = 1.5f; c.in_spacing[1] = 1.25f;
+      c.affine_first = false; c.max_deg = 5;
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      failures += run_case(c, 1, true, false);
+    }
+    {  // upsampling x2: tiny input boxes
+      Case c = make_case("upsample x2", 1, 40, 40, 40, true, false);
+      c.out_shape[0] = c.out_shape[1] = c.out_shape[2] = 80;
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, false});
+      failures += run_case(c, 1, true, false);
+    }
+    {  // all dtypes, linear, generic staging
+      const int dts[] = {TIO_F64, TIO_F16, TIO_BF16, TIO_U8, TIO_I8, TIO_I16, TIO_I32, TIO_I64};
+      for (int dt : dts) {
+        Case c = make_case(("dtype " + std::to_string(dt) + " linear").c_str(), 1, 33, 34, 36, true, true);
+        c.images.push_back(Image{1, dt, TIO_LINEAR, true});
+        failures += run_case(c, 1, true, false);
+      }
+    }
+    {  // 2-D input (K == 1)
+      Case c = make_case("2-D K=1", 1, 70, 90, 1, true, false);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      failures += run_case(c, 1, true, false);
+    }
+    {  // dense control grid (more than 3 control planes under a brick)
+      Case c = make_case("dense cp 40^3", 1, 64, 64, 64, false, true);
+      c.cp_shape[0] = c.cp_shape[1] = c.cp_shape[2] = 40; c.amp = 1.0;
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, false});
+      failures += run_case(c, 1, true, false);
+    }
+  }
+  if (cases == "perf" || cases == "all") {
+    {
+      Case c = make_case("affine f32 fill", batch, size, size, size, true, false);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      failures += run_case(c, reps, false, true);
+    }
+    {
+      Case c = make_case("elastic f32 fill", batch, size, size, size, false, true);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      failures += run_case(c, reps, false, true);
+    }
+    {
+      Case c = make_case("affine+elastic f32 nofill", batch, size, size, size, true, true);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, false});
+      failures += run_case(c, reps, false, true);
+    }
+    {  // one volume against the oracle at full size
+      Case c = make_case("affine+elastic f32 fill b1", 1, size, size, size, true, true);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      failures += run_case(c, reps, true, true);
+    }
+    {
+      Case c = make_case("subject 2xf32 + i16 labels", 2, size, size, size, true, true);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+      failures += run_case(c, reps, false, true);
+    }
+  }
+  printf("failures: %d\n", failures);
+  return failures ? 1 : 0;
+}

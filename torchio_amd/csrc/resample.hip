@@ -18,6 +18,9 @@
 // "interior" path (all 8 taps of all 64 lanes in bounds: no predication, no
 // mask arithmetic — the mask is exactly > 0.5 there), (3) IEEE-exact division
 // by reciprocal + two FMA refinements instead of the 12-instruction expansion.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.hpp"
 
 namespace tio {
@@ -48,16 +51,24 @@ struct ResampleArgs {
   float scale_i, scale_j, scale_k;  // ATen lerp scales of the control grid
   float den[3], rden[3];            // max(S-1,1) per input axis and reciprocal
   float size_m1[3];                 // S-1 per input axis
+  float dh[3], rdh[3], half_h[3];   // den/2, its reciprocal, (S-1)/2: the folded normalise round trip
+  int short_div;                    // every den <= 8192: one division refinement is exact
   int any_linear, any_nearest;      // which coordinate products are needed at all
   int n_images;
   ImgArgs img[TIO_MAX_IMAGES];
   int tiles_k, tiles_j, tiles_i;
+  int cp_lds;    // floats of LDS reserved for the control points (0 = read them from global)
+  int tile_cap;  // floats of LDS available for one staged input brick (tile kernel)
+  int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
 };
 
 constexpr int kTileI = 8;          // output slabs walked by one block
 constexpr int kRowsPerBlock = 4;   // one wave per output row (jo)
 constexpr int kLanes = 64;         // contiguous ko per wave → coalesced stores
 constexpr int kMaxCpLds = 6144;    // floats of control points staged in LDS (24 KiB)
+constexpr int kLdsFloatsPerCU = 40960;   // 160 KiB
+constexpr int kTileMinCap = 6144;       // the per-voxel fallback parks 8 planes x 3 coordinates x 256 threads there
+constexpr int kTileBlocksPerCU = 3;       // resident blocks the default LDS budget is sized for
 
 // IEEE-754 correctly rounded n / d from r = RN(1/d): q0 = RN(n r), two Markstein
 // refinements (each: exact remainder by FMA, correction by FMA).  Checked
@@ -386,6 +397,8 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 
 }  // namespace tio
 
+#include "resample_tile.hpp"
+
 extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
                               const tio_resample_image* images, void* stream) {
   using namespace tio;
@@ -423,6 +436,7 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
   a.passthrough = geom->passthrough_dev;
   const float* sp = geom->affine_first ? geom->in_spacing : geom->out_spacing;
   a.unit_spacing = 1;
+  a.short_div = 1;
   for (int d = 0; d < 3; d++) {
     a.sp[d] = sp[d];
     a.rsp[d] = 1.0f / sp[d];
@@ -431,6 +445,10 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     a.den[d] = static_cast<float>(size - 1 > 1 ? size - 1 : 1);
     a.rden[d] = 1.0f / a.den[d];
     a.size_m1[d] = static_cast<float>(size - 1);
+    a.dh[d] = 0.5f * a.den[d];
+    a.rdh[d] = 1.0f / a.dh[d];
+    a.half_h[d] = 0.5f * a.size_m1[d];
+    if (a.den[d] > 8192.0f) a.short_div = 0;
   }
   if (a.cp != nullptr) {
     if (geom->control_points_dev != nullptr && !(sp[0] > 0.0f && sp[1] > 0.0f && sp[2] > 0.0f))
@@ -454,12 +472,6 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
   }
   if (a.B == 0) return TIO_OK;
 
-  a.tiles_k = (a.Ko + kLanes - 1) / kLanes;
-  a.tiles_j = (a.Jo + kRowsPerBlock - 1) / kRowsPerBlock;
-  a.tiles_i = (a.Io + kTileI - 1) / kTileI;
-  const int64_t blocks = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
-  if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
-  const dim3 grid(static_cast<unsigned>(blocks)), block(kRowsPerBlock * kLanes);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int dtmode = 0;
   for (int i = 0; i < n_images; i++) {
@@ -467,11 +479,83 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     const int need = dt == TIO_F32 ? 0 : ((dt == TIO_I16 || dt == TIO_U8 || dt == TIO_I32) ? 1 : 2);
     dtmode = need > dtmode ? need : dtmode;
   }
-  size_t lds = 0;
-  if (a.cp != nullptr) {
-    const int n_cp = a.ni * a.nj * a.nk * 3;
-    lds = n_cp <= kMaxCpLds ? static_cast<size_t>(n_cp) * sizeof(float) : 0;
+  const int n_cp = a.cp != nullptr ? a.ni * a.nj * a.nk * 3 : 0;
+
+  // Path: LDS-staged bricks whenever a trilinear image is present (the 8-tap gather is
+  // what the staging removes); pure nearest launches keep the one-load gather kernel.
+  // TIO_RESAMPLE_PATH=gather|tile overrides (A/B tests compare the two bit for bit).
+  bool use_tile = a.any_linear != 0;
+  if (const char* env = getenv("TIO_RESAMPLE_PATH")) {
+    if (strcmp(env, "gather") == 0) use_tile = false;
+    if (strcmp(env, "tile") == 0) use_tile = true;
   }
+  if (static_cast<int64_t>(a.Jo) * a.Ko * 8 >= (1LL << 31)) use_tile = false;  // 32-bit byte offsets inside one output plane
+  if (use_tile) {
+    int variant = 0, cap = 0;
+    if (const char* env = getenv("TIO_TILE_VARIANT")) variant = atoi(env);
+    if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) cap = atoi(env);
+    if (const char* env = getenv("TIO_TILE_ABLATE")) a.ablate = atoi(env);
+    a.cp_lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? ((n_cp + 3) & ~3) : 0;
+    // default brick budget: whatever lets kTileBlocksPerCU blocks share the CU's 160 KiB
+    if (cap <= 0) cap = kLdsFloatsPerCU / kTileBlocksPerCU - a.cp_lds - kTileRedInts - 64;
+    const int max_cap = kLdsFloatsPerCU - a.cp_lds - kTileRedInts;
+    a.tile_cap = cap < kTileMinCap ? kTileMinCap : (cap > max_cap ? max_cap : cap);
+    const size_t lds = static_cast<size_t>(a.cp_lds + kTileRedInts + a.tile_cap) * sizeof(float);
+#define TIO_TILE_LAUNCH(EL, DM, TI, TJ, TK, OCC)                                                              \
+  {                                                                                                      \
+    a.tiles_k = (a.Ko + TK - 1) / TK;                                                                    \
+    a.tiles_j = (a.Jo + TJ - 1) / TJ;                                                                    \
+    a.tiles_i = (a.Io + TI - 1) / TI;                                                                    \
+    const int64_t blocks = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;                \
+    if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");  \
+    auto kernel = resample_tile_kernel<EL, DM, TI, TJ, TK, OCC>;                                            \
+    if (lds > 48 * 1024) {                                                                               \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              static_cast<int>(lds)) != hipSuccess)                                      \
+        return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds);             \
+    }                                                                                                    \
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(TJ* TK), lds, s, a);            \
+  }
+#define TIO_TILE_SHAPE(TI, TJ, TK, OCC)                                                  \
+  {                                                                                 \
+    if (a.cp != nullptr) {                                                          \
+      if (dtmode == 0) TIO_TILE_LAUNCH(true, 0, TI, TJ, TK, OCC)                        \
+      else if (dtmode == 1) TIO_TILE_LAUNCH(true, 1, TI, TJ, TK, OCC)                   \
+      else TIO_TILE_LAUNCH(true, 2, TI, TJ, TK, OCC)                                    \
+    } else {                                                                        \
+      if (dtmode == 0) TIO_TILE_LAUNCH(false, 0, TI, TJ, TK, OCC)                       \
+      else if (dtmode == 1) TIO_TILE_LAUNCH(false, 1, TI, TJ, TK, OCC)                  \
+      else TIO_TILE_LAUNCH(false, 2, TI, TJ, TK, OCC)                                   \
+    }                                                                               \
+  }
+#define TIO_TILE_SHAPE_F32(TI, TJ, TK, OCC) /* experimental shapes: float32 launches only */ \
+  {                                                                                 \
+    if (dtmode != 0) {                                                              \
+      TIO_TILE_SHAPE(16, 16, 16, 3)                                                 \
+    } else if (a.cp != nullptr) {                                                   \
+      TIO_TILE_LAUNCH(true, 0, TI, TJ, TK, OCC)                                         \
+    } else {                                                                        \
+      TIO_TILE_LAUNCH(false, 0, TI, TJ, TK, OCC)                                        \
+    }                                                                               \
+  }
+    switch (variant) {
+      case 1: TIO_TILE_SHAPE_F32(16, 8, 32, 3) break;
+      case 2: TIO_TILE_SHAPE_F32(8, 8, 32, 4) break;
+      default: TIO_TILE_SHAPE(16, 16, 16, 3) break;
+    }
+#undef TIO_TILE_SHAPE_F32
+#undef TIO_TILE_SHAPE
+#undef TIO_TILE_LAUNCH
+    return check_launch("tio_resample3d");
+  }
+
+  a.tiles_k = (a.Ko + kLanes - 1) / kLanes;
+  a.tiles_j = (a.Jo + kRowsPerBlock - 1) / kRowsPerBlock;
+  a.tiles_i = (a.Io + kTileI - 1) / kTileI;
+  const int64_t blocks = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
+  if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kRowsPerBlock * kLanes);
+  const size_t lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? static_cast<size_t>(n_cp) * sizeof(float) : 0;
 #define TIO_LAUNCH(EL, DM) hipLaunchKernelGGL((resample_kernel<EL, DM>), grid, block, lds, s, a)
   if (a.cp != nullptr) {
     if (dtmode == 0) TIO_LAUNCH(true, 0); else if (dtmode == 1) TIO_LAUNCH(true, 1); else TIO_LAUNCH(true, 2);
