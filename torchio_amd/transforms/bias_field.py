@@ -85,7 +85,7 @@ def _apply_to_images(transform, batch: SubjectsBatch, std, seed, scale: float, *
             coarse = _sample_coarse_field(data.shape, std=std, scale=scale, seed=seed)
             # `data * field` promotes with the float32 field (bias_field.py:130,196)
             work = data if data.dtype in (torch.float32, torch.float64) else data.float()
-            img_batch.data = ops.engine().bias_field_apply(work, coarse.to(data.device), divide=divide)
+            img_batch.data = ops.engine().bias_field_apply(work, ops.h2d(coarse, data.device), divide=divide)
 
 
 def _coarse_shape(spatial, scale: float) -> list[int]:
@@ -110,8 +110,8 @@ def _apply_bias_per_element(data: Tensor, std_per_element, seed_per_element, sca
         generator = torch.Generator(device="cpu")
         generator.manual_seed(seed)
         fields.append(torch.normal(mean=0.0, std=std, size=(1, data.shape[1], *small), generator=generator))
-    coarse = torch.cat(fields, dim=0).to(data.device)
-    skip = torch.tensor(identity_rows, dtype=torch.uint8).to(data.device) if any(identity_rows) else None
+    coarse = ops.h2d(torch.cat(fields, dim=0), data.device)
+    skip = ops.h2d(torch.tensor(identity_rows, dtype=torch.uint8), data.device) if any(identity_rows) else None
     work = data if data.dtype in ops.FLOAT_DTYPES else data.float()
     result = ops.engine().bias_field_apply(work, coarse, divide=divide, skip=skip)
     if result.dtype != data.dtype:  # `.to(data.dtype)` + exact restore of identity rows (bias_field.py:245-253)

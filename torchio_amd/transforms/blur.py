@@ -75,12 +75,12 @@ def _gaussian_smooth(data: Tensor, sigmas) -> Tensor:
         sigmas = sigmas[0]  # identical rows collapse to the shared kernel set (blur.py:150-153)
     taps, radius, skip = _stacked_gaussian_taps(sigmas if sigmas.ndim == 2 else sigmas[None], per_element=sigmas.ndim == 2)
     work = data if data.dtype in ops.FLOAT_DTYPES else data.float()
-    skip_flags = None if skip is None else torch.from_numpy(skip).to(data.device)
-    result = ops.engine().separable_conv3d(work, taps.to(data.device), radius, skip=skip_flags)
+    skip_flags = None if skip is None else ops.h2d(torch.from_numpy(skip), data.device)
+    result = ops.engine().separable_conv3d(work, ops.h2d(taps, data.device), radius, skip=skip_flags)
     if result.dtype != data.dtype:
         result = result.to(data.dtype)
         if skip is not None:  # untouched rows keep their exact integer values
-            rows = torch.from_numpy(skip.astype(bool)).to(data.device)
+            rows = ops.h2d(torch.from_numpy(skip.astype(bool)), data.device)
             result[rows] = data[rows]
     return result
 

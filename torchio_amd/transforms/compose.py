@@ -35,9 +35,7 @@ class Compose(Transform):
         else:
             self.transforms = list(transforms)
 
-    def forward(self, data: Any) -> Any:
-        if self.copy:
-            data = _copy.deepcopy(data)
+    def _forward(self, data: Any) -> Any:
         batch, unwrap = _wrap(data)
         for transform in self.transforms:
             previous = transform.copy

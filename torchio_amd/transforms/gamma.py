@@ -71,7 +71,7 @@ class _GammaInverse(IntensityTransform):
 def _gamma_pow(data: Tensor, log_gamma) -> Tensor:
     """``sign(x) |x|^gamma`` with the reference's dtype promotion (functional seam S5, gamma.py:88-120)."""
     if isinstance(log_gamma, list):
-        gamma: Any = torch.exp(torch.tensor(log_gamma, dtype=torch.float32)).to(data.device)
+        gamma: Any = ops.h2d(torch.exp(torch.tensor(log_gamma, dtype=torch.float32)), data.device)
         # a (B,1,1,1,1) float32 exponent tensor promotes half / integer data to float32
         work = data if data.dtype in (torch.float32, torch.float64) else data.float()
     else:

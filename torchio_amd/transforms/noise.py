@@ -87,9 +87,9 @@ class Noise(IntensityTransform):
             # data + float32 noise promotes half / integer data to float32 (noise.py:119)
             work = data if data.dtype in (torch.float32, torch.float64) else data.float()
             device = data.device
-            mean_arg = torch.tensor(mean, dtype=torch.float32).to(device) if isinstance(mean, list) else mean
-            std_arg = torch.tensor(std, dtype=torch.float32).to(device) if isinstance(std, list) else std
-            keep_arg = None if keep is None else torch.tensor(keep, dtype=torch.uint8).to(device)
+            mean_arg = ops.h2d(torch.tensor(mean, dtype=torch.float32), device) if isinstance(mean, list) else mean
+            std_arg = ops.h2d(torch.tensor(std, dtype=torch.float32), device) if isinstance(std, list) else std
+            keep_arg = None if keep is None else ops.h2d(torch.tensor(keep, dtype=torch.uint8), device)
             if _NOISE_RNG == "reference":
                 base1 = torch.randn(data.shape, generator=generator).to(device)
                 base2 = torch.randn(data.shape, generator=generator).to(device) if rician else None

@@ -486,15 +486,15 @@ def _apply_spatial_to_batch(
                 displacement = _max_abs_displacement(f)
             _check_folding(f.numpy(), displacement, out_shape, out_spacing)
             stacked.append(f)
-        field_tensor = torch.stack(stacked).to(device)
+        field_tensor = ops.h2d(torch.stack(stacked), device)
         if len(present) != len(fields):
-            cp_skip = torch.tensor([f is None for f in fields], dtype=torch.uint8).to(device)
+            cp_skip = ops.h2d(torch.tensor([f is None for f in fields], dtype=torch.uint8), device)
 
     passthrough = None
     if per_sample is not None and target_space is None:
         flags = [m is None and f is None for m, f in zip(matrices, fields, strict=True)]
         if any(flags):
-            passthrough = torch.tensor(flags, dtype=torch.uint8).to(device)
+            passthrough = ops.h2d(torch.tensor(flags, dtype=torch.uint8), device)
     else:
         flags = [False] * batch_size
 
@@ -519,7 +519,7 @@ def _apply_spatial_to_batch(
     outputs = engine.resample3d(
         tensors,
         out_shape=out_shape,
-        mapping=torch.from_numpy(mapping).to(device),
+        mapping=ops.h2d(torch.from_numpy(mapping), device),
         control_points=field_tensor,
         in_spacing=in_affine.spacing,
         out_spacing=out_affine.spacing,
@@ -557,12 +557,12 @@ def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pa
         return engine.channel_min(data)  # stays on the device: no .item() sync
     elif default_pad_value in ("mean", "otsu"):
         values = [_border_mean(channel, filter_otsu=default_pad_value == "otsu") for channel in data[0]]
-        return torch.tensor(values, dtype=torch.float32).to(data.device)
+        return ops.h2d(torch.tensor(values, dtype=torch.float32), data.device)
     else:
         raise ValueError(f'Unknown default_pad_value "{default_pad_value}"')
     if value == 0.0:
         return None
-    return torch.full((channels,), value, dtype=torch.float32).to(data.device)
+    return ops.h2d(torch.full((channels,), value, dtype=torch.float32), data.device)
 
 
 def _border_mean(channel: Tensor, *, filter_otsu: bool) -> float:
@@ -614,7 +614,7 @@ def _antialias(engine, data: Tensor, in_affine: AffineMatrix, out_affine: Affine
         return data
     taps, radius, _ = _stacked_gaussian_taps(sigmas[None])
     work = data if data.dtype in ops.FLOAT_DTYPES else data.float()
-    return engine.separable_conv3d(work, taps.to(data.device), radius).to(data.dtype)
+    return engine.separable_conv3d(work, ops.h2d(taps, data.device), radius).to(data.dtype)
 
 
 # =============================================================================

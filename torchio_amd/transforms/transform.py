@@ -22,6 +22,7 @@ import torch
 from torch import Tensor
 from torch import nn
 
+from ..data._lazy import LazyCopyScope
 from ..data.batch import ImagesBatch
 from ..data.batch import SubjectsBatch
 from ..data.image import Image
@@ -77,8 +78,19 @@ class Transform(nn.Module):
 
     # -- the envelope ---------------------------------------------------------
     def forward(self, data: Any) -> Any:
+        if self.copy and isinstance(data, (SubjectsBatch, ImagesBatch)):
+            # device-resident batch: share the image tensors now, clone whatever no transform replaced
+            with LazyCopyScope() as scope:
+                data = _copy.deepcopy(data)
+            try:
+                return self._forward(data)
+            finally:
+                scope.materialise()
         if self.copy:
             data = _copy.deepcopy(data)
+        return self._forward(data)
+
+    def _forward(self, data: Any) -> Any:
         batch, unwrap = _wrap(data)
         if not self._per_instance_p_active(batch) and torch.rand(1).item() >= self.p:
             return unwrap(batch)
