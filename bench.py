@@ -198,7 +198,7 @@ def main() -> None:
             },
             "pipeline_algorithmic_GBps": total["algorithmic_bytes"] / total["elapsed_s"] / 1e9,
             "roofline": {
-                "kernel": "tio::resample_kernel (tio_resample3d)",
+                "kernel": "tio::resample_tile_kernel (tio_resample3d: Affine and ElasticDeformation launches, mean)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

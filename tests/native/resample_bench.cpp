@@ -36,6 +36,32 @@ static std::mt19937_64 rng(12345);
 static std::string g_case_filter, g_path_filter;
 static double uni(double lo, double hi) { return std::uniform_real_distribution<double>(lo, hi)(rng); }
 
+
+// calibration kernels for the HBM byte counters (FETCH_SIZE / WRITE_SIZE): known traffic
+__global__ void calib_copy_f4(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) out[i] = in[i];
+}
+__global__ void calib_store64(float* __restrict__ out, size_t n) {  // 16 lanes x 4 B = 64-byte segments, like the 16^3 bricks
+  const size_t row = (blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x) >> 4, lane = threadIdx.x & 15;
+  const size_t rows = n / 16;
+  for (size_t r = row; r < rows; r += (static_cast<size_t>(gridDim.x) * blockDim.x) >> 4) out[((r * 2654435761ull) % rows) * 16 + lane] = 1.0f;
+}
+
+static int run_calibration() {
+  const size_t n = 512ull << 20;  // bytes
+  float *a, *b;
+  HIP_CHECK(hipMalloc(&a, n)); HIP_CHECK(hipMalloc(&b, n));
+  HIP_CHECK(hipMemset(a, 1, n));
+  for (int rep = 0; rep < 3; rep++) {
+    calib_copy_f4<<<8192, 256>>>(reinterpret_cast<const float4*>(a), reinterpret_cast<float4*>(b), n / 16);
+    calib_store64<<<8192, 256>>>(b, n / 4);
+  }
+  HIP_CHECK(hipDeviceSynchronize());
+  printf("calibration: calib_copy_f4 reads %zu and writes %zu bytes per launch; calib_store64 writes %zu bytes per launch\n", n, n, n);
+  hipFree(a); hipFree(b);
+  return 0;
+}
+
 struct Mat3 { double m[3][3]; };
 static Mat3 mul(const Mat3& a, const Mat3& b) {
   Mat3 r{};
@@ -297,6 +323,7 @@ int main(int argc, char** argv) {
   }
   if (tio_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
   int failures = 0;
+  if (cases == "calib") return run_calibration();
   if (cases == "parity" || cases == "all") {
     {  // odd shapes (K % 4 != 0 → scalar staging), fill, shared geometry
       Case c = make_case("odd-shape f32 linear+fill", 2, 50, 37, 75, true, true);
