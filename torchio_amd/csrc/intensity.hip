@@ -145,6 +145,137 @@ __global__ __launch_bounds__(kBlock) void conv_k_kernel(const ConvArgs a) {
   }
 }
 
+// ---- float32 fast paths: 16-byte global accesses ------------------------------------
+// Same arithmetic (tap order, separate multiply and add) as the generic kernels above;
+// used when source and destination are float32, K % 4 == 0, pointers are 16-byte
+// aligned and the radius is small enough for the LDS tile.
+constexpr int kConvMaxRadiusV4 = 16;  // (32 + 2*16) rows x 1 KiB = 64 KiB of LDS
+
+__global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) {
+  // axes I and J.  grid: x = K tiles (256 = 64 lanes x float4), y = tiles along the axis, z = other axis * (B*C)
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int r = a.radius, ntaps = 2 * r + 1;
+  float* s_taps = s_mem;                                                   // ntaps
+  float4* s_tile = reinterpret_cast<float4*>(s_mem + ((ntaps + 3) & ~3));  // (kConvLine + 2r) x 64 float4
+  const int n_other = a.axis == 0 ? a.J : a.I;
+  const int other = blockIdx.z % n_other;
+  const int bc = blockIdx.z / n_other;
+  const int b = bc / a.channels;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 256 + 4 * lane;
+  const int n = a.axis == 0 ? a.I : a.J;
+  const int p0 = blockIdx.y * kConvLine;
+  const int64_t n_spatial = static_cast<int64_t>(a.I) * a.J * a.K;
+  const int64_t stride = a.axis == 0 ? static_cast<int64_t>(a.J) * a.K : a.K;
+  const int64_t other_stride = a.axis == 0 ? a.K : static_cast<int64_t>(a.J) * a.K;
+  const int64_t line = static_cast<int64_t>(bc) * n_spatial + other * other_stride + k;
+  const bool active = k < a.K;
+  const float* src = static_cast<const float*>(a.src);
+  float* dst = static_cast<float*>(a.dst);
+
+  if (a.skip != nullptr && a.skip[b] != 0) {  // rows with no blur: emitted unchanged by the last pass
+    if (a.last_pass && active) {
+      const float* orig = static_cast<const float*>(a.x_orig);
+      for (int q = wave; q < kConvLine && p0 + q < n; q += kBlock / 64) {
+        const int64_t e = line + static_cast<int64_t>(p0 + q) * stride;
+        *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(orig + e);
+      }
+    }
+    return;
+  }
+  const float* t = a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) +
+                   static_cast<int64_t>(a.axis) * a.tap_stride;
+  for (int i = threadIdx.x; i < ntaps; i += kBlock) s_taps[i] = t[i];
+  const int n_out = min(kConvLine, n - p0);
+  const int rows = n_out + 2 * r;
+  if (active) {
+    for (int q0 = wave; q0 < rows; q0 += 4 * (kBlock / 64)) {  // 4 independent 16-byte loads in flight per lane
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = q0 + u * (kBlock / 64);
+        const int pos = min(max(p0 + min(q, rows - 1) - r, 0), n - 1);  // replicate padding == clamp
+        v[u] = *reinterpret_cast<const float4*>(src + line + static_cast<int64_t>(pos) * stride);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = q0 + u * (kBlock / 64);
+        if (q < rows) s_tile[q * 64 + lane] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  for (int q = wave; q < n_out; q += kBlock / 64) {
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4* col = s_tile + q * 64 + lane;
+    for (int tt = 0; tt < ntaps; tt++) {
+      const float w = s_taps[tt];
+      const float4 v = col[tt * 64];
+      acc.x = __fadd_rn(acc.x, __fmul_rn(w, v.x));
+      acc.y = __fadd_rn(acc.y, __fmul_rn(w, v.y));
+      acc.z = __fadd_rn(acc.z, __fmul_rn(w, v.z));
+      acc.w = __fadd_rn(acc.w, __fmul_rn(w, v.w));
+    }
+    *reinterpret_cast<float4*>(dst + line + static_cast<int64_t>(p0 + q) * stride) = acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
+  // axis K.  grid: x = K tiles (256), y = J tiles (4 rows, one per wave), z = I * (B*C).
+  // Row segment staged with one 16-byte load per lane (+ scalar halo), taps applied to
+  // lane-consecutive positions (conflict-free LDS reads), results transposed through LDS
+  // so that the store is one 16-byte access per lane as well.
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int r = a.radius, ntaps = 2 * r + 1;
+  const int r4 = (r + 3) & ~3;                   // aligned offset of the main part inside a staged row
+  const int pitch = kConvKSpan + 2 * r4;         // floats per wave row (multiple of 4)
+  float* s_taps = s_mem;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* s_row = s_mem + ((ntaps + 3) & ~3) + wave * (pitch + kConvKSpan);
+  float* s_out = s_row + pitch;
+  const int i = blockIdx.z % a.I;
+  const int bc = blockIdx.z / a.I;
+  const int b = bc / a.channels;
+  const int j = blockIdx.y * (kBlock / 64) + wave;
+  const int k0 = blockIdx.x * kConvKSpan;
+  const int64_t n_spatial = static_cast<int64_t>(a.I) * a.J * a.K;
+  const int64_t row = static_cast<int64_t>(bc) * n_spatial + (static_cast<int64_t>(i) * a.J + j) * a.K;
+  const bool active = j < a.J;
+  const float* src = static_cast<const float*>(a.src);
+  float* dst = static_cast<float*>(a.dst);
+  const int kk = k0 + 4 * lane;                  // this lane's 4 consecutive positions
+  const bool lane_in = kk < a.K;                 // K % 4 == 0: all four or none
+
+  if (a.skip != nullptr && a.skip[b] != 0) {
+    if (a.last_pass && active && lane_in)
+      *reinterpret_cast<float4*>(dst + row + kk) = *reinterpret_cast<const float4*>(static_cast<const float*>(a.x_orig) + row + kk);
+    return;
+  }
+  const float* t = a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride;
+  for (int q = threadIdx.x; q < ntaps; q += kBlock) s_taps[q] = t[q];
+  const int span = min(kConvKSpan, a.K - k0);
+  if (active) {
+    if (lane_in) *reinterpret_cast<float4*>(s_row + r4 + 4 * lane) = *reinterpret_cast<const float4*>(src + row + kk);
+    for (int q = lane; q < 2 * r; q += 64) {  // halo: r positions on each side, replicate-clamped
+      const int off = q < r ? q - r : span + (q - r);
+      const int pos = min(max(k0 + off, 0), a.K - 1);
+      s_row[r4 + off] = src[row + pos];
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const float* in = s_row + r4 - r;
+    for (int q = lane; q < span; q += 64) {
+      float acc = 0.0f;
+      for (int tt = 0; tt < ntaps; tt++) acc = __fadd_rn(acc, __fmul_rn(s_taps[tt], in[q + tt]));
+      s_out[q] = acc;
+    }
+  }
+  __syncthreads();
+  if (active && lane_in) *reinterpret_cast<float4*>(dst + row + kk) = *reinterpret_cast<const float4*>(s_out + 4 * lane);
+}
+
 template <int DT>
 static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t batch, int32_t channels,
                        const int32_t shape[3], const float* taps, int taps_batched, int tap_stride,
@@ -180,6 +311,26 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
     if (axis == 2) hipLaunchKernelGGL((conv_k_kernel<S, D>), grid, dim3(kBlock), lds, stream, a);  \
     else hipLaunchKernelGGL((conv_line_kernel<S, D>), grid, dim3(kBlock), lds, stream, a);         \
   } while (0)
+    const bool f32_pass = (first ? DT == TIO_F32 : true) && (last ? DT == TIO_F32 : true);
+    const bool aligned = ((shape[2] & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
+                                                     reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if (f32_pass && aligned && radius[axis] <= kConvMaxRadiusV4) {  // 16-byte access fast paths
+      if (axis == 2) {
+        const int r4 = (radius[axis] + 3) & ~3;
+        lds = (((ntaps + 3) & ~3) + 4 * (2 * kConvKSpan + 2 * r4)) * sizeof(float);
+        hipLaunchKernelGGL(conv_k_v4_kernel, grid, dim3(kBlock), lds, stream, a);
+      } else {
+        grid.x = static_cast<unsigned>((shape[2] + 255) / 256);
+        lds = (((ntaps + 3) & ~3) + (kConvLine + 2 * radius[axis]) * 256) * sizeof(float);
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_line_v4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds)) != hipSuccess)
+          return fail(TIO_ERR_LAUNCH, "tio_separable_conv3d: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL(conv_line_v4_kernel, grid, dim3(kBlock), lds, stream, a);
+      }
+      src = dst;
+      continue;
+    }
     if (first && last) TIO_CONV_LAUNCH(DT, DT);
     else if (first) TIO_CONV_LAUNCH(DT, TIO_F32);
     else if (last) TIO_CONV_LAUNCH(TIO_F32, DT);
@@ -244,28 +395,35 @@ __global__ __launch_bounds__(kBlock) void bias_kernel(const void* __restrict__ x
       else v[u] = Elem<DT>::load(x, row + i * slab);
     }
   }
+  // The K- and J-lerps of a coarse plane are invariants of this thread's (j, k) column
+  // (ATen nests K innermost, then J, then I), so they are redone only when the walk
+  // along I enters a new coarse cell — a block-uniform event.
+  auto coarse_plane = [&](int ii) -> float {
+    const int o0 = ii * s_i + lj.i0 * s_j, o1 = ii * s_i + lj.i1 * s_j;
+    float c00, c01, c10, c11;
+    if (in_lds) {
+      c00 = s_coarse[o0 + lk.i0]; c01 = s_coarse[o0 + lk.i1]; c10 = s_coarse[o1 + lk.i0]; c11 = s_coarse[o1 + lk.i1];
+    } else {
+      c00 = fg[o0 + lk.i0]; c01 = fg[o0 + lk.i1]; c10 = fg[o1 + lk.i0]; c11 = fg[o1 + lk.i1];
+    }
+    return lerp2(lerp2(c00, lk.l0, c01, lk.l1), lj.l0, lerp2(c10, lk.l0, c11, lk.l1), lj.l1);
+  };
+  int cur0 = -1, cur1 = -1;
+  float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
   for (int u = 0; u < kBiasTileI; u++) {
     const int i = i_begin + u;
     if (i >= i_end) break;
     const Lerp1D li = lerp_index(i, ci, I, scale_i);
-    const int o00 = li.i0 * s_i + lj.i0 * s_j, o01 = li.i0 * s_i + lj.i1 * s_j;
-    const int o10 = li.i1 * s_i + lj.i0 * s_j, o11 = li.i1 * s_i + lj.i1 * s_j;
-    float c[8];
-    if (in_lds) {
-      c[0] = s_coarse[o00 + lk.i0]; c[1] = s_coarse[o00 + lk.i1]; c[2] = s_coarse[o01 + lk.i0]; c[3] = s_coarse[o01 + lk.i1];
-      c[4] = s_coarse[o10 + lk.i0]; c[5] = s_coarse[o10 + lk.i1]; c[6] = s_coarse[o11 + lk.i0]; c[7] = s_coarse[o11 + lk.i1];
-    } else {
-      c[0] = fg[o00 + lk.i0]; c[1] = fg[o00 + lk.i1]; c[2] = fg[o01 + lk.i0]; c[3] = fg[o01 + lk.i1];
-      c[4] = fg[o10 + lk.i0]; c[5] = fg[o10 + lk.i1]; c[6] = fg[o11 + lk.i0]; c[7] = fg[o11 + lk.i1];
+    if (li.i0 != cur0) {
+      p0 = (li.i0 == cur1) ? p1 : coarse_plane(li.i0);
+      cur0 = li.i0;
     }
-    const float a00 = lerp2(c[0], lk.l0, c[1], lk.l1);
-    const float a01 = lerp2(c[2], lk.l0, c[3], lk.l1);
-    const float a10 = lerp2(c[4], lk.l0, c[5], lk.l1);
-    const float a11 = lerp2(c[6], lk.l0, c[7], lk.l1);
-    const float b0 = lerp2(a00, lj.l0, a01, lj.l1);
-    const float b1 = lerp2(a10, lj.l0, a11, lj.l1);
-    const float field = expf(lerp2(b0, li.l0, b1, li.l1));  // bias_field.py:341
+    if (li.i1 != cur1) {
+      p1 = (li.i1 == cur0) ? p0 : coarse_plane(li.i1);
+      cur1 = li.i1;
+    }
+    const float field = expf(lerp2(p0, li.l0, p1, li.l1));  // bias_field.py:341
     const int64_t idx = row + i * slab;
     if constexpr (DT == TIO_F64) {  // f64 data (x) f32 field promotes to f64
       static_cast<double*>(y)[idx] = divide ? vd[u] / static_cast<double>(field) : vd[u] * static_cast<double>(field);

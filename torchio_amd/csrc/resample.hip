@@ -57,6 +57,7 @@ struct ResampleArgs {
   int n_images;
   ImgArgs img[TIO_MAX_IMAGES];
   int tiles_k, tiles_j, tiles_i;
+  unsigned magic_k, magic_j, magic_i;  // multiply-high reciprocals of the tile counts (tile kernel)
   int cp_lds;    // floats of LDS reserved for the control points (0 = read them from global)
   int tile_cap;  // floats of LDS available for one staged input brick (tile kernel)
   int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
@@ -497,7 +498,8 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     if (const char* env = getenv("TIO_TILE_ABLATE")) a.ablate = atoi(env);
     a.cp_lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? ((n_cp + 3) & ~3) : 0;
     // default brick budget: whatever lets kTileBlocksPerCU blocks share the CU's 160 KiB
-    if (cap <= 0) cap = kLdsFloatsPerCU / kTileBlocksPerCU - a.cp_lds - kTileRedInts - 64;
+    // (minus 2 KiB: the hardware allocates LDS in granules, an exact third does not fit three times)
+    if (cap <= 0) cap = kLdsFloatsPerCU / kTileBlocksPerCU - 512 - a.cp_lds - kTileRedInts;
     const int max_cap = kLdsFloatsPerCU - a.cp_lds - kTileRedInts;
     a.tile_cap = cap < kTileMinCap ? kTileMinCap : (cap > max_cap ? max_cap : cap);
     const size_t lds = static_cast<size_t>(a.cp_lds + kTileRedInts + a.tile_cap) * sizeof(float);
@@ -506,6 +508,9 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     a.tiles_k = (a.Ko + TK - 1) / TK;                                                                    \
     a.tiles_j = (a.Jo + TJ - 1) / TJ;                                                                    \
     a.tiles_i = (a.Io + TI - 1) / TI;                                                                    \
+    a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;                                       \
+    a.magic_j = a.tiles_j > 1 ? 0xFFFFFFFFu / a.tiles_j + 1u : 0u;                                       \
+    a.magic_i = a.tiles_i > 1 ? 0xFFFFFFFFu / a.tiles_i + 1u : 0u;                                       \
     const int64_t blocks = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;                \
     if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");  \
     auto kernel = resample_tile_kernel<EL, DM, TI, TJ, TK, OCC>;                                            \

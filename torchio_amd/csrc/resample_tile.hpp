@@ -340,6 +340,37 @@ __device__ __forceinline__ void stage_brick_f32x4(float* __restrict__ tile, cons
   }
 }
 
+// Interior boxes (every staged position inside the volume): global → LDS directly
+// (global_load_lds_dwordx4: each lane names one 16-byte chunk, a wave fills 1 KiB of
+// consecutive LDS), so the brick never passes through VGPRs and there is no ds_write.
+// Chunk id → (row, chunk) → global offset costs a few integer ops per chunk.
+template <int NT>
+__device__ __forceinline__ void stage_brick_dma(float* __restrict__ tile, const float* __restrict__ src, int tid,
+                                                const TileBox& bx, int J, int K) {
+  const unsigned cpr = static_cast<unsigned>(bx.Lz) >> 2;
+  const unsigned total = static_cast<unsigned>(bx.Lx * bx.Ly) * cpr;
+  const unsigned m_cpr = fastdiv_magic(cpr), m_ly = fastdiv_magic(bx.Ly);
+  const int wave_base = (tid >> 6) << 6;  // wave-uniform first chunk id of this wave in an iteration
+  typedef __attribute__((address_space(3))) float* lds_float_ptr;
+  typedef __attribute__((address_space(1))) const float* global_float_ptr;
+  const int origin = (bx.bx0 * J + bx.by0) * K + bx.za;
+  const int JmLyK = (J - bx.Ly) * K;
+  for (unsigned base = 0; base < total; base += NT) {
+    const unsigned id = base + static_cast<unsigned>(tid);
+    if (id < total) {  // tail lanes are masked off: nothing is written past the box
+      const unsigned row = fastdiv(id, m_cpr, cpr);
+      const unsigned ch = id - row * cpr;
+      const unsigned xr = fastdiv(row, m_ly, bx.Ly);
+      // element offset of (bx0 + xr, by0 + yr, za + 4 ch) = origin + row K + xr (J - Ly) K + 4 ch
+      const int off = origin + static_cast<int>(row) * K + static_cast<int>(xr) * JmLyK + 4 * static_cast<int>(ch);
+      // the hardware writes lane l of the wave at (wave-uniform LDS base) + 16 l
+      lds_float_ptr dst = (lds_float_ptr)(tile) + 4 * (base + static_cast<unsigned>(wave_base));
+      __builtin_amdgcn_global_load_lds((global_float_ptr)(src + off), dst, 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int NT, int DTMODE>
 __device__ __forceinline__ void stage_brick_generic(float* __restrict__ tile, const void* __restrict__ src, int dtype,
                                                     int tid, const TileBox& bx, int I, int J, int K) {
@@ -496,6 +527,8 @@ __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArg
   const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
   __syncthreads();  // previous brick of this block fully consumed
   if (a.ablate & 1) {
+  } else if (vec_ok && bx.interior && !(a.ablate & 8)) {
+    stage_brick_dma<NT>(s_tile, static_cast<const float*>(g.in) + bc * n_in, tid, bx, a.J, a.K);
   } else if (vec_ok) {
     stage_brick_f32x4<NT>(s_tile, static_cast<const float*>(g.in) + bc * n_in, tid, bx, a.I, a.J, a.K);
   } else {
@@ -567,13 +600,15 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
   int* s_red = reinterpret_cast<int*>(smem + a.cp_lds);
   float* s_tile = smem + a.cp_lds + kTileRedInts;
 
+  // tile decode on the scalar unit: host-computed magic multipliers instead of divisions
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int kt = tile % a.tiles_k;
-  const unsigned t1 = tile / a.tiles_k;
-  const int jt = t1 % a.tiles_j;
-  const unsigned t2 = t1 / a.tiles_j;
-  const int it = t2 % a.tiles_i;
-  const int b = t2 / a.tiles_i;
+  const unsigned t1 = fastdiv(tile, a.magic_k, a.tiles_k);
+  const int kt = tile - t1 * a.tiles_k;
+  const unsigned t2 = fastdiv(t1, a.magic_j, a.tiles_j);
+  const int jt = t1 - t2 * a.tiles_j;
+  const unsigned t3 = fastdiv(t2, a.magic_i, a.tiles_i);
+  const int it = t2 - t3 * a.tiles_i;
+  const int b = t3;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -618,9 +653,9 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
   const float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
   const float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
   const float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
-  bool weird = false;
+  bool weird = false;  // |m| > 1e30, Inf or NaN — an integer compare on the bit pattern (scalar ALU)
 #pragma unroll
-  for (int q = 0; q < 12; q++) weird |= !(fabsf(m[q]) <= 1e30f);
+  for (int q = 0; q < 12; q++) weird |= (__float_as_uint(m[q]) & 0x7FFFFFFFu) > 0x7149F2CAu;
 
   bool elastic = false;
   const float* cp = nullptr;
