@@ -279,3 +279,37 @@ def test_engine_rejects_cpu_tensors(hip):
 
     with pytest.raises(EngineError):
         hip.gamma_pow(torch.rand(1, 1, 2, 2, 2), 1.5)
+
+
+@pytest.mark.parametrize(
+    "shape",
+    [(2, 2, 19, 23, 72), (1, 1, 70, 40, 64), (1, 1, 9, 50, 520), (1, 2, 37, 5, 256)],
+)
+def test_separable_conv_float4_paths(oracle, hip, shape):
+    """K % 4 == 0 float32: the marching / 16-byte kernels (several steps, segments and K tiles)."""
+    data = _data(shape, torch.float32, 61)
+    taps, radius = _taps(1, [(1.3, 0.6, 2.0)], 32)
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, radius))
+    assert torch.equal(cpu, gpu.cpu())
+
+
+def test_separable_conv_float4_per_element_skip_and_single_axes(oracle, hip):
+    data = _data((3, 1, 40, 36, 128), torch.float32, 62)
+    taps, radius = _taps(3, [(1.0, 1.7, 0.7), (0.0, 0.0, 0.0), (0.4, 0.5, 1.9)], 16)
+    skip = torch.tensor([0, 1, 0], dtype=torch.uint8)
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, radius), skip=skip)
+    assert torch.equal(cpu, gpu.cpu())
+    assert torch.equal(gpu[1].cpu(), data[1])
+    for sigmas in [(2.0, 0.0, 0.0), (0.0, 1.2, 0.0), (0.0, 0.0, 0.9)]:
+        taps1, radius1 = _taps(1, [sigmas], 16)
+        cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps1, radius1))
+        assert torch.equal(cpu, gpu.cpu())
+
+
+@pytest.mark.parametrize("sigmas", [(0.5, 0.5, 3.5), (3.1, 4.0, 0.4), (0.5, 0.5, 6.0), (5.5, 0.3, 2.7)])
+def test_separable_conv_float4_radius_classes(oracle, hip, sigmas):
+    """K radius <= 8 (register window), 9..16 (LDS loop), > 16 (generic kernels); long line radii."""
+    data = _data((1, 1, 45, 41, 128), torch.float32, 63)
+    taps, radius = _taps(1, [sigmas], 48)
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, radius))
+    assert torch.equal(cpu, gpu.cpu())

@@ -7,6 +7,8 @@
 //   tio_channel_min       (default_pad_value="minimum"; spatial.py:2054-2095)
 // All are HBM-bound elementwise / stencil passes: one read + one write of the
 // volume per op (the separable stencil: per active axis).  No MFMA.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace tio {
@@ -151,12 +153,18 @@ __global__ __launch_bounds__(kBlock) void conv_k_kernel(const ConvArgs a) {
 // aligned and the radius is small enough for the LDS tile.
 constexpr int kConvMaxRadiusV4 = 16;  // (32 + 2*16) rows x 1 KiB = 64 KiB of LDS
 
+constexpr int kConvStep = 16;  // output rows per marching step (axes I, J)
+
 __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) {
-  // axes I and J.  grid: x = K tiles (256 = 64 lanes x float4), y = tiles along the axis, z = other axis * (B*C)
+  // axes I and J.  grid: x = K tiles (256 = 64 lanes x float4), y = segments along the axis, z = other axis * (B*C).
+  // A block marches along the stencil axis with a ring of kConvStep + 2r + kConvStep rows in
+  // LDS: every input row is fetched exactly once (no halo re-reads between steps) and the
+  // 16-byte loads of step s+1 are in flight while step s is computed.
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int r = a.radius, ntaps = 2 * r + 1;
+  const int ring = 2 * kConvStep + 2 * r;
   float* s_taps = s_mem;                                                   // ntaps
-  float4* s_tile = reinterpret_cast<float4*>(s_mem + ((ntaps + 3) & ~3));  // (kConvLine + 2r) x 64 float4
+  float4* s_ring = reinterpret_cast<float4*>(s_mem + ((ntaps + 3) & ~3));  // ring x 64 float4
   const int n_other = a.axis == 0 ? a.J : a.I;
   const int other = blockIdx.z % n_other;
   const int bc = blockIdx.z / n_other;
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * 256 + 4 * lane;
   const int n = a.axis == 0 ? a.I : a.J;
-  const int p0 = blockIdx.y * kConvLine;
+  const int seg = (n + gridDim.y - 1) / gridDim.y;                 // outputs per segment (multiple of kConvStep except the last)
+  const int p_begin = blockIdx.y * seg, p_end = min(p_begin + seg, n);
   const int64_t n_spatial = static_cast<int64_t>(a.I) * a.J * a.K;
   const int64_t stride = a.axis == 0 ? static_cast<int64_t>(a.J) * a.K : a.K;
   const int64_t other_stride = a.axis == 0 ? a.K : static_cast<int64_t>(a.J) * a.K;
@@ -172,12 +181,13 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   const bool active = k < a.K;
   const float* src = static_cast<const float*>(a.src);
   float* dst = static_cast<float*>(a.dst);
+  if (p_begin >= p_end) return;
 
   if (a.skip != nullptr && a.skip[b] != 0) {  // rows with no blur: emitted unchanged by the last pass
     if (a.last_pass && active) {
       const float* orig = static_cast<const float*>(a.x_orig);
-      for (int q = wave; q < kConvLine && p0 + q < n; q += kBlock / 64) {
-        const int64_t e = line + static_cast<int64_t>(p0 + q) * stride;
+      for (int p = p_begin + wave; p < p_end; p += kBlock / 64) {
+        const int64_t e = line + static_cast<int64_t>(p) * stride;
         *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(orig + e);
       }
     }
@@ -185,50 +195,87 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   }
   const float* t = a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) +
                    static_cast<int64_t>(a.axis) * a.tap_stride;
-  for (int i = threadIdx.x; i < ntaps; i += kBlock) s_taps[i] = t[i];
-  const int n_out = min(kConvLine, n - p0);
-  const int rows = n_out + 2 * r;
+  typedef __attribute__((address_space(4))) const float* const_float_ptr;  // taps are read-only for the whole launch
+  const_float_ptr tc = (const_float_ptr)(t);
+  (void)s_taps;
+  constexpr int RW = kConvStep / (kBlock / 64);  // rows per wave per step (4)
+  // logical row index q counts from p_begin - r; ring slot = q mod ring (tracked incrementally)
+  // prologue: rows q in [0, kConvStep + 2r) for the first step
   if (active) {
-    for (int q0 = wave; q0 < rows; q0 += 4 * (kBlock / 64)) {  // 4 independent 16-byte loads in flight per lane
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int q = q0 + u * (kBlock / 64);
-        const int pos = min(max(p0 + min(q, rows - 1) - r, 0), n - 1);  // replicate padding == clamp
-        v[u] = *reinterpret_cast<const float4*>(src + line + static_cast<int64_t>(pos) * stride);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int q = q0 + u * (kBlock / 64);
-        if (q < rows) s_tile[q * 64 + lane] = v[u];
-      }
+    for (int q = wave; q < kConvStep + 2 * r; q += kBlock / 64) {
+      const int pos = min(max(p_begin - r + q, 0), n - 1);  // replicate padding == clamp
+      s_ring[q * 64 + lane] = *reinterpret_cast<const float4*>(src + line + static_cast<int64_t>(pos) * stride);
     }
   }
   __syncthreads();
-  if (!active) return;
-  for (int q = wave; q < n_out; q += kBlock / 64) {
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float4* col = s_tile + q * 64 + lane;
-    for (int tt = 0; tt < ntaps; tt++) {
-      const float w = s_taps[tt];
-      const float4 v = col[tt * 64];
-      acc.x = __fadd_rn(acc.x, __fmul_rn(w, v.x));
-      acc.y = __fadd_rn(acc.y, __fmul_rn(w, v.y));
-      acc.z = __fadd_rn(acc.z, __fmul_rn(w, v.z));
-      acc.w = __fadd_rn(acc.w, __fmul_rn(w, v.w));
+  int slot0 = 0;  // ring slot of logical row (step start - r)
+  // rows of step s+1 (pre1) are written to the ring at the end of step s; rows of step s+2
+  // (pre2) are requested at the start of step s — two steps of 16-byte loads in flight per lane
+  typedef float v4f __attribute__((ext_vector_type(4)));  // native vector type: stays in registers (HIP's float4 struct arrays did not)
+  v4f pre1[RW], pre2[RW];
+#define TIO_FETCH_ROWS(DSTV, P_FIRST) /* rows P_FIRST + r + wave*RW + u, replicate-clamped */        \
+  _Pragma("unroll") for (int u = 0; u < RW; u++) {                                                  \
+    const int pos_ = min(max((P_FIRST) + r + wave * RW + u, 0), n - 1);                             \
+    DSTV[u] = *reinterpret_cast<const v4f*>(src + line + static_cast<int64_t>(pos_) * stride);     \
+  }
+  if (active && p_begin + kConvStep < p_end) { TIO_FETCH_ROWS(pre1, p_begin + kConvStep) }
+  for (int p0 = p_begin; p0 < p_end; p0 += kConvStep) {
+    const bool more = p0 + kConvStep < p_end;
+    if (active && p0 + 2 * kConvStep < p_end) { TIO_FETCH_ROWS(pre2, p0 + 2 * kConvStep) }
+    if (active) {
+#pragma unroll
+      for (int u = 0; u < RW; u++) {
+        const int o = wave * RW + u;  // output row inside the step
+        if (p0 + o < p_end) {
+          float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          int slot = slot0 + o;
+          if (slot >= ring) slot -= ring;
+          for (int tt = 0; tt < ntaps; tt++) {
+            const float w = tc[tt];  // scalar load (constant address space), not an LDS read per lane
+            const float4 v = s_ring[slot * 64 + lane];
+            acc.x = __fadd_rn(acc.x, __fmul_rn(w, v.x));
+            acc.y = __fadd_rn(acc.y, __fmul_rn(w, v.y));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(w, v.z));
+            acc.w = __fadd_rn(acc.w, __fmul_rn(w, v.w));
+            slot = slot + 1 == ring ? 0 : slot + 1;
+          }
+          *reinterpret_cast<float4*>(dst + line + static_cast<int64_t>(p0 + o) * stride) = acc;
+        }
+      }
     }
-    *reinterpret_cast<float4*>(dst + line + static_cast<int64_t>(p0 + q) * stride) = acc;
+    if (more) {
+      // the new rows overwrite slots that were last read one step ago (ring = 2 steps + 2r)
+      if (active) {
+#pragma unroll
+        for (int u = 0; u < RW; u++) {
+          int slot = slot0 + kConvStep + 2 * r + wave * RW + u;
+          if (slot >= ring) slot -= ring;
+          if (slot >= ring) slot -= ring;
+          *reinterpret_cast<v4f*>(&s_ring[slot * 64 + lane]) = pre1[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RW; u++) pre1[u] = pre2[u];
+      slot0 += kConvStep;
+      if (slot0 >= ring) slot0 -= ring;
+      __syncthreads();
+    }
   }
 }
 
+#undef TIO_FETCH_ROWS
+
+constexpr int kConvKRows = 16;  // rows per wave per block (axis K)
+
 __global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
-  // axis K.  grid: x = K tiles (256), y = J tiles (4 rows, one per wave), z = I * (B*C).
-  // Row segment staged with one 16-byte load per lane (+ scalar halo), taps applied to
-  // lane-consecutive positions (conflict-free LDS reads), results transposed through LDS
-  // so that the store is one 16-byte access per lane as well.
+  // axis K.  grid: x = K tiles (256), y = J groups (4 waves x kConvKRows rows), z = I * (B*C).
+  // Each wave walks kConvKRows rows: one 16-byte load per lane per row (the next row's load
+  // is in flight while the current one is filtered), taps applied to lane-consecutive
+  // positions (conflict-free LDS reads), results transposed through LDS so that the store
+  // is one 16-byte access per lane as well.
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int r = a.radius, ntaps = 2 * r + 1;
-  const int r4 = (r + 3) & ~3;                   // aligned offset of the main part inside a staged row
+  const int r4 = max((r + 3) & ~3, 8);           // aligned offset of the main part inside a staged row (>= 8: window path)
   const int pitch = kConvKSpan + 2 * r4;         // floats per wave row (multiple of 4)
   float* s_taps = s_mem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -237,43 +284,114 @@ __global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
   const int i = blockIdx.z % a.I;
   const int bc = blockIdx.z / a.I;
   const int b = bc / a.channels;
-  const int j = blockIdx.y * (kBlock / 64) + wave;
+  const int j0 = (blockIdx.y * (kBlock / 64) + wave) * kConvKRows;
   const int k0 = blockIdx.x * kConvKSpan;
   const int64_t n_spatial = static_cast<int64_t>(a.I) * a.J * a.K;
-  const int64_t row = static_cast<int64_t>(bc) * n_spatial + (static_cast<int64_t>(i) * a.J + j) * a.K;
-  const bool active = j < a.J;
+  const int64_t plane = static_cast<int64_t>(bc) * n_spatial + static_cast<int64_t>(i) * a.J * a.K;
   const float* src = static_cast<const float*>(a.src);
   float* dst = static_cast<float*>(a.dst);
   const int kk = k0 + 4 * lane;                  // this lane's 4 consecutive positions
   const bool lane_in = kk < a.K;                 // K % 4 == 0: all four or none
+  const int j_end = min(j0 + kConvKRows, a.J);
 
   if (a.skip != nullptr && a.skip[b] != 0) {
-    if (a.last_pass && active && lane_in)
-      *reinterpret_cast<float4*>(dst + row + kk) = *reinterpret_cast<const float4*>(static_cast<const float*>(a.x_orig) + row + kk);
+    if (a.last_pass && lane_in) {
+      const float* orig = static_cast<const float*>(a.x_orig);
+      for (int j = j0; j < j_end; j++)
+        *reinterpret_cast<float4*>(dst + plane + static_cast<int64_t>(j) * a.K + kk) =
+            *reinterpret_cast<const float4*>(orig + plane + static_cast<int64_t>(j) * a.K + kk);
+    }
     return;
   }
   const float* t = a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride;
-  for (int q = threadIdx.x; q < ntaps; q += kBlock) s_taps[q] = t[q];
+  typedef __attribute__((address_space(4))) const float* const_float_ptr;  // taps are read-only for the whole launch
+  const_float_ptr tc = (const_float_ptr)(t);  // scalar loads; every wave works on its own LDS rows, no block barrier
+  (void)s_taps;
   const int span = min(kConvKSpan, a.K - k0);
-  if (active) {
-    if (lane_in) *reinterpret_cast<float4*>(s_row + r4 + 4 * lane) = *reinterpret_cast<const float4*>(src + row + kk);
-    for (int q = lane; q < 2 * r; q += 64) {  // halo: r positions on each side, replicate-clamped
-      const int off = q < r ? q - r : span + (q - r);
-      const int pos = min(max(k0 + off, 0), a.K - 1);
-      s_row[r4 + off] = src[row + pos];
+  const float* in = s_row + r4 - r;
+  // halo: lane q < 2r owns one replicate-clamped position outside the span (r on each side);
+  // it is fetched together with the row, one row ahead, so no load sits on the critical path
+  const int h_off = lane < r ? lane - r : span + (lane - r);
+  const int h_pos = min(max(k0 + h_off, 0), a.K - 1);
+  const bool h_in = lane < 2 * r;  // r <= kConvMaxRadiusV4 = 16: at most 32 halo lanes
+  constexpr int G = 4;  // rows per group: the next group's loads are in flight while this one is filtered
+  float4 cur[G], nxt[G];
+  float hcur[G], hnxt[G];
+#pragma unroll
+  for (int u = 0; u < G; u++) {
+    cur[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    hcur[u] = 0.0f;
+    if (j0 + u < j_end) {
+      const int64_t row = plane + static_cast<int64_t>(j0 + u) * a.K;
+      if (lane_in) cur[u] = *reinterpret_cast<const float4*>(src + row + kk);
+      if (h_in) hcur[u] = src[row + h_pos];
     }
   }
-  __syncthreads();
-  if (active) {
-    const float* in = s_row + r4 - r;
-    for (int q = lane; q < span; q += 64) {
-      float acc = 0.0f;
-      for (int tt = 0; tt < ntaps; tt++) acc = __fadd_rn(acc, __fmul_rn(s_taps[tt], in[q + tt]));
-      s_out[q] = acc;
+  for (int jg = j0; jg < j_end; jg += G) {
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      nxt[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      hnxt[u] = 0.0f;
+      if (jg + G + u < j_end) {
+        const int64_t row = plane + static_cast<int64_t>(jg + G + u) * a.K;
+        if (lane_in) nxt[u] = *reinterpret_cast<const float4*>(src + row + kk);
+        if (h_in) hnxt[u] = src[row + h_pos];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const int j = jg + u;
+      if (j < j_end) {
+        const int64_t row = plane + static_cast<int64_t>(j) * a.K;
+        if (lane_in) *reinterpret_cast<float4*>(s_row + r4 + 4 * lane) = cur[u];
+        if (h_in) s_row[r4 + h_off] = hcur[u];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // same wave: LDS operations complete in order
+        __builtin_amdgcn_wave_barrier();
+        if (r <= 8) {
+          // register window: the lane's 4 outputs need positions 4l-8 .. 4l+11 = five aligned
+          // 16-byte LDS reads (instead of one 4-byte read per tap and output); taps outside the
+          // radius are skipped by a scalar branch, so the accumulation order is the oracle's
+          const float4* rv = reinterpret_cast<const float4*>(s_row + r4) + lane;
+          float w[20];
+#pragma unroll
+          for (int d = 0; d < 5; d++) {
+            const float4 c = rv[d - 2];
+            w[4 * d] = c.x; w[4 * d + 1] = c.y; w[4 * d + 2] = c.z; w[4 * d + 3] = c.w;
+          }
+          float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+          for (int jj = 0; jj < 17; jj++) {
+            if (jj >= 8 - r && jj <= 8 + r) {
+              const float tw = tc[jj - (8 - r)];
+              acc.x = __fadd_rn(acc.x, __fmul_rn(tw, w[jj]));
+              acc.y = __fadd_rn(acc.y, __fmul_rn(tw, w[jj + 1]));
+              acc.z = __fadd_rn(acc.z, __fmul_rn(tw, w[jj + 2]));
+              acc.w = __fadd_rn(acc.w, __fmul_rn(tw, w[jj + 3]));
+            }
+          }
+          if (lane_in) *reinterpret_cast<float4*>(dst + row + kk) = acc;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          continue;
+        }
+        for (int q = lane; q < span; q += 64) {
+          float acc = 0.0f;
+          for (int tt = 0; tt < ntaps; tt++) acc = __fadd_rn(acc, __fmul_rn(tc[tt], in[q + tt]));
+          s_out[q] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane_in) *reinterpret_cast<float4*>(dst + row + kk) = *reinterpret_cast<const float4*>(s_out + 4 * lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      cur[u] = nxt[u];
+      hcur[u] = hnxt[u];
     }
   }
-  __syncthreads();
-  if (active && lane_in) *reinterpret_cast<float4*>(dst + row + kk) = *reinterpret_cast<const float4*>(s_out + 4 * lane);
 }
 
 template <int DT>
@@ -316,12 +434,20 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
                                                      reinterpret_cast<uintptr_t>(x)) & 15) == 0;
     if (f32_pass && aligned && radius[axis] <= kConvMaxRadiusV4) {  // 16-byte access fast paths
       if (axis == 2) {
-        const int r4 = (radius[axis] + 3) & ~3;
+        const int r4 = std::max((radius[axis] + 3) & ~3, 8);
         lds = (((ntaps + 3) & ~3) + 4 * (2 * kConvKSpan + 2 * r4)) * sizeof(float);
+        grid.y = static_cast<unsigned>((shape[1] + 4 * kConvKRows - 1) / (4 * kConvKRows));
         hipLaunchKernelGGL(conv_k_v4_kernel, grid, dim3(kBlock), lds, stream, a);
       } else {
+        // one or two marching segments per line: enough blocks to fill the chip, halo re-read only at the cut
+        const int n = shape[axis], other = axis == 0 ? shape[1] : shape[0];
+        const int64_t lines = static_cast<int64_t>((shape[2] + 255) / 256) * other * bcs;
+        int segs = lines >= 4096 ? 1 : (lines >= 2048 ? 2 : 4);
+        int seg_len = ((n + segs - 1) / segs + kConvStep - 1) / kConvStep * kConvStep;
+        segs = (n + seg_len - 1) / seg_len;
         grid.x = static_cast<unsigned>((shape[2] + 255) / 256);
-        lds = (((ntaps + 3) & ~3) + (kConvLine + 2 * radius[axis]) * 256) * sizeof(float);
+        grid.y = static_cast<unsigned>(segs);
+        lds = (((ntaps + 3) & ~3) + (2 * kConvStep + 2 * radius[axis]) * 256) * sizeof(float);
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_line_v4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds)) != hipSuccess)
@@ -459,9 +585,11 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, int stream_id, uin
     const float u1 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h] >> 8), 0.5f), 1.0f / 16777216.0f);
     const float u2 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h + 1] >> 8), 0.5f), 1.0f / 16777216.0f);
     const float radius = sqrtf(__fmul_rn(-2.0f, logf(u1)));
-    const float theta = __fmul_rn(6.28318530717958647692f, u2);
-    float sn, cs;
-    sincosf(theta, &sn, &cs);
+    // cos / sin of 2 pi u2: the hardware units take their argument in revolutions, so u2 in
+    // (0, 1) needs no range reduction (v_cos_f32 / v_sin_f32; within 2e-5 of libm on z,
+    // tests/test_gpu_ops_parity.py::test_philox_stream_and_fast_noise)
+    const float cs = __builtin_amdgcn_cosf(u2);
+    const float sn = __builtin_amdgcn_sinf(u2);
     z[2 * h] = __fmul_rn(radius, cs);
     z[2 * h + 1] = __fmul_rn(radius, sn);
   }
@@ -530,6 +658,20 @@ __global__ __launch_bounds__(kBlock) void noise_kernel(const void* __restrict__ 
           z2[t] = z[g & 3];
         }
       }
+    }
+  }
+  if constexpr (DT == TIO_F32) {
+    // whole, 16-byte aligned quad: one vector load and one vector store per thread
+    if (cnt == 4 && (((base + e0) & 3) == 0) && !rician &&
+        (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)) {
+      const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(x) + base + e0);
+      float4 o;
+      o.x = __fadd_rn(v.x, __fadd_rn(mu, __fmul_rn(sd, z1[0])));  // noise.py:178, :119
+      o.y = __fadd_rn(v.y, __fadd_rn(mu, __fmul_rn(sd, z1[1])));
+      o.z = __fadd_rn(v.z, __fadd_rn(mu, __fmul_rn(sd, z1[2])));
+      o.w = __fadd_rn(v.w, __fadd_rn(mu, __fmul_rn(sd, z1[3])));
+      *reinterpret_cast<float4*>(static_cast<float*>(y) + base + e0) = o;
+      return;
     }
   }
   for (int t = 0; t < cnt; t++) {

@@ -38,7 +38,10 @@ namespace tio {
 
 constexpr int kTileRedInts = 320;    // LDS ints: 7 reduction slots x 32, then 4 pass boxes x 16
 constexpr int kTileBoxBase = 224;
-constexpr int kTileStashPlanes = 4;  // planes parked in the brick area by the per-voxel fallback
+constexpr int kTileStashPlanes = 4;
+#ifndef TILE_GROUP
+#define TILE_GROUP 4
+#endif  // planes parked in the brick area by the per-voxel fallback
 
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned d) {
   return d == 1 ? n : __umulhi(n, magic);  // exact for n * d < 2^32
@@ -556,16 +559,20 @@ __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArg
     if (q < q_begin || q >= q_end) continue;  // scalar branch
     char* out_t = out_c + (q * QT) * slab_b;
     if (bx.interior && full) {
-      TapSet ts[QT];
+      constexpr int G = TILE_GROUP < QT ? TILE_GROUP : QT;  // voxels with their LDS reads in flight together
 #pragma unroll
-      for (int u = 0; u < QT; u++) tile_issue_interior<LAUNDER>(ts[u], X[q * QT + u], Y[q * QT + u], Z[q * QT + u], ta, c);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int u0 = 0; u0 < QT; u0 += G) {
+        TapSet ts[G];
 #pragma unroll
-      for (int u = 0; u < QT; u++) {
-        store_at<DTMODE>(out_t, g.dtype, urow, tile_finish(ts[u]));
-        out_t += slab_b;
+        for (int u = 0; u < G; u++) tile_issue_interior<LAUNDER>(ts[u], X[q * QT + u0 + u], Y[q * QT + u0 + u], Z[q * QT + u0 + u], ta, c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+          store_at<DTMODE>(out_t, g.dtype, urow, tile_finish(ts[u]));
+          out_t += slab_b;
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     } else if (bx.interior) {
 #pragma unroll
       for (int u = 0; u < QT; u++) {
