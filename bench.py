@@ -157,6 +157,7 @@ def main() -> None:
     start = time.perf_counter()
     for _ in range(args.steps):
         out = transform(batch)
+    host_enqueue_s = time.perf_counter() - start  # host time to issue all steps (no sync inside the loop)
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
@@ -197,6 +198,7 @@ def main() -> None:
                 "parallelism": f"batch-split x{args.gpus} (no data-path collective)",
             },
             "pipeline_algorithmic_GBps": total["algorithmic_bytes"] / total["elapsed_s"] / 1e9,
+            "host_enqueue_ms_per_step": 1e3 * host_enqueue_s / args.steps,
             "roofline": {
                 "kernel": "tio::resample_tile_kernel (tio_resample3d: Affine and ElasticDeformation launches, mean)",
                 "bound": "hbm",

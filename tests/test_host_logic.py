@@ -336,3 +336,40 @@ def test_lazy_copy_never_aliases_the_input(oracle):
         assert changed.seg.data.data_ptr() != batch.seg.data.data_ptr()  # label map untouched by Gamma → cloned
         assert not torch.equal(changed.t1.data, original)
     assert torch.equal(batch.t1.data, original)  # the caller's tensors are never modified
+
+
+def test_lazy_params_reads_like_the_eager_dict(oracle):
+    """Elastic control points are parked as tensors and turn into nested lists on any read."""
+    import copy
+    import json
+    import pickle
+
+    import torchio_amd as tio
+    from parity_harness import make_subjects, use_engine
+    from torchio_amd.transforms._lazy_params import LazyParams
+
+    batch = tio.SubjectsBatch.from_subjects(make_subjects(12, 3, seed=5))
+    transform = tio.ElasticDeformation()
+    with use_engine(oracle):
+        torch.manual_seed(7)
+        out = transform(batch)
+        torch.manual_seed(7)
+        again = transform(batch)
+    params = out.applied_transforms[-1].params
+    assert isinstance(params, LazyParams) and isinstance(params, dict)
+    parked, fields = params.raw("control_points")
+    assert parked and len(fields) == 3 and all(isinstance(f, torch.Tensor) for f in fields)
+    assert list(params)[:2] == ["selected_images", "original"]  # keys and their order are those of the eager dict
+    # equality between two histories (both lazy) and against a materialised plain dict
+    assert params == again.applied_transforms[-1].params
+    as_text = json.dumps(params)  # the C encoder goes through .items()
+    assert json.loads(as_text)["control_points"][0][1][2][3] == params["control_points"][0][1][2][3]
+    assert not params.raw("control_points")[0]  # read once → stored as lists from now on
+    assert isinstance(params["control_points"][0], list) and len(params["control_points"][0]) == 7
+    clone = copy.deepcopy(again.applied_transforms[-1].params)
+    assert type(clone) is dict and clone == params
+    assert pickle.loads(pickle.dumps(params)) == dict(params)
+    # the history still drives the inverse transform
+    with use_engine(oracle):
+        restored = out.apply_inverse_transform()
+    assert restored.t1.data.shape == batch.t1.data.shape

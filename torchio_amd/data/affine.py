@@ -13,7 +13,7 @@ from torch import Tensor
 class AffineMatrix:
     """4x4 float64 matrix mapping voxel indices to world (mm) coordinates."""
 
-    __slots__ = ("_matrix",)
+    __slots__ = ("_matrix", "_spacing_cache")
 
     def __init__(self, matrix=None) -> None:
         if matrix is None:
@@ -27,6 +27,7 @@ class AffineMatrix:
         if tuple(value.shape) != (4, 4):
             raise ValueError(f"AffineMatrix must be 4x4, got {tuple(value.shape)}")
         self._matrix = value
+        self._spacing_cache = None  # (tensor version, spacing): the 4x4 may be edited in place through .data
 
     @classmethod
     def from_spacing(cls, spacing, *, origin=(0.0, 0.0, 0.0), direction=None) -> "AffineMatrix":
@@ -50,8 +51,14 @@ class AffineMatrix:
 
     @property
     def spacing(self) -> tuple[float, float, float]:
-        norms = self._column_norms()
-        return (float(norms[0]), float(norms[1]), float(norms[2]))
+        version = self._matrix._version
+        cached = self._spacing_cache
+        if cached is not None and cached[0] == version:
+            return cached[1]
+        norms = self._column_norms().tolist()
+        value = (float(norms[0]), float(norms[1]), float(norms[2]))
+        self._spacing_cache = (version, value)
+        return value
 
     @property
     def origin(self) -> tuple[float, float, float]:

@@ -37,6 +37,7 @@ from ..data.image import LabelMap
 from .blur import _stacked_gaussian_taps
 from .parameter_range import Choice
 from .parameter_range import _ParameterRange
+from ._lazy_params import LazyParams
 from .transform import SpatialTransform
 
 LABEL_INTERPOLATION = "label"
@@ -140,9 +141,7 @@ class Spatial(SpatialTransform):
         degrees = self.degrees.sample()
         translation = self.translation.sample()
         has_affine = not (
-            np.allclose(scales, (1.0, 1.0, 1.0))
-            and np.allclose(degrees, (0.0, 0.0, 0.0))
-            and np.allclose(translation, (0.0, 0.0, 0.0))
+            _all_close(scales, 1.0) and _all_close(degrees, 0.0) and _all_close(translation, 0.0)
         )
         if self.control_points is not None:
             field = self.control_points.clone()
@@ -166,7 +165,8 @@ class Spatial(SpatialTransform):
             return {"selected_images": []}
         first = next(iter(images.values()))
         shape, affine = _spatial_shape(first), first.affines[0]
-        params: dict[str, Any] = {
+        params: dict[str, Any] = LazyParams()
+        params.update({
             "selected_images": list(images),
             "original": _serialize_space((shape, affine)),
             "affine_first": self.affine_first,
@@ -176,7 +176,7 @@ class Spatial(SpatialTransform):
             "antialias": self.antialias,
             "default_pad_value": self.default_pad_value,
             "default_pad_label": self.default_pad_label,
-        }
+        })
         n = self._resolve_n(batch)
         if n is None:
             forward, field, displacement, has_geometry = self._sample_one(shape, affine)
@@ -185,7 +185,7 @@ class Spatial(SpatialTransform):
             # the (possibly random) target is resolved AFTER the geometry (spatial.py:474-481)
             params["target"] = _serialize_space(_resolve_target_space(self.target, batch, shape, affine))
             params["affine_matrix"] = None if forward is None else forward.tolist()
-            params["control_points"] = None if field is None else field.cpu().tolist()
+            params.set_lazy("control_points", None if field is None else field.detach().to(device="cpu", dtype=torch.float32))
             params["max_displacement"] = list(displacement) if displacement else None
             return params
 
@@ -198,13 +198,13 @@ class Spatial(SpatialTransform):
             forward, field, displacement, has_geometry = self._sample_one(shape, affine)
             any_geometry = any_geometry or has_geometry
             matrices.append(None if forward is None else forward.tolist())
-            fields.append(None if field is None else field.cpu().tolist())
+            fields.append(None if field is None else field.detach().to(device="cpu", dtype=torch.float32))
             displacements.append(list(displacement) if displacement else None)
         if any_geometry:
             _check_shared_space(images, shape, affine)
         params["target"] = _serialize_space(_resolve_target_space(self.target, batch, shape, affine))
         params["affine_matrix"] = matrices
-        params["control_points"] = fields
+        params.set_lazy("control_points", fields)  # nested lists only if somebody reads the history
         params["max_displacement"] = displacements
         self._tag_batched(params, batch, n, keep, ["affine_matrix", "control_points", "max_displacement"])
         return params
@@ -653,20 +653,44 @@ def _build_forward_affine(*, scales, degrees, translation, center, shape, affine
     return transform
 
 
+def _all_close(values, target: float) -> bool:
+    """``np.allclose(values, target)`` (rtol 1e-5, atol 1e-8) for a short tuple of Python floats."""
+    bound = 1e-8 + 1e-5 * abs(target)
+    return all(abs(v - target) <= bound for v in values)
+
+
+_BORDER_MASKS: dict[tuple, Tensor] = {}
+
+
+def _interior_mask(grid_shape, locked_borders: int) -> Tensor:
+    """``(ni, nj, nk, 1)`` bool: False on the *locked_borders* outer layers of the control grid."""
+    key = (tuple(grid_shape), locked_borders)
+    mask = _BORDER_MASKS.get(key)
+    if mask is None:
+        mask = torch.ones(*grid_shape, 1, dtype=torch.bool)
+        for border in range(locked_borders):
+            for dim in range(3):
+                index = [slice(None)] * 3
+                index[dim] = border
+                mask[tuple(index)] = False
+                index[dim] = -1 - border
+                mask[tuple(index)] = False
+        _BORDER_MASKS[key] = mask
+    return mask
+
+
 def _sample_control_points(grid_shape, max_displacement, locked_borders: int) -> Tensor:
-    """``U(-max, +max)`` per axis from ONE ``torch.rand(ni, nj, nk, 3)`` draw; outer layers zeroed."""
+    """``U(-max, +max)`` per axis from ONE ``torch.rand(ni, nj, nk, 3)`` draw; outer layers zeroed.
+
+    Same values as the reference's step-by-step version (``(u - 0.5) * 2`` is exact, so
+    one multiply by ``2 * max`` rounds once, like ``* max`` after it), built with three
+    tensor ops instead of ~25.
+    """
     field = torch.rand(*grid_shape, 3, dtype=torch.float32)
     field -= 0.5
-    field *= 2
-    for axis in range(3):
-        field[..., axis] *= max_displacement[axis]
-    for border in range(locked_borders):
-        for dim in range(3):
-            index = [slice(None)] * 3
-            index[dim] = border
-            field[tuple(index)] = 0
-            index[dim] = -1 - border
-            field[tuple(index)] = 0
+    field *= torch.tensor([2.0 * float(m) for m in max_displacement], dtype=torch.float32)
+    if locked_borders > 0:
+        field = torch.where(_interior_mask(grid_shape, locked_borders), field, torch.zeros((), dtype=torch.float32))
     return field
 
 
@@ -696,6 +720,8 @@ def _check_shared_space(images: dict[str, ImagesBatch], reference_shape, referen
         if shape != reference_shape:
             raise RuntimeError(f'Image "{name}" has shape {shape}, expected {reference_shape}')
         for affine in img_batch.affines:
+            if affine is reference_affine or torch.equal(affine.data, reference_affine.data):
+                continue
             if not torch.allclose(affine.data, reference_affine.data, rtol=1e-6, atol=1e-6):
                 raise RuntimeError(
                     "Spatial transforms with affine or elastic components require"
@@ -714,15 +740,16 @@ def _resolve_spatial_params(params: dict[str, Any]):
     def displacement_of(value):
         return None if value is None else (float(value[0]), float(value[1]), float(value[2]))
 
+    parked, raw_fields = params.raw("control_points") if isinstance(params, LazyParams) else (False, None)
     if "affine_matrix" not in (params.get("_batched_keys") or []):
         return (
             matrix_of(params["affine_matrix"]),
-            field_of(params["control_points"]),
+            raw_fields if parked else field_of(params["control_points"]),
             displacement_of(params["max_displacement"]),
             None,
         )
     matrices = [matrix_of(m) for m in params["affine_matrix"]]
-    fields = [field_of(c) for c in params["control_points"]]
+    fields = list(raw_fields) if parked else [field_of(c) for c in params["control_points"]]
     displacements = [displacement_of(d) for d in params["max_displacement"]]
     if all(m is None for m in matrices) and all(f is None for f in fields):
         return None, None, None, None
