@@ -283,7 +283,7 @@ def test_engine_rejects_cpu_tensors(hip):
 
 @pytest.mark.parametrize(
     "shape",
-    [(2, 2, 19, 23, 72), (1, 1, 70, 40, 64), (1, 1, 9, 50, 520), (1, 2, 37, 5, 256)],
+    [(2, 2, 19, 23, 72), (1, 1, 70, 40, 64), (1, 1, 9, 50, 520), (1, 2, 37, 5, 256), (1, 1, 16, 14, 12), (2, 1, 9, 33, 4)],
 )
 def test_separable_conv_float4_paths(oracle, hip, shape):
     """K % 4 == 0 float32: the marching / 16-byte kernels (several steps, segments and K tiles)."""

@@ -7,6 +7,8 @@
 //   tio_channel_min       (default_pad_value="minimum"; spatial.py:2054-2095)
 // All are HBM-bound elementwise / stencil passes: one read + one write of the
 // volume per op (the separable stencil: per active axis).  No MFMA.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.hpp"
@@ -42,6 +44,7 @@ struct ConvArgs {
   int orig_dtype;
   int last_pass;
   int tiles_a;  // tiles along the stencil axis (axes I, J) / row groups (axis K)
+  int radius_k;  // > 0: the J pass also applies the K taps to every row it produces (fused J+K)
 };
 
 template <int SRC_DT, int DST_DT>
@@ -155,6 +158,7 @@ constexpr int kConvMaxRadiusV4 = 16;  // (32 + 2*16) rows x 1 KiB = 64 KiB of LD
 
 constexpr int kConvStep = 16;  // output rows per marching step (axes I, J)
 
+template <bool FUSE_K>
 __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) {
   // axes I and J.  grid: x = K tiles (256 = 64 lanes x float4), y = segments along the axis, z = other axis * (B*C).
   // A block marches along the stencil axis with a ring of kConvStep + 2r + kConvStep rows in
@@ -165,6 +169,8 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   const int ring = 2 * kConvStep + 2 * r;
   float* s_taps = s_mem;                                                   // ntaps
   float4* s_ring = reinterpret_cast<float4*>(s_mem + ((ntaps + 3) & ~3));  // ring x 64 float4
+  // fused J+K: every wave owns one staged row (8 + 256 + 8 floats) behind the ring
+  float* s_krow = reinterpret_cast<float*>(s_ring + ring * 64) + (threadIdx.x >> 6) * 272;
   const int n_other = a.axis == 0 ? a.J : a.I;
   const int other = blockIdx.z % n_other;
   const int bc = blockIdx.z / n_other;
@@ -197,7 +203,8 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
                    static_cast<int64_t>(a.axis) * a.tap_stride;
   typedef __attribute__((address_space(4))) const float* const_float_ptr;  // taps are read-only for the whole launch
   const_float_ptr tc = (const_float_ptr)(t);
-  (void)s_taps;
+  const_float_ptr tk = (const_float_ptr)(a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride);
+  (void)s_taps; (void)tk; (void)s_krow;
   constexpr int RW = kConvStep / (kBlock / 64);  // rows per wave per step (4)
   // logical row index q counts from p_begin - r; ring slot = q mod ring (tracked incrementally)
   // prologue: rows q in [0, kConvStep + 2r) for the first step
@@ -238,6 +245,42 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
             acc.z = __fadd_rn(acc.z, __fmul_rn(w, v.z));
             acc.w = __fadd_rn(acc.w, __fmul_rn(w, v.w));
             slot = slot + 1 == ring ? 0 : slot + 1;
+          }
+          if constexpr (FUSE_K) {
+            // the row this wave just produced (its 256 K positions are spread over the 64 lanes)
+            // goes through the register-window K filter of conv_k_v4_kernel before it is stored:
+            // the float32 rounding between the J and the K pass is kept, only the HBM round trip goes
+            const int rk = a.radius_k;
+            const float edge_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc.x), 0));
+            const float edge_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc.w), a.K / 4 - 1));
+            *reinterpret_cast<float4*>(s_krow + 8 + 4 * lane) = acc;
+            for (int h = lane; h < 2 * rk; h += a.K / 4) {  // only the K/4 lanes that own data are active here
+              if (h < rk) s_krow[8 - rk + h] = edge_l;         // replicate padding, left
+              else s_krow[8 + a.K + (h - rk)] = edge_r;        // right
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float4* rv = reinterpret_cast<const float4*>(s_krow + 8) + lane;
+            float w[20];
+#pragma unroll
+            for (int d = 0; d < 5; d++) {
+              const float4 c = rv[d - 2];
+              w[4 * d] = c.x; w[4 * d + 1] = c.y; w[4 * d + 2] = c.z; w[4 * d + 3] = c.w;
+            }
+            float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int jj = 0; jj < 17; jj++) {
+              if (jj >= 8 - rk && jj <= 8 + rk) {
+                const float tw = tk[jj - (8 - rk)];
+                out.x = __fadd_rn(out.x, __fmul_rn(tw, w[jj]));
+                out.y = __fadd_rn(out.y, __fmul_rn(tw, w[jj + 1]));
+                out.z = __fadd_rn(out.z, __fmul_rn(tw, w[jj + 2]));
+                out.w = __fadd_rn(out.w, __fmul_rn(tw, w[jj + 3]));
+              }
+            }
+            acc = out;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
           }
           *reinterpret_cast<float4*>(dst + line + static_cast<int64_t>(p0 + o) * stride) = acc;
         }
@@ -402,9 +445,14 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
   for (int ax = 0; ax < 3; ax++)
     if (radius[ax] > 0) active[n_active++] = ax;
   const void* src = x;
+  // J and K can share one pass when the whole K row sits in one 256-wide tile and both radii
+  // are small: the J kernel filters every row it produces along K before storing it
+  const bool fuse_jk = DT == TIO_F32 && radius[1] > 0 && radius[2] > 0 && radius[1] <= kConvMaxRadiusV4 && radius[2] <= 8 &&
+                       shape[2] <= 256 && (shape[2] & 3) == 0 && getenv("TIO_CONV_NO_FUSE") == nullptr;
   for (int s = 0; s < n_active; s++) {
     const int axis = active[s];
-    const bool first = s == 0, last = s == n_active - 1;
+    if (axis == 2 && fuse_jk) break;  // done by the J pass
+    const bool first = s == 0, last = s == n_active - 1 || (axis == 1 && fuse_jk);
     void* dst = last ? y : static_cast<void*>((s % 2 == 0) ? tmp0 : tmp1);
     ConvArgs a{};
     a.src = src; a.dst = dst; a.x_orig = x; a.taps = taps; a.skip = skip;
@@ -447,12 +495,15 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
         segs = (n + seg_len - 1) / seg_len;
         grid.x = static_cast<unsigned>((shape[2] + 255) / 256);
         grid.y = static_cast<unsigned>(segs);
-        lds = (((ntaps + 3) & ~3) + (2 * kConvStep + 2 * radius[axis]) * 256) * sizeof(float);
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_line_v4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds)) != hipSuccess)
+        const bool fused = axis == 1 && fuse_jk;
+        a.radius_k = fused ? radius[2] : 0;
+        lds = (((ntaps + 3) & ~3) + (2 * kConvStep + 2 * radius[axis]) * 256 + (fused ? 4 * 272 : 0)) * sizeof(float);
+        const void* fn = fused ? reinterpret_cast<const void*>(conv_line_v4_kernel<true>)
+                               : reinterpret_cast<const void*>(conv_line_v4_kernel<false>);
+        if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
           return fail(TIO_ERR_LAUNCH, "tio_separable_conv3d: cannot reserve %zu bytes of LDS", lds);
-        hipLaunchKernelGGL(conv_line_v4_kernel, grid, dim3(kBlock), lds, stream, a);
+        if (fused) hipLaunchKernelGGL(conv_line_v4_kernel<true>, grid, dim3(kBlock), lds, stream, a);
+        else hipLaunchKernelGGL(conv_line_v4_kernel<false>, grid, dim3(kBlock), lds, stream, a);
       }
       src = dst;
       continue;
