@@ -250,10 +250,13 @@ __device__ __forceinline__ TileBox make_box(const int (&r)[6], const ResampleArg
                 (zmax + 1 <= a.K - 1) & !weird;
   // every tap of every voxel out of bounds (second taps < 0 or first taps > S-1 on some axis)
   bx.outside = ((xmax + 1 < 0) | (xmin > a.I - 1) | (ymax + 1 < 0) | (ymin > a.J - 1) | (zmax + 1 < 0) | (zmin > a.K - 1)) & !weird;
-  // staged box: taps clamped to [-1, S] (one zero layer stands for everything outside)
-  bx.bx0 = max(xmin, -1); bx.bx1 = min(xmax + 1, a.I);
-  bx.by0 = max(ymin, -1); bx.by1 = min(ymax + 1, a.J);
-  bx.zlo = max(zmin, -1); bx.zhi = min(zmax + 1, a.K);
+  // staged box: every tap of every voxel, NOT clipped to the volume — cells outside are
+  // staged as zeros, so boundary bricks address the brick exactly like interior ones (no
+  // per-tap clamping; adding +0 terms never changes ATen's partial sums).  A box whose
+  // tracked range hit the +-kTileFar clamp is either `outside` or wider than 4096 → !fits.
+  bx.bx0 = xmin; bx.bx1 = xmax + 1;
+  bx.by0 = ymin; bx.by1 = ymax + 1;
+  bx.zlo = zmin; bx.zhi = zmax + 1;
   bx.za = bx.zlo & ~3;
   bx.Lx = bx.bx1 - bx.bx0 + 1; bx.Ly = bx.by1 - bx.by0 + 1; bx.Lz = ((bx.zhi + 4) & ~3) - bx.za;
   bx.fits = !weird && (static_cast<int64_t>(bx.Lx) * bx.Ly * bx.Lz <= static_cast<int64_t>(a.tile_cap)) && (bx.Lx <= 4096) &&
@@ -263,9 +266,11 @@ __device__ __forceinline__ TileBox make_box(const int (&r)[6], const ResampleArg
 
 // floor + clamp (coordinates may be astronomically far away) of a float bound pair →
 // the two ints the reduction maximises: -min first tap (≥ -2) and max first tap (≤ S)
+constexpr float kTileFar = 8192.0f;  // first taps are tracked in [-kTileFar, S + kTileFar]; beyond → never "fits"
+
 __device__ __forceinline__ void bound_ints(float lo, float hi, float cap, int& neg_lo, int& pos_hi) {
-  neg_lo = -static_cast<int>(fminf(fmaxf(floorf(lo), -2.0f), cap));
-  pos_hi = static_cast<int>(fminf(fmaxf(floorf(hi), -2.0f), cap));
+  neg_lo = -static_cast<int>(fminf(fmaxf(floorf(lo), -kTileFar), cap + kTileFar));
+  pos_hi = static_cast<int>(fminf(fmaxf(floorf(hi), -kTileFar), cap + kTileFar));
 }
 
 __device__ __forceinline__ void store_box(int* s, const TileBox& b) {
@@ -450,63 +455,33 @@ __device__ __forceinline__ float tile_finish(const TapSet& ts) {
   return val;
 }
 
-// Boundary brick: tap indices are clamped into the staged box — anything clamped lands
-// on a zero cell (the box reaches the one-voxel apron wherever a tap can leave the
-// volume), and adding +0 terms never changes ATen's partial sums.  The in-bounds weight
-// mask is only needed when a fill value is present.
-template <bool LAUNDER>
-__device__ __forceinline__ float tile_sample_boundary(const float* __restrict__ tile, float x, float y, float z,
-                                                      const TileBox& bx, float hx, float hy, float hz, bool has_fill,
-                                                      float fillv, int dep) {
-  if constexpr (LAUNDER) TIO_OPAQUE3(x, y, z, dep);
-  const int sY = bx.Lz, sX = bx.Ly * bx.Lz;
+// In-bounds weight mask of ATen's fill logic (spatial.py:1719-1728): the trilinear weights of
+// the taps that lie inside the volume, accumulated in ATen's tap order.  Only needed in
+// bricks that touch the outside AND have a fill value.
+__device__ __forceinline__ float tile_mask(const TapSet& ts, float x, float y, float z, float hx, float hy, float hz) {
+  // first-tap indices from the coordinate the weights were taken from: x0 = floor(x)
   const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
   const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
-  const float wx0 = x1 - x, wx1 = x - x0, wy0 = y1 - y, wy1 = y - y0, wz0 = z1 - z, wz1 = z - z0;
+  const bool ox0 = (x0 >= 0.0f) & (x0 <= hx), ox1 = (x1 >= 0.0f) & (x1 <= hx);
+  const bool oy0 = (y0 >= 0.0f) & (y0 <= hy), oy1 = (y1 >= 0.0f) & (y1 <= hy);
+  const bool oz0 = (z0 >= 0.0f) & (z0 <= hz), oz1 = (z1 >= 0.0f) & (z1 <= hz);
   float w[8];
-  w[0] = __fmul_rn(__fmul_rn(wx0, wy0), wz0);
-  w[1] = __fmul_rn(__fmul_rn(wx1, wy0), wz0);
-  w[2] = __fmul_rn(__fmul_rn(wx0, wy1), wz0);
-  w[3] = __fmul_rn(__fmul_rn(wx1, wy1), wz0);
-  w[4] = __fmul_rn(__fmul_rn(wx0, wy0), wz1);
-  w[5] = __fmul_rn(__fmul_rn(wx1, wy0), wz1);
-  w[6] = __fmul_rn(__fmul_rn(wx0, wy1), wz1);
-  w[7] = __fmul_rn(__fmul_rn(wx1, wy1), wz1);
-  const float bxl = static_cast<float>(bx.bx0), bxh = static_cast<float>(bx.bx1);
-  const float byl = static_cast<float>(bx.by0), byh = static_cast<float>(bx.by1);
-  const float bzl = static_cast<float>(bx.zlo), bzh = static_cast<float>(bx.zhi);
-  const int ax0 = (static_cast<int>(fminf(fmaxf(x0, bxl), bxh)) - bx.bx0) * sX;
-  const int ax1 = (static_cast<int>(fminf(fmaxf(x1, bxl), bxh)) - bx.bx0) * sX;
-  const int ay0 = (static_cast<int>(fminf(fmaxf(y0, byl), byh)) - bx.by0) * sY;
-  const int ay1 = (static_cast<int>(fminf(fmaxf(y1, byl), byh)) - bx.by0) * sY;
-  const int az0 = static_cast<int>(fminf(fmaxf(z0, bzl), bzh)) - bx.za;
-  const int az1 = static_cast<int>(fminf(fmaxf(z1, bzl), bzh)) - bx.za;
-  const float v0 = tile[ax0 + ay0 + az0], v1 = tile[ax1 + ay0 + az0];
-  const float v2 = tile[ax0 + ay1 + az0], v3 = tile[ax1 + ay1 + az0];
-  const float v4 = tile[ax0 + ay0 + az1], v5 = tile[ax1 + ay0 + az1];
-  const float v6 = tile[ax0 + ay1 + az1], v7 = tile[ax1 + ay1 + az1];
-  float val = __fadd_rn(0.0f, __fmul_rn(v0, w[0]));
-  val = __fadd_rn(val, __fmul_rn(v1, w[1]));
-  val = __fadd_rn(val, __fmul_rn(v2, w[2]));
-  val = __fadd_rn(val, __fmul_rn(v3, w[3]));
-  val = __fadd_rn(val, __fmul_rn(v4, w[4]));
-  val = __fadd_rn(val, __fmul_rn(v5, w[5]));
-  val = __fadd_rn(val, __fmul_rn(v6, w[6]));
-  val = __fadd_rn(val, __fmul_rn(v7, w[7]));
-  if (has_fill) {
-    const bool ox0 = (x0 >= 0.0f) & (x0 <= hx), ox1 = (x1 >= 0.0f) & (x1 <= hx);
-    const bool oy0 = (y0 >= 0.0f) & (y0 <= hy), oy1 = (y1 >= 0.0f) & (y1 <= hy);
-    const bool oz0 = (z0 >= 0.0f) & (z0 <= hz), oz1 = (z1 >= 0.0f) & (z1 <= hz);
-    float mask = 0.0f;
+  w[0] = __fmul_rn(__fmul_rn(ts.wx0, ts.wy0), ts.wz0);
+  w[1] = __fmul_rn(__fmul_rn(ts.wx1, ts.wy0), ts.wz0);
+  w[2] = __fmul_rn(__fmul_rn(ts.wx0, ts.wy1), ts.wz0);
+  w[3] = __fmul_rn(__fmul_rn(ts.wx1, ts.wy1), ts.wz0);
+  w[4] = __fmul_rn(__fmul_rn(ts.wx0, ts.wy0), ts.wz1);
+  w[5] = __fmul_rn(__fmul_rn(ts.wx1, ts.wy0), ts.wz1);
+  w[6] = __fmul_rn(__fmul_rn(ts.wx0, ts.wy1), ts.wz1);
+  w[7] = __fmul_rn(__fmul_rn(ts.wx1, ts.wy1), ts.wz1);
+  float mask = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const bool ok = ((k & 1) ? ox1 : ox0) & ((k & 2) ? oy1 : oy0) & ((k & 4) ? oz1 : oz0);
-      const float next = __fadd_rn(mask, w[k]);  // same order as ATen's accumulation
-      mask = ok ? next : mask;
-    }
-    val = (mask > 0.5f) ? val : fillv;
+  for (int k = 0; k < 8; k++) {
+    const bool ok = ((k & 1) ? ox1 : ox0) & ((k & 2) ? oy1 : oy0) & ((k & 4) ? oz1 : oz0);
+    const float next = __fadd_rn(mask, w[k]);  // same order as ATen's accumulation
+    mask = ok ? next : mask;
   }
-  return val;
+  return mask;
 }
 
 // ---- one channel of one pass: stage the box, sample the pass's quarters, store ----------
@@ -585,10 +560,17 @@ __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArg
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
+      // brick touching the outside: same addressing (the box holds zeros there); the mask
+      // decides between the sample and the fill value where one is configured
 #pragma unroll
       for (int u = 0; u < QT; u++) {
         const int t = q * QT + u;
-        const float val = tile_sample_boundary<LAUNDER>(s_tile, X[t], Y[t], Z[t], bx, hx, hy, hz, has_fill, fillv, c);
+        TapSet ts;
+        float x = X[t], y = Y[t], z = Z[t];
+        if constexpr (LAUNDER) TIO_OPAQUE3(x, y, z, c);
+        tile_issue_interior<false>(ts, x, y, z, ta, c);
+        float val = tile_finish(ts);
+        if (has_fill) val = (tile_mask(ts, x, y, z, hx, hy, hz) > 0.5f) ? val : fillv;
         if (full || (col_active && t < i_count)) store_at<DTMODE>(out_t, g.dtype, urow, val);
         out_t += slab_b;
         if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
