@@ -166,7 +166,8 @@ static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
 
 struct Paths { const char* name; const char* path; const char* variant; };
 static const Paths kPaths[] = {
-    {"gather", "gather", "0"}, {"tile16x16x16", "tile", "0"}, {"tile16x8x32", "tile", "1"}, {"tile8x8x32", "tile", "2"}};
+    {"gather", "gather", "0"}, {"tile16x16x16", "tile", "0"}, {"tile16x8x32", "tile", "1"}, {"tile8x8x32", "tile", "2"},
+    {"tile8x16x32w8", "tile", "3"}, {"tile8x16x16", "tile", "4"}};
 
 static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
   if (!g_case_filter.empty() && cs.name.find(g_case_filter) == std::string::npos) return 0;

@@ -499,7 +499,8 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     a.cp_lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? ((n_cp + 3) & ~3) : 0;
     // default brick budget: whatever lets kTileBlocksPerCU blocks share the CU's 160 KiB
     // (minus 2 KiB: the hardware allocates LDS in granules, an exact third does not fit three times)
-    if (cap <= 0) cap = kLdsFloatsPerCU / kTileBlocksPerCU - 512 - a.cp_lds - kTileRedInts;
+    const int bpc = variant == 3 ? 2 : ((variant == 2 || variant == 4) ? 4 : kTileBlocksPerCU);  // resident blocks the variant is built for
+    if (cap <= 0) cap = kLdsFloatsPerCU / bpc - 512 - a.cp_lds - kTileRedInts;
     const int max_cap = kLdsFloatsPerCU - a.cp_lds - kTileRedInts;
     a.tile_cap = cap < kTileMinCap ? kTileMinCap : (cap > max_cap ? max_cap : cap);
     const size_t lds = static_cast<size_t>(a.cp_lds + kTileRedInts + a.tile_cap) * sizeof(float);
@@ -546,6 +547,8 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     switch (variant) {
       case 1: TIO_TILE_SHAPE_F32(16, 8, 32, 3) break;
       case 2: TIO_TILE_SHAPE_F32(8, 8, 32, 4) break;
+      case 3: TIO_TILE_SHAPE_F32(8, 16, 32, 2) break;   /* 512 threads, 2 blocks per CU */
+      case 4: TIO_TILE_SHAPE_F32(8, 16, 16, 4) break;
       default: TIO_TILE_SHAPE(16, 16, 16, 3) break;
     }
 #undef TIO_TILE_SHAPE_F32

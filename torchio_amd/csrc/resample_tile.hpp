@@ -36,8 +36,8 @@ namespace tio {
 // loop-varying scalar so it cannot leave the loop it is written in.
 #define TIO_OPAQUE3(A, B, C, DEP) asm("" : "+v"(A), "+v"(B), "+v"(C) : "s"(DEP))
 
-constexpr int kTileRedInts = 320;    // LDS ints: 7 reduction slots x 32, then 4 pass boxes x 16
-constexpr int kTileBoxBase = 224;
+constexpr int kTileRedInts = 512;    // LDS ints: 7 reduction slots x (8 ints x <= 8 waves), then 4 pass boxes x 16
+constexpr int kTileBoxBase = 448;
 constexpr int kTileStashPlanes = 4;
 #ifndef TILE_GROUP
 #define TILE_GROUP 4
@@ -64,7 +64,7 @@ template <int NW>
 __device__ __forceinline__ void block_max6(int (&r)[6], int* s_red, int slot, int wave, int lane) {
 #pragma unroll
   for (int q = 0; q < 6; q++) r[q] = wave_max_i32(r[q]);
-  int* s = s_red + slot * 32;
+  int* s = s_red + slot * (NW * 8);
   if (lane == 0) {
 #pragma unroll
     for (int q = 0; q < 6; q++) s[wave * 8 + q] = r[q];
@@ -676,6 +676,10 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
   const float hx = a.size_m1[0], hy = a.size_m1[1], hz = a.size_m1[2];
   const float ci0 = static_cast<float>(i_begin), ci_last = static_cast<float>(i_last);
   const bool short_div = a.short_div != 0;
+  // Identity mapping (ElasticDeformation alone, Resample onto the same grid): the chain
+  // c*1 + 0 + 0 + 0 returns its argument bit for bit (c >= 0, so no -0 subtlety), skip it.
+  const bool ident = (m00 == 1.0f) & (m01 == 0.0f) & (m02 == 0.0f) & (m03 == 0.0f) & (m10 == 0.0f) & (m11 == 1.0f) &
+                     (m12 == 0.0f) & (m13 == 0.0f) & (m20 == 0.0f) & (m21 == 0.0f) & (m22 == 1.0f) & (m23 == 0.0f);
 #define TIO_AFFINE_ROW(M0, M1, M2, M3, A, B, C) \
   __builtin_fmaf(1.0f, M3, __builtin_fmaf(C, M2, __builtin_fmaf(B, M1, __fmul_rn(A, M0))))
 #define TIO_FINISH_COORD(T, DI, DJ, DK, HAS_D)                                                  \
@@ -689,7 +693,11 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
         q_j = exact_div(q_j, a.sp[1], a.rsp[1]);                                                \
         q_k = exact_div(q_k, a.sp[2], a.rsp[2]);                                                \
       }                                                                                         \
-      if (a.affine_first) {                                                                     \
+      if (ident) { /* c + d either way round */                                                 \
+        vi = __fadd_rn(ci, q_i);                                                                \
+        vj = __fadd_rn(cj, q_j);                                                                \
+        vk = __fadd_rn(ck, q_k);                                                                \
+      } else if (a.affine_first) {                                                              \
         vi = __fadd_rn(TIO_AFFINE_ROW(m00, m01, m02, m03, ci, cj, ck), q_i);                    \
         vj = __fadd_rn(TIO_AFFINE_ROW(m10, m11, m12, m13, ci, cj, ck), q_j);                    \
         vk = __fadd_rn(TIO_AFFINE_ROW(m20, m21, m22, m23, ci, cj, ck), q_k);                    \
