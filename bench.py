@@ -112,6 +112,31 @@ def cpu_baseline(size: int, n_volumes: int, seed: int, budget_s: float = 12.0) -
     }
 
 
+def aten_baseline(size: int, batch: int, device, steps: int = 3) -> dict:
+    """Stock ATen ops on the same GPU: the reference's op sequence restated in tests/aten_pipeline.py."""
+    import aten_pipeline  # noqa: PLC0415
+
+    rng = torch.Generator()
+    data = torch.rand(batch, 1, size, size, size, device=device)
+    # Steady state: the same parameter draw every step, so MIOpen's per-shape selection of the
+    # grouped conv3d (which otherwise costs seconds whenever a new blur radius shows up) is
+    # paid in the warm-up and not timed.
+    aten_pipeline.compose_step(data, rng.manual_seed(7))
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for _ in range(steps):
+        aten_pipeline.compose_step(data, rng.manual_seed(7))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - start
+    return {
+        "value": steps * batch / elapsed,
+        "unit": "volumes/s",
+        "kind": "stock ATen (grid_sample x2 per resampling, interpolate, conv3d, randn) on the same MI355X, conv shapes warm",
+        "sample": f"{steps} x {batch} x 1x{size}^3 f32",
+        "peak_memory_GiB": torch.cuda.max_memory_allocated() / 2**30,
+    }
+
+
 def load_traffic() -> float | None:
     """Per-launch HBM bytes of the dominant kernel from the committed PMC summary, if any."""
     path = os.path.join(ROOT, "profiles", "resample_traffic.json")
@@ -132,6 +157,7 @@ def main() -> None:
     parser.add_argument("--noise-rng", choices=["reference", "philox"], default="philox")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-volumes", type=int, default=8)
+    parser.add_argument("--aten-baseline", action="store_true", help="also time the stock-ATen restatement of the pipeline")
     args = parser.parse_args()
 
     info = tdist.init_process_group()
@@ -212,6 +238,11 @@ def main() -> None:
                 "launches_timed": len(timer.pairs),
             },
         }
+        if args.gpus == 1 and args.aten_baseline:
+            out = None
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            line["aten_baseline"] = aten_baseline(args.size, min(args.batch, 2), device)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_volumes, 99)
         print(json.dumps(line), flush=True)
