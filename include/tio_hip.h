@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 1
+#define TIO_ABI_VERSION 2
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -39,7 +39,8 @@ typedef enum tio_status {
   TIO_ERR_INVALID_ARGUMENT = -1,
   TIO_ERR_UNSUPPORTED_DTYPE = -2,
   TIO_ERR_LAUNCH = -3,
-  TIO_ERR_NO_DEVICE = -4
+  TIO_ERR_NO_DEVICE = -4,
+  TIO_ERR_UNSUPPORTED_CONFIG = -5 /* valid arguments, but this fused form is not available for them: nothing was launched */
 } tio_status;
 
 /* Element types of image tensors (torch dtype ↔ code is fixed here). */
@@ -153,6 +154,29 @@ int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t dtype,
                          const float* taps_dev, int32_t taps_batched,
                          int32_t tap_stride, const int32_t radius[3],
                          const uint8_t* skip_dev, void* stream);
+
+/*
+ * Blur with its neighbours folded in: y = Noise(Blur(BiasField(x))) in the separable passes
+ * of tio_separable_conv3d — the bias field multiplies every row on its way into the first
+ * (I) pass, the noise is added to every row the last (fused J+K) pass stores, so the two
+ * elementwise transforms cost no extra trip through HBM.  Values are bit-identical to
+ * tio_bias_field_apply -> tio_separable_conv3d -> tio_add_noise (same float32 operations in
+ * the same order; tests compare the two).  Replaces, for a Compose that holds them back to
+ * back, bias_field.py:99-132 + blur.py:76-252 + noise.py:98-123.
+ *   bias_coarse_dev == NULL: no bias stage;  noise_on == 0: no noise stage (fast-mode
+ *   Philox draws only, as tio_add_noise with base1_dev == NULL, not rician);
+ *   tmp: scratch of 2 x size(y) floats.
+ * Returns TIO_ERR_UNSUPPORTED_CONFIG (and launches nothing) unless: float32, 16-byte
+ * aligned, all three radii in 1..16 (K: 1..8), K <= 256 and K % 4 == 0 — the caller then
+ * runs the three entry points one after the other.
+ */
+int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, int32_t batch,
+                   int32_t channels, const int32_t shape[3], const float* taps_dev,
+                   int32_t taps_batched, int32_t tap_stride, const int32_t radius[3],
+                   const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],
+                   int32_t noise_on, float noise_mean, float noise_std,
+                   const float* noise_mean_dev, const float* noise_std_dev,
+                   int32_t noise_batched, uint64_t philox_seed, void* stream);
 
 /*
  * BiasField: y = x * exp(trilinear_upsample(coarse))   (or x / ... when divide)

@@ -8,11 +8,12 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_IMAGES = 8
 
 # tio_status
 OK = 0
+UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing was launched
 
 # tio_dtype (values fixed by include/tio_hip.h)
 F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
@@ -88,6 +89,12 @@ PROTOTYPES = {
 HIP_ONLY_PROTOTYPES = {
     "last_error": (C.c_char_p, []),
     "device_count": (C.c_int, []),
+    "blur_fused": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, C.c_int32,
+         _I32x3, C.c_void_p, _I32x3, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64,
+         C.c_void_p],
+    ),
 }
 
 #: every symbol include/tio_hip.h declares for libtio_hip.so

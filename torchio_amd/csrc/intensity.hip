@@ -18,6 +18,42 @@ namespace tio {
 constexpr int kBlock = 256;
 
 // =============================================================================
+// Philox4x32-10 + Box-Muller (fast noise mode; definition in oracle/tio_oracle.c)
+// =============================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int round = 0; round < 10; round++) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c[0];
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c[2];
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = static_cast<uint32_t>(p0);
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__device__ __forceinline__ void philox_normal4(uint64_t seed, int stream_id, uint64_t q, float z[4]) {
+  uint32_t c[4] = {static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), static_cast<uint32_t>(stream_id), 0u};
+  philox4x32_10(c, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float u1 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h] >> 8), 0.5f), 1.0f / 16777216.0f);
+    const float u2 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h + 1] >> 8), 0.5f), 1.0f / 16777216.0f);
+    const float radius = sqrtf(__fmul_rn(-2.0f, logf(u1)));
+    // cos / sin of 2 pi u2: the hardware units take their argument in revolutions, so u2 in
+    // (0, 1) needs no range reduction (v_cos_f32 / v_sin_f32; within 2e-5 of libm on z,
+    // tests/test_gpu_ops_parity.py::test_philox_stream_and_fast_noise)
+    const float cs = __builtin_amdgcn_cosf(u2);
+    const float sn = __builtin_amdgcn_sinf(u2);
+    z[2 * h] = __fmul_rn(radius, cs);
+    z[2 * h + 1] = __fmul_rn(radius, sn);
+  }
+}
+
+// =============================================================================
 // Separable cross-correlation with replicate padding
 // =============================================================================
 // One pass = one axis.  Lanes always run along K (contiguous), so every global
@@ -45,6 +81,15 @@ struct ConvArgs {
   int last_pass;
   int tiles_a;  // tiles along the stencil axis (axes I, J) / row groups (axis K)
   int radius_k;  // > 0: the J pass also applies the K taps to every row it produces (fused J+K)
+  // tio_blur_fused: BiasField folded into the loads of the I pass, Noise into the stores of the last pass
+  const float* bias_coarse;          // (B, C, ci, cj, ck) or nullptr
+  int bias_ci, bias_cj, bias_ck;
+  float bias_si, bias_sj, bias_sk;   // ATen lerp scales of the coarse grid
+  int noise_on, noise_batched;
+  float noise_mean, noise_std;
+  const float* noise_mean_b;
+  const float* noise_std_b;
+  uint64_t noise_seed;
 };
 
 template <int SRC_DT, int DST_DT>
@@ -158,7 +203,7 @@ constexpr int kConvMaxRadiusV4 = 16;  // (32 + 2*16) rows x 1 KiB = 64 KiB of LD
 
 constexpr int kConvStep = 16;  // output rows per marching step (axes I, J)
 
-template <bool FUSE_K>
+template <bool FUSE_K, bool PRE_BIAS, bool POST_NOISE>
 __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) {
   // axes I and J.  grid: x = K tiles (256 = 64 lanes x float4), y = segments along the axis, z = other axis * (B*C).
   // A block marches along the stencil axis with a ring of kConvStep + 2r + kConvStep rows in
@@ -206,12 +251,63 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   const_float_ptr tk = (const_float_ptr)(a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride);
   (void)s_taps; (void)tk; (void)s_krow;
   constexpr int RW = kConvStep / (kBlock / 64);  // rows per wave per step (4)
+  // PRE_BIAS (I pass of tio_blur_fused): every row is multiplied by exp(trilinear(coarse)) on its
+  // way into the ring — the arithmetic of bias_kernel (K- and J-lerps of a coarse plane are
+  // invariants of the lane's four k positions, redone only when the row enters a new cell)
+  Lerp1D b_lk[4];
+  Lerp1D b_lj{0, 0, 1.0f, 0.0f};
+  float b_p0[4] = {0.f, 0.f, 0.f, 0.f}, b_p1[4] = {0.f, 0.f, 0.f, 0.f};
+  int b_cur0 = -1, b_cur1 = -1;
+  const float* b_fg = nullptr;
+  if constexpr (PRE_BIAS) {
+    b_fg = a.bias_coarse + static_cast<int64_t>(bc) * (a.bias_ci * a.bias_cj * a.bias_ck);
+    b_lj = lerp_index(other, a.bias_cj, a.J, a.bias_sj);
+#pragma unroll
+    for (int e = 0; e < 4; e++) b_lk[e] = lerp_index(min(k + e, a.K - 1), a.bias_ck, a.K, a.bias_sk);
+  }
+  auto bias_row = [&](float4 v, int pos) -> float4 {
+    if constexpr (PRE_BIAS) {
+      const Lerp1D li = lerp_index(pos, a.bias_ci, a.I, a.bias_si);
+      const int s_i = a.bias_cj * a.bias_ck, s_j = a.bias_ck;
+      auto plane = [&](int ii, float (&out)[4]) {
+        const float* r0 = b_fg + ii * s_i + b_lj.i0 * s_j;
+        const float* r1 = b_fg + ii * s_i + b_lj.i1 * s_j;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          out[e] = lerp2(lerp2(r0[b_lk[e].i0], b_lk[e].l0, r0[b_lk[e].i1], b_lk[e].l1), b_lj.l0,
+                         lerp2(r1[b_lk[e].i0], b_lk[e].l0, r1[b_lk[e].i1], b_lk[e].l1), b_lj.l1);
+      };
+      if (li.i0 != b_cur0) {
+        if (li.i0 == b_cur1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) b_p0[e] = b_p1[e];
+        } else {
+          plane(li.i0, b_p0);
+        }
+        b_cur0 = li.i0;
+      }
+      if (li.i1 != b_cur1) {
+        if (li.i1 == b_cur0) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) b_p1[e] = b_p0[e];
+        } else {
+          plane(li.i1, b_p1);
+        }
+        b_cur1 = li.i1;
+      }
+      v.x = __fmul_rn(v.x, expf(lerp2(b_p0[0], li.l0, b_p1[0], li.l1)));  // bias_field.py:341, :130
+      v.y = __fmul_rn(v.y, expf(lerp2(b_p0[1], li.l0, b_p1[1], li.l1)));
+      v.z = __fmul_rn(v.z, expf(lerp2(b_p0[2], li.l0, b_p1[2], li.l1)));
+      v.w = __fmul_rn(v.w, expf(lerp2(b_p0[3], li.l0, b_p1[3], li.l1)));
+    }
+    return v;
+  };
   // logical row index q counts from p_begin - r; ring slot = q mod ring (tracked incrementally)
   // prologue: rows q in [0, kConvStep + 2r) for the first step
   if (active) {
     for (int q = wave; q < kConvStep + 2 * r; q += kBlock / 64) {
       const int pos = min(max(p_begin - r + q, 0), n - 1);  // replicate padding == clamp
-      s_ring[q * 64 + lane] = *reinterpret_cast<const float4*>(src + line + static_cast<int64_t>(pos) * stride);
+      s_ring[q * 64 + lane] = bias_row(*reinterpret_cast<const float4*>(src + line + static_cast<int64_t>(pos) * stride), pos);
     }
   }
   __syncthreads();
@@ -281,6 +377,19 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
             acc = out;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (POST_NOISE) {
+              // the arithmetic of noise_kernel's 16-byte path: same Philox block (global element
+              // index >> 2), same mean + std * z, same add
+              const int64_t e0 = line + static_cast<int64_t>(p0 + o) * stride;  // element index of acc.x in the tensor
+              float z[4];
+              philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
+              const float mu = a.noise_batched ? a.noise_mean_b[b] : a.noise_mean;
+              const float sd = a.noise_batched ? a.noise_std_b[b] : a.noise_std;
+              acc.x = __fadd_rn(acc.x, __fadd_rn(mu, __fmul_rn(sd, z[0])));
+              acc.y = __fadd_rn(acc.y, __fadd_rn(mu, __fmul_rn(sd, z[1])));
+              acc.z = __fadd_rn(acc.z, __fadd_rn(mu, __fmul_rn(sd, z[2])));
+              acc.w = __fadd_rn(acc.w, __fadd_rn(mu, __fmul_rn(sd, z[3])));
+            }
           }
           *reinterpret_cast<float4*>(dst + line + static_cast<int64_t>(p0 + o) * stride) = acc;
         }
@@ -294,7 +403,12 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
           int slot = slot0 + kConvStep + 2 * r + wave * RW + u;
           if (slot >= ring) slot -= ring;
           if (slot >= ring) slot -= ring;
-          *reinterpret_cast<v4f*>(&s_ring[slot * 64 + lane]) = pre1[u];
+          if constexpr (PRE_BIAS) {
+            const int pos = min(max(p0 + kConvStep + r + wave * RW + u, 0), n - 1);
+            s_ring[slot * 64 + lane] = bias_row(make_float4(pre1[u].x, pre1[u].y, pre1[u].z, pre1[u].w), pos);
+          } else {
+            *reinterpret_cast<v4f*>(&s_ring[slot * 64 + lane]) = pre1[u];
+          }
         }
       }
 #pragma unroll
@@ -437,10 +551,21 @@ __global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
   }
 }
 
+struct ConvFuse {  // optional pointwise stages of tio_blur_fused
+  const float* bias_coarse = nullptr;
+  int bias_shape[3] = {0, 0, 0};
+  int noise_on = 0, noise_batched = 0;
+  float noise_mean = 0.0f, noise_std = 0.0f;
+  const float* noise_mean_b = nullptr;
+  const float* noise_std_b = nullptr;
+  uint64_t noise_seed = 0;
+  bool any() const { return bias_coarse != nullptr || noise_on != 0; }
+};
+
 template <int DT>
 static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t batch, int32_t channels,
                        const int32_t shape[3], const float* taps, int taps_batched, int tap_stride,
-                       const int32_t radius[3], const uint8_t* skip, hipStream_t stream) {
+                       const int32_t radius[3], const uint8_t* skip, hipStream_t stream, const ConvFuse& fuse = ConvFuse()) {
   int active[3], n_active = 0;
   for (int ax = 0; ax < 3; ax++)
     if (radius[ax] > 0) active[n_active++] = ax;
@@ -449,6 +574,12 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
   // are small: the J kernel filters every row it produces along K before storing it
   const bool fuse_jk = DT == TIO_F32 && radius[1] > 0 && radius[2] > 0 && radius[1] <= kConvMaxRadiusV4 && radius[2] <= 8 &&
                        shape[2] <= 256 && (shape[2] & 3) == 0 && getenv("TIO_CONV_NO_FUSE") == nullptr;
+  if (fuse.any()) {
+    // the pointwise stages ride on the marching I pass (loads) and the fused J+K pass (stores)
+    const bool ok = DT == TIO_F32 && n_active == 3 && fuse_jk && radius[0] <= kConvMaxRadiusV4 && skip == nullptr &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(tmp0)) & 15) == 0;
+    if (!ok) return TIO_ERR_UNSUPPORTED_CONFIG;
+  }
   for (int s = 0; s < n_active; s++) {
     const int axis = active[s];
     if (axis == 2 && fuse_jk) break;  // done by the J pass
@@ -497,13 +628,31 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
         grid.y = static_cast<unsigned>(segs);
         const bool fused = axis == 1 && fuse_jk;
         a.radius_k = fused ? radius[2] : 0;
+        const bool pre_bias = axis == 0 && fuse.bias_coarse != nullptr;
+        const bool post_noise = fused && fuse.noise_on != 0;
+        if (pre_bias) {
+          a.bias_coarse = fuse.bias_coarse;
+          a.bias_ci = fuse.bias_shape[0]; a.bias_cj = fuse.bias_shape[1]; a.bias_ck = fuse.bias_shape[2];
+          a.bias_si = lerp_scale(a.bias_ci, shape[0]); a.bias_sj = lerp_scale(a.bias_cj, shape[1]); a.bias_sk = lerp_scale(a.bias_ck, shape[2]);
+        }
+        if (post_noise) {
+          a.noise_on = 1; a.noise_batched = fuse.noise_batched; a.noise_mean = fuse.noise_mean; a.noise_std = fuse.noise_std;
+          a.noise_mean_b = fuse.noise_mean_b; a.noise_std_b = fuse.noise_std_b; a.noise_seed = fuse.noise_seed;
+        }
         lds = (((ntaps + 3) & ~3) + (2 * kConvStep + 2 * radius[axis]) * 256 + (fused ? 4 * 272 : 0)) * sizeof(float);
-        const void* fn = fused ? reinterpret_cast<const void*>(conv_line_v4_kernel<true>)
-                               : reinterpret_cast<const void*>(conv_line_v4_kernel<false>);
-        if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
-          return fail(TIO_ERR_LAUNCH, "tio_separable_conv3d: cannot reserve %zu bytes of LDS", lds);
-        if (fused) hipLaunchKernelGGL(conv_line_v4_kernel<true>, grid, dim3(kBlock), lds, stream, a);
-        else hipLaunchKernelGGL(conv_line_v4_kernel<false>, grid, dim3(kBlock), lds, stream, a);
+#define TIO_LINE_LAUNCH(FK, PB, PN)                                                                                   \
+  {                                                                                                                   \
+    auto kern = conv_line_v4_kernel<FK, PB, PN>;                                                                      \
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               static_cast<int>(lds)) != hipSuccess)                                  \
+      return fail(TIO_ERR_LAUNCH, "tio_separable_conv3d: cannot reserve %zu bytes of LDS", lds);                       \
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, stream, a);                                                      \
+  }
+        if (fused && post_noise) TIO_LINE_LAUNCH(true, false, true)
+        else if (fused) TIO_LINE_LAUNCH(true, false, false)
+        else if (pre_bias) TIO_LINE_LAUNCH(false, true, false)
+        else TIO_LINE_LAUNCH(false, false, false)
+#undef TIO_LINE_LAUNCH
       }
       src = dst;
       continue;
@@ -607,42 +756,6 @@ __global__ __launch_bounds__(kBlock) void bias_kernel(const void* __restrict__ x
     } else {
       Elem<DT>::store(y, idx, divide ? __fdiv_rn(v[u], field) : __fmul_rn(v[u], field));
     }
-  }
-}
-
-// =============================================================================
-// Philox4x32-10 + Box-Muller (fast noise mode; definition in oracle/tio_oracle.c)
-// =============================================================================
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int round = 0; round < 10; round++) {
-    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c[0];
-    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c[2];
-    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = static_cast<uint32_t>(p1);
-    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = static_cast<uint32_t>(p0);
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
-
-__device__ __forceinline__ void philox_normal4(uint64_t seed, int stream_id, uint64_t q, float z[4]) {
-  uint32_t c[4] = {static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), static_cast<uint32_t>(stream_id), 0u};
-  philox4x32_10(c, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const float u1 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h] >> 8), 0.5f), 1.0f / 16777216.0f);
-    const float u2 = __fmul_rn(__fadd_rn(static_cast<float>(c[2 * h + 1] >> 8), 0.5f), 1.0f / 16777216.0f);
-    const float radius = sqrtf(__fmul_rn(-2.0f, logf(u1)));
-    // cos / sin of 2 pi u2: the hardware units take their argument in revolutions, so u2 in
-    // (0, 1) needs no range reduction (v_cos_f32 / v_sin_f32; within 2e-5 of libm on z,
-    // tests/test_gpu_ops_parity.py::test_philox_stream_and_fast_noise)
-    const float cs = __builtin_amdgcn_cosf(u2);
-    const float sn = __builtin_amdgcn_sinf(u2);
-    z[2 * h] = __fmul_rn(radius, cs);
-    z[2 * h + 1] = __fmul_rn(radius, sn);
   }
 }
 
@@ -911,6 +1024,42 @@ extern "C" int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t d
   TIO_DISPATCH_FLOAT(dtype, TIO_CONV)
 #undef TIO_CONV
   return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_separable_conv3d: dtype %d", dtype);
+}
+
+extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, int32_t batch, int32_t channels,
+                              const int32_t shape[3], const float* taps_dev, int32_t taps_batched, int32_t tap_stride,
+                              const int32_t radius[3], const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],
+                              int32_t noise_on, float noise_mean, float noise_std, const float* noise_mean_dev,
+                              const float* noise_std_dev, int32_t noise_batched, uint64_t philox_seed, void* stream) {
+  if (x == nullptr || y == nullptr || tmp == nullptr || shape == nullptr || radius == nullptr || taps_dev == nullptr)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: null argument");
+  if (dtype != TIO_F32) return TIO_ERR_UNSUPPORTED_CONFIG;
+  if (batch < 0 || channels < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: bad batch/channels");
+  for (int d = 0; d < 3; d++) {
+    if (shape[d] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: shapes must be >= 1");
+    if (radius[d] < 0 || radius[d] > kMaxRadius || 2 * radius[d] + 1 > tap_stride)
+      return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: bad radius");
+  }
+  if (bias_coarse_dev != nullptr) {
+    if (bias_coarse_shape == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: null coarse shape");
+    for (int d = 0; d < 3; d++)
+      if (bias_coarse_shape[d] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: bad coarse shape");
+  }
+  if (noise_on && noise_batched && (noise_mean_dev == nullptr || noise_std_dev == nullptr))
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: batched noise needs mean_dev and std_dev");
+  if (batch == 0) return TIO_OK;
+  const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
+  ConvFuse fuse;
+  fuse.bias_coarse = bias_coarse_dev;
+  if (bias_coarse_dev != nullptr)
+    for (int d = 0; d < 3; d++) fuse.bias_shape[d] = bias_coarse_shape[d];
+  fuse.noise_on = noise_on; fuse.noise_batched = noise_batched; fuse.noise_mean = noise_mean; fuse.noise_std = noise_std;
+  fuse.noise_mean_b = noise_mean_dev; fuse.noise_std_b = noise_std_dev; fuse.noise_seed = philox_seed;
+  float* tmp0 = static_cast<float*>(tmp);
+  float* tmp1 = tmp0 + static_cast<int64_t>(batch) * channels * n;
+  const int status = launch_conv<TIO_F32>(x, y, tmp0, tmp1, batch, channels, shape, taps_dev, taps_batched, tap_stride, radius, nullptr,
+                                          static_cast<hipStream_t>(stream), fuse);
+  return status;
 }
 
 extern "C" int tio_bias_field_apply(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels,

@@ -41,6 +41,8 @@ class LazyCopyScope:
     def materialise(self) -> None:
         """Give every container that still shares its input tensor a private copy."""
         for holder, tensor in self._borrowed:
+            if getattr(holder, "_pending", None) is not None:
+                holder._flush()  # deferred stages replace the tensor: no clone needed afterwards
             if holder._data is tensor:
                 holder._data = tensor.clone()
         self._borrowed.clear()

@@ -15,6 +15,7 @@ import torch
 from torch import Tensor
 
 from . import _lazy
+from . import _pending
 from .affine import AffineMatrix
 from .image import Image
 from .image import ScalarImage
@@ -52,6 +53,7 @@ class ImagesBatch(_History):
         if len(affines) != data.shape[0]:
             raise ValueError(f"Expected {data.shape[0]} affines, got {len(affines)}")
         self._data = data
+        self._pending = None  # deferred BiasField / Blur stages (data/_pending.py); None = tensor is final
         self._affines = affines
         self._image_class = image_class
         self.applied_transforms = []
@@ -65,13 +67,25 @@ class ImagesBatch(_History):
 
     @property
     def data(self) -> Tensor:
+        if self._pending is not None:  # somebody wants values: launch whatever was deferred
+            self._flush()
         return self._data
 
     @data.setter
     def data(self, value: Tensor) -> None:
         if value.ndim != 5:
             raise ValueError(f"Expected 5D tensor, got {value.ndim}D")
+        self._pending = None
         self._data = value
+
+    def _flush(self, *, noise=None) -> None:
+        """Launch the deferred stages (see data/_pending.py), optionally with a trailing noise stage."""
+        pending, self._pending = self._pending, None
+        if pending is None or pending.is_empty():
+            if noise is not None:
+                raise RuntimeError("noise can only be folded into a pending blur")
+            return
+        self._data = _pending.flush(self._data, pending, noise=noise)
 
     @property
     def affines(self) -> list[AffineMatrix]:
@@ -86,11 +100,11 @@ class ImagesBatch(_History):
         return self._data.device
 
     def to(self, *args, **kwargs) -> "ImagesBatch":
-        self._data = self._data.to(*args, **kwargs)
+        self._data = self.data.to(*args, **kwargs)
         return self
 
     def __getitem__(self, index: int) -> Image:
-        return self._image_class(self._data[index], affine=self._affines[index].clone())
+        return self._image_class(self.data[index], affine=self._affines[index].clone())
 
     def __len__(self) -> int:
         return self.batch_size
@@ -100,7 +114,7 @@ class ImagesBatch(_History):
 
     def __deepcopy__(self, memo):
         scope = _lazy.active_scope()
-        data = self._data if scope is not None else self._data.clone()
+        data = self.data if scope is not None else self.data.clone()  # (.data: finished values)
         new = ImagesBatch(data, [a.clone() for a in self._affines], image_class=self._image_class)
         if scope is not None:
             scope.borrow(new, data)  # cloned later unless a transform replaces it (see _lazy.py)

@@ -241,6 +241,59 @@ class Engine:
         )
         return out
 
+    def blur_fused(
+        self,
+        data: Tensor,
+        taps: Tensor,
+        radius: Sequence[int],
+        *,
+        bias_coarse: Tensor | None = None,
+        noise: tuple | None = None,
+    ) -> Tensor | None:
+        """``Noise(Blur(BiasField(data)))`` in the passes of the separable stencil (``tio_blur_fused``).
+
+        ``bias_coarse``: ``(B, C, si, sj, sk)`` float32 or ``None``; ``noise``: ``(mean, std,
+        philox_seed)`` with scalar or ``(B,)`` tensors, or ``None``.  Returns ``None`` when this
+        engine / these arguments have no fused form (nothing was launched): the caller then runs
+        the three ops one after the other, which gives the same values.
+        """
+        if "blur_fused" not in self._fn or data.dtype != torch.float32 or data.ndim != 5:
+            return None
+        batch, channels = data.shape[:2]
+        data = data.contiguous()
+        taps = taps.to(torch.float32).contiguous()
+        self._check("blur_fused", data, taps, bias_coarse)
+        coarse_shape = None
+        if bias_coarse is not None:
+            bias_coarse = bias_coarse.to(torch.float32).contiguous()
+            if bias_coarse.ndim != 5 or bias_coarse.shape[:2] != data.shape[:2]:
+                raise ValueError("bias_coarse must be (B, C, si, sj, sk)")
+            coarse_shape = _i32x3(bias_coarse.shape[2:])
+        noise_on, mean_f, std_f, mean_t, std_t, batched, seed = 0, 0.0, 0.0, None, None, 0, 0
+        if noise is not None:
+            mean, std, seed = noise
+            noise_on = 1
+            batched = int(isinstance(mean, Tensor) or isinstance(std, Tensor))
+            if batched:
+                mean_t = torch.as_tensor(mean, dtype=torch.float32, device=data.device).expand(batch).contiguous()
+                std_t = torch.as_tensor(std, dtype=torch.float32, device=data.device).expand(batch).contiguous()
+            else:
+                mean_f, std_f = float(mean), float(std)
+        out = torch.empty_like(data)
+        tmp = torch.empty((2, *data.shape), dtype=torch.float32, device=data.device)
+        with torch.cuda.device(data.device):
+            status = self._fn["blur_fused"](
+                _ptr(data), _ptr(out), _ptr(tmp), dtype_code(data.dtype), batch, channels, _i32x3(data.shape[2:]), _ptr(taps),
+                int(taps.shape[0] == batch and batch > 1), taps.shape[2], _i32x3(radius), _ptr(bias_coarse), coarse_shape,
+                noise_on, mean_f, std_f, _ptr(mean_t), _ptr(std_t), batched, int(seed) & (2**64 - 1), self._stream(data),
+            )
+        if status == _abi.UNSUPPORTED_CONFIG:
+            return None
+        if status != _abi.OK:
+            message = (self._fn["last_error"]() or b"").decode(errors="replace")
+            raise EngineError(f"tio_blur_fused failed with status {status}: {message}")
+        return out
+
     def bias_field_apply(
         self, data: Tensor, coarse: Tensor, *, divide: bool = False, skip: Tensor | None = None
     ) -> Tensor:

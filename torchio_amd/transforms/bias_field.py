@@ -13,6 +13,7 @@ import torch
 from torch import Tensor
 
 from .. import ops
+from ..data import _pending
 from ..data.batch import SubjectsBatch
 from .parameter_range import to_nonneg_range
 from .transform import IntensityTransform
@@ -78,6 +79,8 @@ def _apply_to_images(transform, batch: SubjectsBatch, std, seed, scale: float, *
     if not per_element and std == 0:
         return
     for img_batch in transform._get_images(batch).values():
+        if not divide and _defer_bias(img_batch, std, seed, scale, per_element):
+            continue
         if per_element:
             img_batch.data = _apply_bias_per_element(img_batch.data, std, seed, scale, divide=divide)
         else:
@@ -86,6 +89,27 @@ def _apply_to_images(transform, batch: SubjectsBatch, std, seed, scale: float, *
             # `data * field` promotes with the float32 field (bias_field.py:130,196)
             work = data if data.dtype in (torch.float32, torch.float64) else data.float()
             img_batch.data = ops.engine().bias_field_apply(work, ops.h2d(coarse, data.device), divide=divide)
+
+
+def _defer_bias(img_batch, std, seed, scale: float, per_element: bool) -> bool:
+    """Queue the multiply on the batch (data/_pending.py): a ``Blur`` that follows folds it into its loads."""
+    data = img_batch.data  # finished values of whatever came before
+    if not _pending.eligible(data):
+        return False
+    if per_element:
+        if any(s == 0 for s in std):
+            return False  # identity rows are restored bit-exactly: plain path
+        small = _coarse_shape(data.shape[2:], scale)
+        fields = []
+        for std_b, seed_b in zip(std, seed, strict=True):
+            generator = torch.Generator(device="cpu")
+            generator.manual_seed(seed_b)
+            fields.append(torch.normal(mean=0.0, std=std_b, size=(1, data.shape[1], *small), generator=generator))
+        coarse = torch.cat(fields, dim=0)
+    else:
+        coarse = _sample_coarse_field(data.shape, std=std, scale=scale, seed=seed)
+    img_batch._pending = _pending.Pending(bias_coarse=ops.h2d(coarse, data.device))
+    return True
 
 
 def _coarse_shape(spatial, scale: float) -> list[int]:

@@ -15,6 +15,7 @@ import torch
 from torch import Tensor
 
 from .. import ops
+from ..data import _pending
 from ..data.batch import SubjectsBatch
 from .parameter_range import to_nonneg_range
 from .transform import IntensityTransform
@@ -58,8 +59,37 @@ class Blur(IntensityTransform):
             else:
                 spacing = np.asarray(img_batch.affines[0].spacing, dtype=np.float64)
                 sigmas = [s / sp if sp > 0 else 0.0 for s, sp in zip(params["std"], spacing, strict=True)]
-            img_batch.data = _gaussian_smooth(img_batch.data, sigmas)
+            if not _defer_blur(img_batch, sigmas):
+                img_batch.data = _gaussian_smooth(img_batch.data, sigmas)
         return batch
+
+
+def _defer_blur(img_batch, sigmas) -> bool:
+    """Queue the stencil on the batch instead of launching it (data/_pending.py) when the data qualifies.
+
+    A ``BiasField`` queued just before and a ``Noise`` arriving just after are then folded into
+    the stencil's passes; any other reader of ``img_batch.data`` launches what is queued.
+    """
+    raw = img_batch._data
+    if not _pending.eligible(raw):
+        return False
+    sigmas = np.asarray(sigmas, dtype=np.float64)
+    if np.all(sigmas <= 0):
+        return False  # identity: leave it to the plain path (returns the data untouched)
+    if sigmas.ndim == 2 and np.all(sigmas == sigmas[0]):
+        sigmas = sigmas[0]
+    taps, radius, skip = _stacked_gaussian_taps(sigmas if sigmas.ndim == 2 else sigmas[None], per_element=sigmas.ndim == 2)
+    if skip is not None:
+        return False  # rows restored bit-exactly: plain path
+    queue = img_batch._pending
+    if queue is not None and queue.blur is not None:  # two stencils in a row: finish the first
+        img_batch._flush()
+        queue = None
+    if queue is None:
+        queue = _pending.Pending()
+    queue.blur = (ops.h2d(taps, raw.device), [int(r) for r in radius])
+    img_batch._pending = queue
+    return True
 
 
 def _gaussian_smooth(data: Tensor, sigmas) -> Tensor:

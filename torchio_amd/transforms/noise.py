@@ -23,6 +23,7 @@ import torch
 from torch import Tensor
 
 from .. import ops
+from ..data import _pending
 from ..data.batch import SubjectsBatch
 from .parameter_range import to_nonneg_range
 from .parameter_range import to_range
@@ -83,6 +84,16 @@ class Noise(IntensityTransform):
         generator.manual_seed(seed)
         engine = ops.engine()
         for index, img_batch in enumerate(self._get_images(batch).values()):
+            queue = img_batch._pending
+            if (
+                queue is not None and queue.blur is not None and _NOISE_RNG != "reference" and not rician and keep is None
+                and _pending.eligible(img_batch._data)
+            ):  # a Blur is still queued on this tensor: the noise rides on its stores
+                device = img_batch._data.device
+                mean_arg = ops.h2d(torch.tensor(mean, dtype=torch.float32), device) if isinstance(mean, list) else mean
+                std_arg = ops.h2d(torch.tensor(std, dtype=torch.float32), device) if isinstance(std, list) else std
+                img_batch._flush(noise=(mean_arg, std_arg, (index << 32) | int(seed)))
+                continue
             data = img_batch.data
             # data + float32 noise promotes half / integer data to float32 (noise.py:119)
             work = data if data.dtype in (torch.float32, torch.float64) else data.float()
