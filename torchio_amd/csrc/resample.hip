@@ -491,6 +491,7 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     if (strcmp(env, "tile") == 0) use_tile = true;
   }
   if (static_cast<int64_t>(a.Jo) * a.Ko * 8 >= (1LL << 31)) use_tile = false;  // 32-bit byte offsets inside one output plane
+  if (n_in >= (1LL << 30)) use_tile = false;  // 32-bit byte offsets inside one input channel (f32 brick DMA)
   if (use_tile) {
     int variant = 0, cap = 0;
     if (const char* env = getenv("TIO_TILE_VARIANT")) variant = atoi(env);

@@ -84,16 +84,22 @@ __device__ __forceinline__ void block_max6(int (&r)[6], int* s_red, int slot, in
 // 2v / den, and (t * 0.5) * h == t * (0.5 h) because t * 0.5 is exact.  short_div: one
 // Markstein refinement is already correctly rounded for every divisor k/2, k <= 8192
 // (exhaustive over all mantissas: tests/native/divtest.c).
-__device__ __forceinline__ float normalise_roundtrip_folded(float v, float dh, float rdh, float half_h, bool short_div) {
+template <bool SHORT>
+__device__ __forceinline__ float normalise_roundtrip_folded(float v, float dh, float rdh, float half_h) {
   float q = __fmul_rn(v, rdh);
   float e = __builtin_fmaf(-dh, q, v);
   q = __builtin_fmaf(e, rdh, q);
-  if (!short_div) {
+  if constexpr (!SHORT) {
     e = __builtin_fmaf(-dh, q, v);
     q = __builtin_fmaf(e, rdh, q);
   }
   const float g = __fsub_rn(q, 1.0f);
   return __fmul_rn(__fadd_rn(g, 1.0f), half_h);
+}
+// block-uniform choice at run time (the compiler turns it into a select over both results;
+// the hot loops branch once outside instead and call the template)
+__device__ __forceinline__ float normalise_roundtrip_folded(float v, float dh, float rdh, float half_h, bool short_div) {
+  return short_div ? normalise_roundtrip_folded<true>(v, dh, rdh, half_h) : normalise_roundtrip_folded<false>(v, dh, rdh, half_h);
 }
 
 // one control plane of the displacement field for this thread's (j, k) column:
@@ -348,19 +354,22 @@ __device__ __forceinline__ void stage_brick_f32x4(float* __restrict__ tile, cons
   }
 }
 
-// Interior boxes (every staged position inside the volume): global → LDS directly
+// float32, K % 4 == 0, 16-byte aligned base: global → LDS directly
 // (global_load_lds_dwordx4: each lane names one 16-byte chunk, a wave fills 1 KiB of
-// consecutive LDS), so the brick never passes through VGPRs and there is no ds_write.
-// Chunk id → (row, chunk) → global offset costs a few integer ops per chunk.
-template <int NT>
-__device__ __forceinline__ void stage_brick_dma(float* __restrict__ tile, const float* __restrict__ src, int tid,
-                                                const TileBox& bx, int J, int K) {
+// consecutive LDS), so the brick never passes through VGPRs.  Chunks outside the volume are
+// written as zeros by the lanes that own them.  Asynchronous: the caller waits
+// (tile_dma_wait) right before the barrier that precedes the first read.
+template <int NT, bool INSIDE>
+__device__ __forceinline__ void stage_brick_dma_loop(float* __restrict__ tile, const float* __restrict__ src, int tid,
+                                                     const TileBox& bx, int I, int J, int K) {
   const unsigned cpr = static_cast<unsigned>(bx.Lz) >> 2;
   const unsigned total = static_cast<unsigned>(bx.Lx * bx.Ly) * cpr;
   const unsigned m_cpr = fastdiv_magic(cpr), m_ly = fastdiv_magic(bx.Ly);
-  const int wave_base = (tid >> 6) << 6;  // wave-uniform first chunk id of this wave in an iteration
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) << 6;  // first chunk id of this wave in an iteration (SGPR)
   typedef __attribute__((address_space(3))) float* lds_float_ptr;
-  typedef __attribute__((address_space(1))) const float* global_float_ptr;
+  typedef __attribute__((address_space(1))) const char* global_byte_ptr;
+  // element offset of chunk (xr, yr, ch): origin + row K + xr (J - Ly) K + 4 ch with row = xr Ly + yr;
+  // byte offsets fit 32 bits (the launcher keeps larger volumes on the gather path)
   const int origin = (bx.bx0 * J + bx.by0) * K + bx.za;
   const int JmLyK = (J - bx.Ly) * K;
   for (unsigned base = 0; base < total; base += NT) {
@@ -369,15 +378,36 @@ __device__ __forceinline__ void stage_brick_dma(float* __restrict__ tile, const 
       const unsigned row = fastdiv(id, m_cpr, cpr);
       const unsigned ch = id - row * cpr;
       const unsigned xr = fastdiv(row, m_ly, bx.Ly);
-      // element offset of (bx0 + xr, by0 + yr, za + 4 ch) = origin + row K + xr (J - Ly) K + 4 ch
-      const int off = origin + static_cast<int>(row) * K + static_cast<int>(xr) * JmLyK + 4 * static_cast<int>(ch);
-      // the hardware writes lane l of the wave at (wave-uniform LDS base) + 16 l
-      lds_float_ptr dst = (lds_float_ptr)(tile) + 4 * (base + static_cast<unsigned>(wave_base));
-      __builtin_amdgcn_global_load_lds((global_float_ptr)(src + off), dst, 16, 0, 0);
+      bool ok = true;
+      if constexpr (!INSIDE) {
+        const unsigned yr = row - xr * bx.Ly;
+        ok = (static_cast<unsigned>(bx.bx0 + static_cast<int>(xr)) < static_cast<unsigned>(I)) &
+             (static_cast<unsigned>(bx.by0 + static_cast<int>(yr)) < static_cast<unsigned>(J)) &
+             (static_cast<unsigned>(bx.za + 4 * static_cast<int>(ch)) < static_cast<unsigned>(K));
+      }
+      if (ok) {
+        const unsigned off = static_cast<unsigned>(origin + static_cast<int>(row) * K + static_cast<int>(xr) * JmLyK +
+                                                   4 * static_cast<int>(ch));
+        // the hardware writes lane l of the wave at (wave-uniform LDS base) + 16 l
+        lds_float_ptr dst = (lds_float_ptr)(tile) + 4 * (base + static_cast<unsigned>(wave_base));
+        __builtin_amdgcn_global_load_lds((global_byte_ptr)(src) + 4u * off, dst, 16, 0, 0);
+      } else {
+        *reinterpret_cast<float4*>(tile + 4 * id) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+template <int NT>
+__device__ __forceinline__ void stage_brick_dma(float* __restrict__ tile, const float* __restrict__ src, int tid,
+                                                const TileBox& bx, int I, int J, int K) {
+  if (bx.interior)  // block uniform: no chunk can be outside
+    stage_brick_dma_loop<NT, true>(tile, src, tid, bx, I, J, K);
+  else
+    stage_brick_dma_loop<NT, false>(tile, src, tid, bx, I, J, K);
+}
+
+__device__ __forceinline__ void tile_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int NT, int DTMODE>
 __device__ __forceinline__ void stage_brick_generic(float* __restrict__ tile, const void* __restrict__ src, int dtype,
@@ -491,7 +521,8 @@ template <int NT, int DTMODE, int TI, bool LAUNDER>
 __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArgs& g, int b, int c, const float (&X)[TI],
                                              const float (&Y)[TI], const float (&Z)[TI], const TileBox& bx, float* s_tile,
                                              unsigned tile_lds_addr, int tid, int row, int slab, int i_begin, int i_count,
-                                             bool col_active, bool full, int q_begin, int q_end, int64_t n_in, int64_t n_out) {
+                                             bool col_active, bool full, int q_begin, int q_end, int64_t n_in, int64_t n_out,
+                                             bool prestaged = false) {
   constexpr int NQ = 4, QT = TI / NQ;
   const float hx = a.size_m1[0], hy = a.size_m1[1], hz = a.size_m1[2];
   const int t_begin = q_begin * QT, t_end = min(q_end * QT, i_count);
@@ -503,10 +534,13 @@ __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArg
   ta.base_f = static_cast<float>(tile_lds_addr);
   const int es = dtype_size(g.dtype);
   const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
-  __syncthreads();  // previous brick of this block fully consumed
+  if (!prestaged) __syncthreads();  // previous brick of this block fully consumed
   if (a.ablate & 1) {
-  } else if (vec_ok && bx.interior && !(a.ablate & 8)) {
-    stage_brick_dma<NT>(s_tile, static_cast<const float*>(g.in) + bc * n_in, tid, bx, a.J, a.K);
+  } else if (prestaged) {  // the caller issued the DMA before phase A
+    tile_dma_wait();
+  } else if (vec_ok && !(a.ablate & 8)) {
+    stage_brick_dma<NT>(s_tile, static_cast<const float*>(g.in) + bc * n_in, tid, bx, a.I, a.J, a.K);
+    tile_dma_wait();
   } else if (vec_ok) {
     stage_brick_f32x4<NT>(s_tile, static_cast<const float*>(g.in) + bc * n_in, tid, bx, a.I, a.J, a.K);
   } else {
@@ -682,7 +716,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
                      (m12 == 0.0f) & (m13 == 0.0f) & (m20 == 0.0f) & (m21 == 0.0f) & (m22 == 1.0f) & (m23 == 0.0f);
 #define TIO_AFFINE_ROW(M0, M1, M2, M3, A, B, C) \
   __builtin_fmaf(1.0f, M3, __builtin_fmaf(C, M2, __builtin_fmaf(B, M1, __fmul_rn(A, M0))))
-#define TIO_FINISH_COORD(T, DI, DJ, DK, HAS_D)                                                  \
+#define TIO_FINISH_COORD(T, DI, DJ, DK, HAS_D, NORM)                                                \
   {                                                                                             \
     float vi, vj, vk;                                                                           \
     if (HAS_D) {                                                                                \
@@ -712,10 +746,13 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
       vj = TIO_AFFINE_ROW(m10, m11, m12, m13, ci, cj, ck);                                      \
       vk = TIO_AFFINE_ROW(m20, m21, m22, m23, ci, cj, ck);                                      \
     }                                                                                           \
-    X[T] = normalise_roundtrip_folded(vi, a.dh[0], a.rdh[0], a.half_h[0], short_div);           \
-    Y[T] = normalise_roundtrip_folded(vj, a.dh[1], a.rdh[1], a.half_h[1], short_div);           \
-    Z[T] = normalise_roundtrip_folded(vk, a.dh[2], a.rdh[2], a.half_h[2], short_div);           \
+    X[T] = NORM(vi, a.dh[0], a.rdh[0], a.half_h[0]);                                            \
+    Y[T] = NORM(vj, a.dh[1], a.rdh[1], a.half_h[1]);                                            \
+    Z[T] = NORM(vk, a.dh[2], a.rdh[2], a.half_h[2]);                                            \
   }
+#define TIO_NORM_RT(V, D, R, H) normalise_roundtrip_folded(V, D, R, H, short_div)
+#define TIO_NORM_SHORT(V, D, R, H) normalise_roundtrip_folded<true>(V, D, R, H)
+#define TIO_NORM_FULL(V, D, R, H) normalise_roundtrip_folded<false>(V, D, R, H)
 #define TIO_TRACK_ALL(T)                                                     \
   {                                                                          \
     if ((T) == 0) {                                                          \
@@ -725,6 +762,38 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
       lo[1] = fminf(lo[1], Y[T]); hi[1] = fmaxf(hi[1], Y[T]);                \
       lo[2] = fminf(lo[2], Z[T]); hi[2] = fmaxf(hi[2], Z[T]);                \
     }                                                                        \
+  }
+
+  // ---- affine-only bricks: the box from the 8 brick corners, before phase A ----------------
+  // Every operation of the coordinate chain (products, sums, the correctly rounded division,
+  // the un-normalisation) is monotone in each of the three output indices, so the brick's
+  // coordinate extremes sit at its corners.  Each wave evaluates the 8 corners (lane & 7)
+  // with the very same instruction sequence and reduces them on its own: no LDS, no barrier,
+  // and the brick can be requested from HBM before the per-voxel coordinates are computed.
+  const float capx = hx + 1.0f, capy = hy + 1.0f, capz = hz + 1.0f;
+  TileBox box_full;
+  bool have_box = false, prestaged = false;
+  if (!elastic) {
+    int r[6];
+    {
+      const int j_lo = jt * TJ, j_hi = min(j_lo + TJ, a.Jo) - 1, k_lo = kt * TK, k_hi = min(k_lo + TK, a.Ko) - 1;
+      const float ci = (lane & 1) ? ci_last : ci0;
+      const float cj = static_cast<float>((lane & 2) ? j_hi : j_lo), ck = static_cast<float>((lane & 4) ? k_hi : k_lo);
+      float X[1], Y[1], Z[1];
+      TIO_FINISH_COORD(0, 0.0f, 0.0f, 0.0f, false, TIO_NORM_RT)
+      bound_ints(X[0], X[0], capx, r[0], r[1]);
+      bound_ints(Y[0], Y[0], capy, r[2], r[3]);
+      bound_ints(Z[0], Z[0], capz, r[4], r[5]);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) r[q] = wave_max_i32(r[q]);
+    box_full = make_box(r, a, weird);
+    have_box = true;
+    const ImgArgs& g0 = a.img[0];
+    prestaged = (a.n_images == 1) & (g0.channels == 1) & (g0.interp == TIO_LINEAR) & (box_full.fits != 0) & (box_full.outside == 0) &
+                (g0.dtype == TIO_F32) & ((a.K & 3) == 0) & ((reinterpret_cast<uintptr_t>(g0.in) & 15) == 0) & (a.ablate == 0);
+    if (prestaged)
+      stage_brick_dma<NT>(s_tile, static_cast<const float*>(g0.in) + static_cast<int64_t>(b) * n_in, tid, box_full, a.I, a.J, a.K);
   }
 
   bool done = false;
@@ -748,20 +817,27 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
           if (ib - ia >= 1) { cp_plane(cp, ia + 1, s_i, s_j, lj, lk, p); P[3] = p[0]; P[4] = p[1]; P[5] = p[2]; }
           if (ib - ia >= 2) { cp_plane(cp, ia + 2, s_i, s_j, lj, lk, p); P[6] = p[0]; P[7] = p[1]; P[8] = p[2]; }
         }
-#pragma unroll
-        for (int t = 0; t < TI; t++) {
-          const float ci = fminf(ci0 + static_cast<float>(t), ci_last);
-          const int e0 = 3 * (__builtin_amdgcn_readlane(li_lane.i0, t) - ia);  // scalars: uniform register index
-          const int e1 = 3 * (__builtin_amdgcn_readlane(li_lane.i1, t) - ia);
-          const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l0), t));
-          const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l1), t));
-          const float di = lerp2(P[e0], l0, P[e1], l1);
-          const float dj = lerp2(P[e0 + 1], l0, P[e1 + 1], l1);
-          const float dk = lerp2(P[e0 + 2], l0, P[e1 + 2], l1);
-          TIO_FINISH_COORD(t, di, dj, dk, true)
-          TIO_TRACK_ALL(t)
-          if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#define TIO_PLANE_LOOP(NORM)                                                                                      \
+  _Pragma("unroll") for (int t = 0; t < TI; t++) {                                                                \
+    const float ci = fminf(ci0 + static_cast<float>(t), ci_last);                                                 \
+    const int e0 = 3 * (__builtin_amdgcn_readlane(li_lane.i0, t) - ia); /* scalars: uniform register index */     \
+    const int e1 = 3 * (__builtin_amdgcn_readlane(li_lane.i1, t) - ia);                                           \
+    const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l0), t));                    \
+    const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l1), t));                    \
+    const float di = lerp2(P[e0], l0, P[e1], l1);                                                                 \
+    const float dj = lerp2(P[e0 + 1], l0, P[e1 + 1], l1);                                                         \
+    const float dk = lerp2(P[e0 + 2], l0, P[e1 + 2], l1);                                                         \
+    TIO_FINISH_COORD(t, di, dj, dk, true, NORM)                                                                   \
+    TIO_TRACK_ALL(t)                                                                                              \
+    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+        // one block-uniform branch instead of a select per division
+        if (short_div) {
+          TIO_PLANE_LOOP(TIO_NORM_SHORT)
+        } else {
+          TIO_PLANE_LOOP(TIO_NORM_FULL)
         }
+#undef TIO_PLANE_LOOP
       } else {
 #pragma unroll
         for (int t = 0; t < TI; t++) {
@@ -769,7 +845,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
           const float ci = static_cast<float>(io);
           const Lerp1D li = lerp_index(io, a.ni, a.Io, a.scale_i);
           const Disp d = cp_trilerp3(cp, s_i, s_j, li, lj, lk);
-          TIO_FINISH_COORD(t, d.i, d.j, d.k, true)
+          TIO_FINISH_COORD(t, d.i, d.j, d.k, true, TIO_NORM_RT)
           TIO_TRACK_ALL(t)
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -778,27 +854,30 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
     }
   }
   if (!done) {
-#pragma unroll
-    for (int t = 0; t < TI; t++) {
-      const float ci = fminf(ci0 + static_cast<float>(t), ci_last);
-      TIO_FINISH_COORD(t, 0.0f, 0.0f, 0.0f, false)
-      if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#define TIO_AFFINE_LOOP(NORM)                                          \
+  _Pragma("unroll") for (int t = 0; t < TI; t++) {                     \
+    const float ci = fminf(ci0 + static_cast<float>(t), ci_last);      \
+    TIO_FINISH_COORD(t, 0.0f, 0.0f, 0.0f, false, NORM)                 \
+    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);               \
+  }
+    if (short_div) {
+      TIO_AFFINE_LOOP(TIO_NORM_SHORT)
+    } else {
+      TIO_AFFINE_LOOP(TIO_NORM_FULL)
     }
-    // every operation of the chain is monotone in ci, so a column's extremes over a run of
-    // planes sit at the run's end points
-    lo[0] = fminf(X[0], X[TI - 1]); hi[0] = fmaxf(X[0], X[TI - 1]);
-    lo[1] = fminf(Y[0], Y[TI - 1]); hi[1] = fmaxf(Y[0], Y[TI - 1]);
-    lo[2] = fminf(Z[0], Z[TI - 1]); hi[2] = fmaxf(Z[0], Z[TI - 1]);
+#undef TIO_AFFINE_LOOP
+    lo[0] = hi[0] = lo[1] = hi[1] = lo[2] = hi[2] = 0.0f;  // unused: the box came from the corners
   }
 #undef TIO_TRACK_ALL
 #undef TIO_FINISH_COORD
+#undef TIO_NORM_RT
+#undef TIO_NORM_SHORT
+#undef TIO_NORM_FULL
 #undef TIO_AFFINE_ROW
 
   // ---- phase B: bounding boxes: whole brick, else halves, else quarters ----------------
-  const float capx = hx + 1.0f, capy = hy + 1.0f, capz = hz + 1.0f;
   int nsplit = 1;
-  TileBox box_full;
-  {
+  if (!have_box) {
     int r[6];
     bound_ints(lo[0], hi[0], capx, r[0], r[1]);
     bound_ints(lo[1], hi[1], capy, r[2], r[3]);
@@ -861,7 +940,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
   const bool single = (nsplit == 1) & (a.n_images == 1) & (a.img[0].channels == 1);
   if (single && a.img[0].interp == TIO_LINEAR && box_full.fits && !box_full.outside) {
     tile_channel<NT, DTMODE, TI, false>(a, a.img[0], b, 0, X, Y, Z, box_full, s_tile, tile_lds_addr, tid, row, slab, i_begin, i_count, col_active,
-                                        full, 0, 4, n_in, n_out);
+                                        full, 0, 4, n_in, n_out, prestaged);
     return;
   }
   for (int p = 0; p < nsplit; p++) {
