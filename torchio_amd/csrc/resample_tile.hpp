@@ -59,19 +59,20 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return max(max(r0, r1), max(r2, r3));
 }
 
-// block-wide max of 6 values; every call uses its own LDS slot, so one barrier per call
-template <int NW>
-__device__ __forceinline__ void block_max6(int (&r)[6], int* s_red, int slot, int wave, int lane) {
+// block-wide max of N <= 8 values; every call uses its own LDS slot, so one barrier per call
+template <int NW, int N>
+__device__ __forceinline__ void block_max6(int (&r)[N], int* s_red, int slot, int wave, int lane) {
+  static_assert(N <= 8, "a slot holds 8 ints per wave");
 #pragma unroll
-  for (int q = 0; q < 6; q++) r[q] = wave_max_i32(r[q]);
+  for (int q = 0; q < N; q++) r[q] = wave_max_i32(r[q]);
   int* s = s_red + slot * (NW * 8);
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 6; q++) s[wave * 8 + q] = r[q];
+    for (int q = 0; q < N; q++) s[wave * 8 + q] = r[q];
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 6; q++) {
+  for (int q = 0; q < N; q++) {
     int v = s[q];
 #pragma unroll
     for (int w = 1; w < NW; w++) v = max(v, s[w * 8 + q]);
@@ -680,14 +681,30 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
 #pragma unroll
   for (int q = 0; q < 12; q++) weird |= (__float_as_uint(m[q]) & 0x7FFFFFFFu) > 0x7149F2CAu;
 
-  bool elastic = false;
+  bool elastic = false, plane_cached = false;
   const float* cp = nullptr;
+  int cp_bad = 0;  // per thread; joins the box reduction
+  int ia = 0, ib = 0;
+  Lerp1D li_lane = {0, 0, 0.0f, 0.0f};
   if constexpr (ELASTIC_POSSIBLE) {
     elastic = !(a.cp_skip != nullptr && a.cp_skip[b] != 0);
     if (elastic) {
       const int n_cp = a.ni * a.nj * a.nk * 3;
       const float* cp_global = a.cp + (a.cp_batched ? static_cast<int64_t>(b) * n_cp : 0);
       cp = cp_global;
+      // the TI plane lerps are block uniform: lane t computes plane t's once, the unrolled
+      // loop reads them back as scalars (v_readlane) instead of redoing them per voxel
+      li_lane = lerp_index(min(i_begin + (lane & (TI - 1)), i_last), a.ni, a.Io, a.scale_i);
+      ia = __builtin_amdgcn_readlane(li_lane.i0, 0);
+      ib = __builtin_amdgcn_readlane(li_lane.i1, TI - 1);
+      // <= 3 control planes under the brick (the usual coarse grid): every column reads its 36
+      // control values straight from global memory (4 KiB, cache resident) - no staging, no
+      // barrier.  Denser grids stage the whole field in LDS for the per-voxel lerp below.
+      plane_cached = ib - ia <= 2;
+    }
+    if (elastic && !plane_cached) {
+      const int n_cp = a.ni * a.nj * a.nk * 3;
+      const float* cp_global = cp;
       int bad = 0;
       if (a.cp_lds > 0) {
         for (int t = tid; t < n_cp; t += NT) {
@@ -802,12 +819,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
       const Lerp1D lj = lerp_index(jo, a.nj, a.Jo, a.scale_j);
       const Lerp1D lk = lerp_index(ko, a.nk, a.Ko, a.scale_k);
       const int s_i = a.nj * a.nk * 3, s_j = a.nk * 3;
-      // the TI plane lerps are block uniform: lane t computes plane t's once, the unrolled
-      // loop reads them back as scalars (v_readlane) instead of redoing them per voxel
-      const Lerp1D li_lane = lerp_index(min(i_begin + (lane & (TI - 1)), i_last), a.ni, a.Io, a.scale_i);
-      const int ia = __builtin_amdgcn_readlane(li_lane.i0, 0);
-      const int ib = __builtin_amdgcn_readlane(li_lane.i1, TI - 1);
-      if (ib - ia <= 2) {  // ≤ 3 control planes under the brick: lerp them once per column
+      if (plane_cached) {  // ≤ 3 control planes under the brick: lerp them once per column
         typedef float plane_vec __attribute__((ext_vector_type(16)));
         plane_vec P = {};  // P[3 e + c]: component c of control plane ia + e
         {
@@ -817,6 +829,9 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
           if (ib - ia >= 1) { cp_plane(cp, ia + 1, s_i, s_j, lj, lk, p); P[3] = p[0]; P[4] = p[1]; P[5] = p[2]; }
           if (ib - ia >= 2) { cp_plane(cp, ia + 2, s_i, s_j, lj, lk, p); P[6] = p[0]; P[7] = p[1]; P[8] = p[2]; }
         }
+        // NaN / Inf control values reach the lerped planes (NaN * 0 = NaN): flag the brick
+#pragma unroll
+        for (int e = 0; e < 9; e++) cp_bad |= !(fabsf(P[e]) <= 1e30f);
 #define TIO_PLANE_LOOP(NORM)                                                                                      \
   _Pragma("unroll") for (int t = 0; t < TI; t++) {                                                                \
     const float ci = fminf(ci0 + static_cast<float>(t), ci_last);                                                 \
@@ -878,11 +893,14 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
   // ---- phase B: bounding boxes: whole brick, else halves, else quarters ----------------
   int nsplit = 1;
   if (!have_box) {
-    int r[6];
-    bound_ints(lo[0], hi[0], capx, r[0], r[1]);
-    bound_ints(lo[1], hi[1], capy, r[2], r[3]);
-    bound_ints(lo[2], hi[2], capz, r[4], r[5]);
-    block_max6<NW>(r, s_red, 0, wave, lane);
+    int r7[7];
+    bound_ints(lo[0], hi[0], capx, r7[0], r7[1]);
+    bound_ints(lo[1], hi[1], capy, r7[2], r7[3]);
+    bound_ints(lo[2], hi[2], capz, r7[4], r7[5]);
+    r7[6] = cp_bad;  // a non-finite displacement seen by any column of the brick
+    block_max6<NW, 7>(r7, s_red, 0, wave, lane);
+    weird |= r7[6] != 0;
+    const int r[6] = {r7[0], r7[1], r7[2], r7[3], r7[4], r7[5]};
     box_full = make_box(r, a, weird);
   }
   if (!box_full.fits && !weird && !box_full.outside) {
@@ -904,7 +922,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
       bound_ints(l3[0], h3[0], capx, r[0], r[1]);
       bound_ints(l3[1], h3[1], capy, r[2], r[3]);
       bound_ints(l3[2], h3[2], capz, r[4], r[5]);
-      block_max6<NW>(r, s_red, 1 + h, wave, lane);
+      block_max6<NW, 6>(r, s_red, 1 + h, wave, lane);
       const TileBox bh = make_box(r, a, weird);
       ok2 &= (bh.fits | bh.outside) != 0;
       if (tid == 0) store_box(s_box + h * 16, bh);
@@ -924,7 +942,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
         bound_ints(l3[0], h3[0], capx, r[0], r[1]);
         bound_ints(l3[1], h3[1], capy, r[2], r[3]);
         bound_ints(l3[2], h3[2], capz, r[4], r[5]);
-        block_max6<NW>(r, s_red, 3 + q, wave, lane);
+        block_max6<NW, 6>(r, s_red, 3 + q, wave, lane);
         const TileBox bq = make_box(r, a, weird);
         if (tid == 0) store_box(s_box + q * 16, bq);  // overwrites the halves: every wave passed the last barrier after reading them
       }
