@@ -144,6 +144,33 @@ def test_tile_equals_gather_at_bench_size(hip, resample_path, elastic):
     assert torch.equal(expected, actual)
 
 
+def _same_bits_or_both_nan(a, b):
+    return bool(((a == b) | (a.isnan() & b.isnan())).all())
+
+
+@pytest.mark.parametrize("poison", ["nan", "inf", "huge"])
+@pytest.mark.parametrize("with_fill", [False, True])
+def test_tile_non_finite_control_points_match_gather(oracle, hip, resample_path, poison, with_fill):
+    """Bricks whose displacement is NaN / Inf / absurd leave the brick path; the others stay on it."""
+    batch, shape = 2, (64, 48, 96)
+    data = _data((batch, 1, *shape), torch.float32, 71)
+    control = _control_points(batch, (7, 7, 7), 72, amplitude=5.0)
+    value = {"nan": float("nan"), "inf": float("inf"), "huge": 3.0e35}[poison]
+    control[0, 3, 3, 3, 1] = value
+    control[1, 2, 4, 1, 0] = -value
+    kwargs = dict(
+        out_shape=shape, mapping=_mapping(batch, 73, scale=0.1, shift=3.0), control_points=control,
+        in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["linear"],
+        fills=[torch.tensor([-2.0]) if with_fill else None],
+    )
+    resample_path("gather")
+    cpu, expected = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    resample_path("tile")
+    _, actual = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert _same_bits_or_both_nan(expected[0], actual[0])
+    assert _same_bits_or_both_nan(cpu[0], actual[0].cpu())
+
+
 def test_native_driver_parity_sweep():
     """tests/native/resample_bench --cases parity: every path vs the oracle through the bare C ABI."""
     binary = os.path.join(ROOT, "tests", "native", "_build", "resample_bench")
