@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 2
+#define TIO_ABI_VERSION 3
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -58,7 +58,16 @@ typedef enum tio_dtype {
 
 typedef enum tio_interp {
   TIO_NEAREST = 0, /* grid_sample(mode="nearest"): nearbyint, half-to-even      */
-  TIO_LINEAR = 1   /* grid_sample(mode="bilinear"): 8-tap trilinear, zero pad   */
+  TIO_LINEAR = 1,  /* grid_sample(mode="bilinear"): 8-tap trilinear, zero pad   */
+  /* label_interpolation="label" with one_hot_label_interpolation="linear", C == 1,
+   * no antialias (_resample_label_partial_volume, spatial.py:1275-1389), fused:
+   * the one-hot (B, L, I, J, K) tensor is never built.  Per output voxel the value of
+   * one-hot channel l is the sum, in ATen's tap order, of the trilinear weights of
+   * the in-bounds taps that carry label l; the winner is torch.argmax's (first
+   * maximum = smallest label); the voxel is in bounds when the float32 sum over the
+   * channels (torch.sum's cascade over the sorted label table) exceeds 0.5, else it
+   * receives the pad label.                                                       */
+  TIO_LABEL_PV = 2
 } tio_interp;
 
 /* ------------------------------------------------------------------------ */
@@ -117,6 +126,18 @@ typedef struct tio_resample_image {
    * branch (no mask step, spatial.py:2075-2076).  Non-NULL = trilinear in-bounds
    * weight mask, out = mask > 0.5 ? sampled : fill[c]  (spatial.py:1719-1728).  */
   const float* fill_dev;
+  /* TIO_LABEL_PV only (ignored otherwise; requires channels == 1).
+   *   labels_dev / n_labels: torch.unique(data) of the WHOLE batch tensor as
+   *     ascending float64 (spatial.py:1360).  Only the POSITION of a label in this
+   *     table matters, and only through the rounding order of the reference's
+   *     channel sum (ATen's cascade_sum dumps its accumulator every 16 channels);
+   *     NULL / 0 = plain sequential sum in ascending label order, which is what the
+   *     cascade does for fewer than 16 distinct labels.
+   *   pad_label: default_pad_label, cast to the image dtype like
+   *     torch.full_like(resampled, default_pad_label)  (spatial.py:1380-1384).  */
+  const double* labels_dev;
+  int32_t n_labels;
+  double pad_label;
 } tio_resample_image;
 
 /* Resample n_images image tensors through ONE coordinate computation. */

@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../include/tio_hip.h"
@@ -137,6 +138,24 @@ static inline void store_from_float(void* p, int dtype, int64_t i, float v) {
   }
 }
 
+static inline double load_as_double(const void* p, int dtype, int64_t i) {
+  switch (dtype) {
+    case TIO_F64: return ((const double*)p)[i];
+    case TIO_I32: return (double)((const int32_t*)p)[i];
+    case TIO_I64: return (double)((const int64_t*)p)[i];
+    default: return (double)load_as_float(p, dtype, i); /* exact: these types embed in float32 */
+  }
+}
+
+static inline void store_from_double(void* p, int dtype, int64_t i, double v) {
+  switch (dtype) {
+    case TIO_F64: ((double*)p)[i] = v; break;
+    case TIO_I32: ((int32_t*)p)[i] = (int32_t)(int64_t)v; break;
+    case TIO_I64: ((int64_t*)p)[i] = (int64_t)v; break;
+    default: store_from_float(p, dtype, i, (float)v); break;
+  }
+}
+
 static inline size_t dtype_size(int dtype) {
   switch (dtype) {
     case TIO_F32: case TIO_I32: return 4;
@@ -227,6 +246,76 @@ static inline float normalise_roundtrip(float v, int32_t size) {
 
 static inline int in_bounds(float f, int32_t n) { return f >= 0.0f && f <= (float)(n - 1); }
 
+/* ------------------------------------------------------------------------ */
+/* "label" partial-volume mode, literally: spatial.py:1275-1389 (C == 1)      */
+/* ------------------------------------------------------------------------ */
+static int compare_doubles(const void* a, const void* b) {
+  double x = *(const double*)a, y = *(const double*)b;
+  return (x > y) - (x < y);
+}
+
+/* torch.unique(data): sorted distinct values of the whole tensor; caller frees */
+static double* unique_labels(const void* data, int dtype, int64_t n, int32_t* count) {
+  double* values = (double*)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+  for (int64_t i = 0; i < n; i++) values[i] = load_as_double(data, dtype, i);
+  qsort(values, (size_t)n, sizeof(double), compare_doubles);
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; i++)
+    if (m == 0 || values[i] != values[m - 1]) values[m++] = values[i];
+  *count = (int32_t)m;
+  return values;
+}
+
+/* ATen sum over a strided dimension: multi_row_sum (cpu/SumKernel.cpp, torch 2.10),
+ * one row.  Four accumulators; level 0 is dumped upwards after every level_step terms. */
+static float cascade_sum(const float* x, int64_t size) {
+  int ceil_log2 = 1;
+  if (size > 2) {
+    ceil_log2 = 0;
+    while (((int64_t)1 << ceil_log2) < size) ceil_log2++;
+  }
+  const int64_t level_power = (ceil_log2 / 4 > 4) ? ceil_log2 / 4 : 4;
+  const int64_t level_step = (int64_t)1 << level_power;
+  const int64_t level_mask = level_step - 1;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  int64_t i = 0;
+  for (; i + level_step <= size;) {
+    for (int64_t j = 0; j < level_step; ++j, ++i) acc[0] += x[i];
+    for (int j = 1; j < 4; ++j) {
+      acc[j] += acc[j - 1];
+      acc[j - 1] = 0.0f;
+      const int64_t mask = level_mask << (j * level_power);
+      if ((i & mask) != 0) break;
+    }
+  }
+  for (; i < size; ++i) acc[0] += x[i];
+  for (int j = 1; j < 4; ++j) acc[0] += acc[j];
+  return acc[0];
+}
+
+/* exported for the unit test that pins cascade_sum against torch.sum */
+float tio_oracle_cascade_sum(const float* x, int64_t size) { return cascade_sum(x, size); }
+
+/* one voxel: one-hot channel vector -> grid_sample(linear, zeros) -> argmax / sum > 0.5 */
+static void label_pv_voxel(const tio_resample_image* img, const double* labels, int32_t n_labels, float* channels,
+                           int64_t base_in, int64_t out_index, const float w[8], const int ok[8],
+                           const int64_t off[8]) {
+  for (int32_t l = 0; l < n_labels; l++) channels[l] = 0.0f;
+  for (int t = 0; t < 8; t++) {
+    if (!ok[t]) continue; /* out-of-bounds taps are skipped by grid_sampler_3d */
+    const double value = load_as_double(img->in, img->dtype, base_in + off[t]);
+    for (int32_t l = 0; l < n_labels; l++) {
+      const float one_hot = (value == labels[l]) ? 1.0f : 0.0f; /* (values == targets).float() */
+      channels[l] += one_hot * w[t];
+    }
+  }
+  int32_t winner = 0; /* argmax: first maximum */
+  for (int32_t l = 1; l < n_labels; l++)
+    if (channels[l] > channels[winner]) winner = l;
+  const int in_bounds = cascade_sum(channels, n_labels) > 0.5f;
+  store_from_double(img->out, img->dtype, out_index, in_bounds ? labels[winner] : img->pad_label);
+}
+
 int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
                           const tio_resample_image* images, void* stream) {
   (void)stream;
@@ -239,9 +328,29 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
   const int32_t ni = g->cp_shape[0], nj = g->cp_shape[1], nk = g->cp_shape[2];
   const float* spacing = g->affine_first ? g->in_spacing : g->out_spacing;
 
+  /* "label" images: torch.unique over the whole batch tensor (spatial.py:1360), unless the
+   * caller already supplies the table */
+  double* own_labels[TIO_MAX_IMAGES] = {0};
+  const double* label_table[TIO_MAX_IMAGES] = {0};
+  int32_t label_count[TIO_MAX_IMAGES] = {0};
+  int32_t max_labels = 1;
+  for (int32_t im = 0; im < n_images; im++) {
+    if (images[im].interp != TIO_LABEL_PV) continue;
+    if (images[im].channels != 1) return TIO_ERR_INVALID_ARGUMENT;
+    if (images[im].labels_dev != NULL && images[im].n_labels > 0) {
+      label_table[im] = images[im].labels_dev;
+      label_count[im] = images[im].n_labels;
+    } else {
+      own_labels[im] = unique_labels(images[im].in, images[im].dtype, (int64_t)B * n_in, &label_count[im]);
+      label_table[im] = own_labels[im];
+    }
+    if (label_count[im] > max_labels) max_labels = label_count[im];
+  }
+
 #pragma omp parallel for collapse(2) schedule(static)
   for (int32_t b = 0; b < B; b++) {
     for (int32_t io = 0; io < Io; io++) {
+      float* channels = (float*)malloc((size_t)max_labels * sizeof(float));
       const float* m = g->mapping_dev + (g->mapping_batched ? (int64_t)b * 12 : 0);
       const int pass = g->passthrough_dev && g->passthrough_dev[b];
       const int elastic = has_cp && !(g->cp_skip_dev && g->cp_skip_dev[b]);
@@ -323,6 +432,11 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
 
           for (int32_t im = 0; im < n_images; im++) {
             const tio_resample_image* img = &images[im];
+            if (img->interp == TIO_LABEL_PV) {
+              label_pv_voxel(img, label_table[im], label_count[im], channels, (int64_t)b * n_in, (int64_t)b * n_out + o_idx,
+                             w, ok, off);
+              continue;
+            }
             for (int32_t c = 0; c < img->channels; c++) {
               const int64_t base_in = ((int64_t)b * img->channels + c) * n_in;
               const int64_t base_out = ((int64_t)b * img->channels + c) * n_out;
@@ -340,8 +454,10 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
           }
         }
       }
+      free(channels);
     }
   }
+  for (int32_t im = 0; im < n_images; im++) free(own_labels[im]);
   return TIO_OK;
 }
 

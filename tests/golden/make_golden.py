@@ -90,6 +90,20 @@ CASES = [
     ("noise_f64", "Noise", dict(std=0.1), (8, 8, 8), 2, "identity", "float64", "int16"),
     ("gamma", "Gamma", dict(log_gamma=(-0.3, 0.3)), (16, 14, 12), 1, "identity", "float32", "int16"),
     ("gamma_batch_p", "Gamma", dict(log_gamma=(-0.5, 0.5), p=0.6), (10, 10, 10), 4, "identity", "float32", "int16"),
+    # label_interpolation="label": partial-volume resampling of label maps (spatial.py:1275-1389).
+    # New cases are appended so that the seeds (1000 + index) of the earlier ones never move.
+    ("affine_label_pv", "Affine", dict(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5), label_interpolation="label"), (16, 14, 12), 1, "identity", "float32", "int16"),
+    ("affine_label_pv_batch_pad7", "Affine", dict(degrees=(-25, 25), label_interpolation="label", default_pad_label=7), (12, 14, 16), 3, "aniso", "float32", "int32"),
+    ("resample_label_pv_half_voxel_ties", "Resample", dict(target=2, label_interpolation="label"), (16, 14, 12), 1, "identity", "float32", "int16"),
+    ("resample_label_pv_upsample", "Resample", dict(target=0.6, label_interpolation="label"), (10, 9, 8), 1, "identity", "float32", "uint8"),
+    ("spatial_label_pv_elastic_p", "Spatial", dict(degrees=(-10, 10), max_displacement=5.0, label_interpolation="label", p=0.6), (12, 12, 14), 4, "oblique", "float32", "int16"),
+    ("affine_label_pv_out_of_view", "Affine", dict(translation=(100.0, 0.0, 0.0), label_interpolation="label", default_pad_label=3), (8, 8, 8), 1, "identity", "float32", "int16"),
+    ("affine_label_pv_40_labels", "Affine", dict(degrees=(-20, 20), scales=(0.8, 1.2), label_interpolation="label"), (16, 16, 16), 2, "identity", "float32", "int16", "many"),
+    ("affine_label_pv_float_labels", "Affine", dict(degrees=(-15, 15), label_interpolation="label"), (12, 12, 12), 1, "identity", "float32", "float32", "many"),
+    ("resample_label_pv_antialias", "Resample", dict(target=(1.5, 0.8, 2.2), antialias=True, label_interpolation="label"), (16, 14, 12), 2, "identity", "float32", "int16"),
+    ("affine_label_pv_nearest_one_hot", "Affine", dict(degrees=(-10, 10), label_interpolation="label", one_hot_label_interpolation="nearest"), (12, 12, 12), 1, "identity", "float32", "int16"),
+    ("affine_label_pv_multichannel_int", "Affine", dict(degrees=(-10, 10), translation=(-3, 3), label_interpolation="label"), (12, 12, 12), 2, "identity", "float32", "uint8", "onehot"),
+    ("affine_label_pv_multichannel_f64", "Affine", dict(degrees=(-10, 10), label_interpolation="label", default_pad_label=2), (10, 10, 10), 1, "identity", "float32", "float64", "onehot"),
 ]
 
 COMPOSE = [
@@ -102,12 +116,27 @@ COMPOSE = [
 ]
 
 
-def make_inputs(shape, batch, kind, t1_dtype, seg_dtype, seed):
+def label_map(shape, dtype, seg_kind, element):
+    if seg_kind == "spheres":
+        return spheres(shape, dtype)
+    if seg_kind == "many":  # 40 non-contiguous label values (> 16: ATen's channel sum cascades), 4-voxel blocks
+        axes = [torch.arange(s) // 4 for s in shape]
+        i, j, k = torch.meshgrid(*axes, indexing="ij")
+        index = (i * 7 + j * 3 + k + element) % 40
+        return (index * 3 - 17).to(dtype).unsqueeze(0)
+    if seg_kind == "onehot":  # an already one-hot map: three channels
+        base = spheres(shape, torch.int16)[0]
+        return torch.stack([(base == 0), (base == 1) | (base == 2), (base >= 3)]).to(dtype)
+    raise ValueError(seg_kind)
+
+
+def make_inputs(shape, batch, kind, t1_dtype, seg_dtype, seed, seg_kind="spheres"):
     g = torch.Generator().manual_seed(seed)
     items = []
-    for _ in range(batch):
+    for element in range(batch):
         t1 = (torch.rand(2, *shape, generator=g) * 2 - 0.5).to(getattr(torch, t1_dtype))
-        items.append({"t1": t1, "seg": spheres(shape, getattr(torch, seg_dtype)), "affine": affine_matrix(kind)})
+        seg = label_map(shape, getattr(torch, seg_dtype), seg_kind, element)
+        items.append({"t1": t1, "seg": seg, "affine": affine_matrix(kind)})
     return items
 
 
@@ -141,8 +170,8 @@ def run(lib, transform, items, seed):
 
 def main():
     cases = []
-    for index, (name, cls, kwargs, shape, batch, kind, t1_dtype, seg_dtype) in enumerate(CASES):
-        items = make_inputs(shape, batch, kind, t1_dtype, seg_dtype, seed=1000 + index)
+    for index, (name, cls, kwargs, shape, batch, kind, t1_dtype, seg_dtype, *rest) in enumerate(CASES):
+        items = make_inputs(shape, batch, kind, t1_dtype, seg_dtype, seed=1000 + index, seg_kind=rest[0] if rest else "spheres")
         transform = getattr(tio, cls)(**kwargs)
         out, result = run(tio, transform, items, seed=2000 + index)
         entry = {"name": name, "cls": cls, "kwargs": kwargs, "seed": 2000 + index, "inputs": items, "expected": result}

@@ -94,8 +94,62 @@ def test_unsupported_modes_raise_instead_of_falling_back():
     s = subject()
     with pytest.raises(NotImplementedError, match="not implemented by the HIP engine"):
         tio.Affine(degrees=(5, 5), image_interpolation="cubic")(s)
-    with pytest.raises(NotImplementedError):
-        tio.Affine(degrees=(5, 5), label_interpolation="label")(s)
+    with pytest.raises(NotImplementedError, match="one_hot_label_interpolation"):
+        tio.Affine(degrees=(5, 5), label_interpolation="label", one_hot_label_interpolation="cubic")(s)
+
+
+# -- "label" partial-volume mode ------------------------------------------------------
+def test_label_mode_identity_pad_and_value_set():
+    s = subject(size=12)
+    labels = set(s.seg.data.unique().tolist())
+    out = tio.Affine(degrees=(12, 12), translation=(2, 2), label_interpolation="label", default_pad_label=9)(s)
+    assert out.seg.data.dtype == s.seg.data.dtype and out.seg.data.shape == s.seg.data.shape
+    assert set(out.seg.data.unique().tolist()) <= labels | {9}
+    # a transform with nothing to do is skipped by the envelope; a pure re-gridding onto the same grid is exact
+    same = tio.Resample(target=1.0, label_interpolation="label")(s)
+    assert torch.equal(same.seg.data, s.seg.data)
+    # everything out of view -> the pad label everywhere
+    gone = tio.Affine(translation=(500.0, 0.0, 0.0), label_interpolation="label", default_pad_label=4)(s)
+    assert bool((gone.seg.data == 4).all())
+
+
+def test_label_mode_fused_equals_materialised_one_hot():
+    """The fused kernel against the reference's four steps with the one-hot channels built.
+
+    ``antialias=True`` selects the materialised path; with an unchanged grid the smoothing has
+    sigma 0 on every axis, so both paths compute the same pipeline.
+    """
+    for seed, pad in ((3, 0), (4, 2)):
+        s = subject(size=14, seed=seed)
+        kwargs = dict(degrees=(-20, 20), scales=(0.8, 1.2), translation=(-3, 3), max_displacement=3.0,
+                      label_interpolation="label", default_pad_label=pad)
+        torch.manual_seed(seed)
+        fused = tio.Spatial(**kwargs)(s)
+        torch.manual_seed(seed)
+        materialised = tio.Spatial(antialias=True, **kwargs)(s)
+        assert torch.equal(fused.seg.data, materialised.seg.data)
+        assert torch.equal(fused.t1.data, materialised.t1.data)
+
+
+def test_cascade_sum_restatements_match_torch_sum(oracle):
+    """ATen's channel sum (multi_row_sum cascade) as restated in the oracle and on the host."""
+    import ctypes
+
+    from oracle.oracle import LIBRARY_PATH
+    from torchio_amd.transforms.spatial import _cascade_sum_channels
+
+    lib = ctypes.CDLL(LIBRARY_PATH)
+    lib.tio_oracle_cascade_sum.restype = ctypes.c_float
+    lib.tio_oracle_cascade_sum.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    generator = torch.Generator().manual_seed(5)
+    for channels in (1, 2, 5, 15, 16, 17, 33, 100, 256, 257, 300):
+        # inner extent a multiple of 32 per thread chunk: ATen's vectorised main path (its remainder columns
+        # use a different, thread-partition dependent order that nothing here reproduces)
+        x = torch.rand(2, channels, 4, 8, 256, generator=generator) * (torch.rand(2, channels, 4, 8, 256, generator=generator) < 0.2)
+        expected = x.sum(dim=1)
+        assert torch.equal(_cascade_sum_channels(x), expected), channels
+        column = x[1, :, 2, 3, 77].contiguous()
+        assert lib.tio_oracle_cascade_sum(column.data_ptr(), channels) == expected[1, 2, 3, 77].item()
 
 
 # -- envelope: copy, wrapping, scope ------------------------------------------------

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_IMAGES = 8
 
 # tio_status
@@ -18,7 +18,7 @@ UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing
 # tio_dtype (values fixed by include/tio_hip.h)
 F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
 # tio_interp
-NEAREST, LINEAR = 0, 1
+NEAREST, LINEAR, LABEL_PV = 0, 1, 2
 
 
 class ResampleGeom(C.Structure):
@@ -51,6 +51,9 @@ class ResampleImage(C.Structure):
         ("dtype", C.c_int32),
         ("interp", C.c_int32),
         ("fill_dev", C.c_void_p),
+        ("labels_dev", C.c_void_p),
+        ("n_labels", C.c_int32),
+        ("pad_label", C.c_double),
     ]
 
 

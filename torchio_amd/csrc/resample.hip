@@ -32,6 +32,10 @@ struct ImgArgs {
   int channels;
   int dtype;
   int interp;
+  // TIO_LABEL_PV only: sorted label table (may be null), its length, the pad label
+  const double* labels;
+  int n_labels;
+  double pad_label;
 };
 
 struct ResampleArgs {
@@ -176,6 +180,10 @@ __device__ __forceinline__ void sample_boundary(const ImgArgs& g, int b, int64_t
   }
 }
 
+}  // namespace tio
+#include "resample_label.hpp"
+namespace tio {
+
 // DTMODE selects which element types a kernel instantiation can sample, so that the
 // common launches do not pay registers for the rare ones: 0 = float32 only,
 // 1 = float32 + {int16, uint8, int32} (intensity + label maps), 2 = every tio_dtype.
@@ -202,7 +210,10 @@ __device__ __forceinline__ void sample_boundary(const ImgArgs& g, int b, int64_t
     }                                                           \
   }
 
-template <bool ELASTIC_POSSIBLE, int DTMODE>
+// LABEL_PV = true: the same coordinates, every image resampled in the "label"
+// partial-volume mode (resample_label.hpp); launched separately so that the intensity
+// kernels carry none of its registers.
+template <bool ELASTIC_POSSIBLE, int DTMODE, bool LABEL_PV = false>
 __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const ResampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_cp[];
 
@@ -345,6 +356,29 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
       // x0 ∈ [0, S-2] ⇔ x0 and x1 both in bounds (integral floats; NaN fails)
       interior = (x0 >= 0.0f) & (x0 <= hx - 1.0f) & (y0 >= 0.0f) & (y0 <= hy - 1.0f) & (z0 >= 0.0f) & (z0 <= hz - 1.0f);
     }
+    const int64_t o_idx = io * slab + row;
+    if constexpr (LABEL_PV) {
+      const bool bx0 = (x0 >= 0.0f) & (x0 <= hx), bx1 = (x1 >= 0.0f) & (x1 <= hx);
+      const bool by0 = (y0 >= 0.0f) & (y0 <= hy), by1 = (y1 >= 0.0f) & (y1 <= hy);
+      const bool bz0 = (z0 >= 0.0f) & (z0 <= hz), bz1 = (z1 >= 0.0f) & (z1 <= hz);
+      const int ix0 = static_cast<int>(fminf(fmaxf(x0, 0.0f), hx)), ix1 = static_cast<int>(fminf(fmaxf(x1, 0.0f), hx));
+      const int iy0 = static_cast<int>(fminf(fmaxf(y0, 0.0f), hy)), iy1 = static_cast<int>(fminf(fmaxf(y1, 0.0f), hy));
+      const int iz0 = static_cast<int>(fminf(fmaxf(z0, 0.0f), hz)), iz1 = static_cast<int>(fminf(fmaxf(z1, 0.0f), hz));
+      int off[8];
+      unsigned okbits = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool ok = ((k & 1) ? bx1 : bx0) & ((k & 2) ? by1 : by0) & ((k & 4) ? bz1 : bz0);
+        off[k] = (((k & 1) ? ix1 : ix0) * a.J + ((k & 2) ? iy1 : iy0)) * a.K + ((k & 4) ? iz1 : iz0);
+        okbits |= ok ? (1u << k) : 0u;
+      }
+      for (int im = 0; im < a.n_images; im++) {
+        const ImgArgs& g = a.img[im];
+        label_pv_voxel(g.in, g.out, g.dtype, g.labels, g.n_labels, g.pad_label, static_cast<int64_t>(b) * n_in,
+                       static_cast<int64_t>(b) * n_out + o_idx, w, off, okbits);
+      }
+      continue;
+    }
     // nearest: nearbyint = round half to even (v_rndne_f32)
     const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
     bool okn = true;
@@ -352,7 +386,6 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
       okn = (xn >= 0.0f) & (xn <= hx) & (yn >= 0.0f) & (yn <= hy) & (zn >= 0.0f) & (zn <= hz);
       interior = interior & okn;
     }
-    const int64_t o_idx = io * slab + row;
 
     if (__builtin_amdgcn_ballot_w64(!interior) == 0) {  // wave-uniform: whole wave interior
       const int base = (static_cast<int>(x0) * a.J + static_cast<int>(y0)) * a.K + static_cast<int>(z0);
@@ -458,29 +491,54 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     a.scale_j = lerp_scale(a.nj, a.Jo);
     a.scale_k = lerp_scale(a.nk, a.Ko);
   }
-  a.n_images = n_images;
+  // "label" partial-volume images go through their own launch of the gather kernel (same
+  // coordinates); everything else shares one launch of the brick / gather kernel
+  ResampleArgs pv = a;
+  a.n_images = 0;
+  pv.n_images = 0;
+  pv.any_linear = 1;
+  int dtmode = 0;
   for (int i = 0; i < n_images; i++) {
     const tio_resample_image& s = images[i];
     if (s.in == nullptr || s.out == nullptr || s.channels < 1)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d has null data or no channels", i);
     if (dtype_size(s.dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d dtype %d", i, s.dtype);
-    if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR)
+    if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR && s.interp != TIO_LABEL_PV)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d interp %d", i, s.interp);
-    a.img[i] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp};
+    if (s.interp == TIO_LABEL_PV) {
+      if (s.channels != 1)
+        return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d: TIO_LABEL_PV needs channels == 1, got %d", i, s.channels);
+      if (s.n_labels < 0 || (s.n_labels > 0 && s.labels_dev == nullptr))
+        return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d: bad label table", i);
+      pv.img[pv.n_images++] = ImgArgs{s.in, s.out, nullptr, 1, s.dtype, s.interp, s.labels_dev, s.n_labels, s.pad_label};
+      continue;
+    }
+    a.img[a.n_images++] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp, nullptr, 0, 0.0};
     // the in-bounds weight mask needs the trilinear weights even for nearest data (spatial.py:1722-1727)
     if (s.interp == TIO_LINEAR || s.fill_dev != nullptr) a.any_linear = 1;
     if (s.interp == TIO_NEAREST) a.any_nearest = 1;
+    const int need = s.dtype == TIO_F32 ? 0 : ((s.dtype == TIO_I16 || s.dtype == TIO_U8 || s.dtype == TIO_I32) ? 1 : 2);
+    dtmode = need > dtmode ? need : dtmode;
   }
   if (a.B == 0) return TIO_OK;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int dtmode = 0;
-  for (int i = 0; i < n_images; i++) {
-    const int dt = images[i].dtype;
-    const int need = dt == TIO_F32 ? 0 : ((dt == TIO_I16 || dt == TIO_U8 || dt == TIO_I32) ? 1 : 2);
-    dtmode = need > dtmode ? need : dtmode;
-  }
   const int n_cp = a.cp != nullptr ? a.ni * a.nj * a.nk * 3 : 0;
+
+  if (pv.n_images > 0) {
+    pv.tiles_k = (pv.Ko + kLanes - 1) / kLanes;
+    pv.tiles_j = (pv.Jo + kRowsPerBlock - 1) / kRowsPerBlock;
+    pv.tiles_i = (pv.Io + kTileI - 1) / kTileI;
+    const int64_t blocks = static_cast<int64_t>(pv.B) * pv.tiles_i * pv.tiles_j * pv.tiles_k;
+    if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+    const dim3 grid(static_cast<unsigned>(blocks)), block(kRowsPerBlock * kLanes);
+    const size_t lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? static_cast<size_t>(n_cp) * sizeof(float) : 0;
+    if (pv.cp != nullptr)
+      hipLaunchKernelGGL((resample_kernel<true, 2, true>), grid, block, lds, s, pv);
+    else
+      hipLaunchKernelGGL((resample_kernel<false, 2, true>), grid, block, lds, s, pv);
+    if (a.n_images == 0) return check_launch("tio_resample3d");
+  }
 
   // Path: LDS-staged bricks whenever a trilinear image is present (the 8-tap gather is
   // what the staging removes); pure nearest launches keep the one-load gather kernel.

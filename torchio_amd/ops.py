@@ -29,7 +29,7 @@ _DTYPE_CODES = {
     torch.int64: _abi.I64,
 }
 FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
-INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR}
+INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR, "label": _abi.LABEL_PV}
 
 
 def h2d(tensor: Tensor, device) -> Tensor:
@@ -126,6 +126,8 @@ class Engine:
         fills: Sequence[Tensor | None],
         cp_skip: Tensor | None = None,
         passthrough: Tensor | None = None,
+        label_tables: Sequence[Tensor | None] | None = None,
+        pad_labels: Sequence[float] | None = None,
     ) -> list[Tensor]:
         """Resample every ``(B, C, I, J, K)`` tensor in *images* through one coordinate pass.
 
@@ -133,7 +135,10 @@ class Engine:
         ``control_points`` ``(1|B, ni, nj, nk, 3)`` float32 in mm or ``None``;
         ``fills[n]`` is ``None`` (zero padding, no mask) or a ``(C,)`` float32
         tensor.  Returns new contiguous tensors ``(B, C, *out_shape)`` with the
-        input dtypes.
+        input dtypes.  Images with interpolation ``"label"`` (single channel) take the
+        fused partial-volume mode: ``label_tables[n]`` is ``torch.unique(images[n])`` as
+        float64 on the data's device (or ``None``: exact for fewer than 16 labels) and
+        ``pad_labels[n]`` the out-of-bounds label; ``fills[n]`` is ignored for them.
         """
         if not images:
             return []
@@ -195,6 +200,15 @@ class Engine:
                 descs[slot].dtype = dtype_code(data.dtype)
                 descs[slot].interp = INTERP_CODES[interp] if isinstance(interp, str) else int(interp)
                 descs[slot].fill_dev = None if fill is None else fill.data_ptr()
+                if descs[slot].interp == _abi.LABEL_PV:
+                    table = None if label_tables is None else label_tables[n]
+                    if table is not None:
+                        table = table.to(device=data.device, dtype=torch.float64).contiguous()
+                        self._check("resample3d", table)
+                        descs[slot].labels_dev = table.data_ptr()
+                        descs[slot].n_labels = table.numel()
+                    descs[slot].pad_label = 0.0 if pad_labels is None else float(pad_labels[n])
+                    keep_alive.append(table)
                 keep_alive += [data, fill]
                 outputs.append(out)
             self._call("resample3d", first, C.byref(geom), len(chunk), descs, self._stream(first))

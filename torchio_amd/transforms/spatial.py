@@ -11,9 +11,12 @@ materialising an ``(I, J, K, 3)`` grid and calling ``F.grid_sample`` twice
 floats per element (and the control points) and every selected image is
 resampled by ONE fused kernel launch (``tio_resample3d``).
 
+The ``"label"`` partial-volume mode (spatial.py:1275-1389) is fused into the same
+call for the usual case (single-channel label map, linear one-hot interpolation, no
+antialias): the ``(B, L, I, J, K)`` one-hot tensor is never built.
+
 Not implemented on the engine (raise, never fall back): interpolation orders
->= 2 (reference uses torch-interpol, spatial.py:1734-1761) and the ``"label"``
-partial-volume mode (spatial.py:1275-1389).
+>= 2 (reference uses torch-interpol, spatial.py:1734-1761).
 """
 from __future__ import annotations
 
@@ -499,43 +502,141 @@ def _apply_spatial_to_batch(
         flags = [False] * batch_size
 
     engine = ops.engine()
-    tensors, interps, fills = [], [], []
+    mapping_dev = ops.h2d(torch.from_numpy(mapping), device)
+
+    def resample(tensors, interps, fills, **label_arguments):
+        return engine.resample3d(
+            tensors,
+            out_shape=out_shape,
+            mapping=mapping_dev,
+            control_points=field_tensor,
+            in_spacing=in_affine.spacing,
+            out_spacing=out_affine.spacing,
+            affine_first=affine_first,
+            interps=interps,
+            fills=fills,
+            cp_skip=cp_skip,
+            passthrough=passthrough,
+            **label_arguments,
+        )
+
+    # every image that the fused launch can take shares ONE tio_resample3d call; the
+    # "label" partial-volume mode rides along (its own kernel inside the call) unless it needs
+    # the materialised one-hot channels (antialias, nearest one-hot interpolation)
+    tensors, interps, fills, tables, pads, fused_names = [], [], [], [], [], []
+    finished: dict[str, Tensor] = {}
     for name in image_names:
         img_batch = batch.images[name]
         is_label = issubclass(img_batch._image_class, LabelMap)
         interpolation = label_interpolation if is_label else image_interpolation
-        if interpolation == LABEL_INTERPOLATION or _ORDERS[interpolation] > 1:
+        data = img_batch.data
+        table, pad = None, 0.0
+        if interpolation == LABEL_INTERPOLATION:  # only reachable for label maps (validated by the constructors)
+            if _ORDERS[one_hot_label_interpolation] > 1:
+                raise NotImplementedError(
+                    f'one_hot_label_interpolation "{one_hot_label_interpolation}" is not implemented by the HIP engine'
+                    ' (supported: "nearest", "linear")'
+                )
+            if data.shape[1] > 1:
+                # already one-hot / probabilistic: channels resampled as they are, zero outside,
+                # floating-point result (spatial.py:1345-1358)
+                work = data.float()
+                if antialias:
+                    work = _antialias(engine, work, in_affine, out_affine)
+                if data.dtype.is_floating_point and data.dtype != torch.float32:
+                    finished[name] = resample([work], [one_hot_label_interpolation], [None])[0].to(data.dtype)
+                    continue
+                data, interpolation, fill = work, one_hot_label_interpolation, None
+            elif antialias or one_hot_label_interpolation != "linear":
+                finished[name] = _label_partial_volume_composite(
+                    engine, resample, data, in_affine, out_affine, antialias=antialias,
+                    one_hot_label_interpolation=one_hot_label_interpolation, default_pad_label=default_pad_label,
+                    passthrough_flags=flags,
+                )
+                continue
+            else:
+                fill = None
+                table = torch.unique(data).to(torch.float64)  # sorted; sizes the reference's one-hot (spatial.py:1360)
+                pad = float(default_pad_label)
+        elif _ORDERS[interpolation] > 1:
             raise NotImplementedError(
                 f'interpolation "{interpolation}" is not implemented by the HIP engine (supported: "nearest", "linear")'
             )
-        data = img_batch.data
-        fill = _fill_value(engine, img_batch, default_pad_value=default_pad_value, default_pad_label=default_pad_label)
-        if antialias and not is_label:
-            data = _antialias(engine, data, in_affine, out_affine)
+        else:
+            fill = _fill_value(engine, img_batch, default_pad_value=default_pad_value, default_pad_label=default_pad_label)
+            if antialias and not is_label:
+                data = _antialias(engine, data, in_affine, out_affine)
         tensors.append(data)
         interps.append(interpolation)
         fills.append(fill)
+        tables.append(table)
+        pads.append(pad)
+        fused_names.append(name)
 
-    outputs = engine.resample3d(
-        tensors,
-        out_shape=out_shape,
-        mapping=ops.h2d(torch.from_numpy(mapping), device),
-        control_points=field_tensor,
-        in_spacing=in_affine.spacing,
-        out_spacing=out_affine.spacing,
-        affine_first=affine_first,
-        interps=interps,
-        fills=fills,
-        cp_skip=cp_skip,
-        passthrough=passthrough,
-    )
-    for name, output in zip(image_names, outputs, strict=True):
+    if tensors:
+        label_arguments = {"label_tables": tables, "pad_labels": pads} if LABEL_INTERPOLATION in interps else {}
+        finished.update(zip(fused_names, resample(tensors, interps, fills, **label_arguments), strict=True))
+    for name in image_names:
         img_batch = batch.images[name]
         originals = list(img_batch.affines)
-        img_batch.data = output
+        img_batch.data = finished[name]
         img_batch.affines[:] = [
             originals[index] if flags[index] else out_affine.clone() for index in range(len(originals))
         ]
+
+
+def _cascade_sum_channels(sampled: Tensor) -> Tensor:
+    """``sampled.sum(dim=1)`` in the rounding order of ATen's CPU kernel, on any device.
+
+    The reference thresholds this float32 sum at 0.5 (spatial.py:1378); ATen's
+    ``cascade_sum`` adds the channels in order into one accumulator and moves it up a
+    level every 16 channels (aten/src/ATen/native/cpu/SumKernel.cpp, ``multi_row_sum``).
+    """
+    size = sampled.shape[1]
+    ceil_log2 = 1 if size <= 2 else (size - 1).bit_length()
+    power = max(4, ceil_log2 // 4)
+    step, mask = 1 << power, (1 << power) - 1
+    zeros = torch.zeros_like(sampled[:, 0])
+    levels = [zeros.clone() for _ in range(4)]
+    index = 0
+    while index + step <= size:
+        for _ in range(step):
+            levels[0] = levels[0] + sampled[:, index]
+            index += 1
+        for level in range(1, 4):
+            levels[level] = levels[level] + levels[level - 1]
+            levels[level - 1] = zeros.clone()
+            if index & (mask << (level * power)):
+                break
+    for remaining in range(index, size):
+        levels[0] = levels[0] + sampled[:, remaining]
+    for level in range(1, 4):
+        levels[0] = levels[0] + levels[level]
+    return levels[0]
+
+
+def _label_partial_volume_composite(
+    engine, resample, data: Tensor, in_affine: AffineMatrix, out_affine: AffineMatrix, *, antialias: bool,
+    one_hot_label_interpolation: str, default_pad_label: float, passthrough_flags: list[bool],
+) -> Tensor:
+    """The reference's four steps with the one-hot channels materialised (spatial.py:1360-1389).
+
+    Needed when the channels are smoothed before sampling (``antialias=True``) or sampled
+    with ``"nearest"``; the plain linear case is fused inside ``tio_resample3d`` instead.
+    """
+    labels = torch.unique(data)
+    one_hot = (data[:, :1] == labels.view(1, -1, 1, 1, 1)).float()
+    if antialias:
+        one_hot = _antialias(engine, one_hot, in_affine, out_affine)
+    sampled = resample([one_hot], [one_hot_label_interpolation], [None])[0]
+    resampled = labels[sampled.argmax(dim=1)]
+    in_bounds = _cascade_sum_channels(sampled) > 0.5
+    resampled = torch.where(in_bounds, resampled, torch.full_like(resampled, default_pad_label))
+    out = resampled.unsqueeze(1).to(data.dtype)
+    for index, keep in enumerate(passthrough_flags):
+        if keep:  # the kernel copied the one-hot rows; the labels of a gated-out element are the input's
+            out[index] = data[index]
+    return out
 
 
 def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pad_label: float) -> Tensor | None:
