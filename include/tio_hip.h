@@ -246,6 +246,49 @@ int tio_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch,
                   int32_t params_batched, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* Feeding side: dense-inference patch aggregation        */
+/* ------------------------------------------------------------------------ */
+
+typedef enum tio_overlap_mode {
+  TIO_OVERLAP_CROP = 0,    /* out[dst] = patch[src]          (aggregator.py:166-204) */
+  TIO_OVERLAP_AVERAGE = 1, /* out += patch; weights += 1     (aggregator.py:206-214) */
+  TIO_OVERLAP_HANN = 2     /* out += patch * w; weights += w (aggregator.py:216-232) */
+} tio_overlap_mode;
+
+#define TIO_MAX_PATCHES 32 /* placements per call */
+
+/* Where one patch lands: voxels [src_ini, src_ini + extent) of the patch go to
+ * [dst_ini, dst_ini + extent) of the volume (PatchLocation.to_slices(), or the trimmed
+ * centre that 'crop' keeps).  HOST memory, copied into the launch. */
+typedef struct tio_patch_placement {
+  int32_t dst_ini[3];
+  int32_t src_ini[3];
+  int32_t extent[3];
+} tio_patch_placement;
+
+/*
+ * PatchAggregator.add_batch without the D2H copy (aggregator.py:94-99 forces
+ * tensor.cpu() and accumulates with one Python slice assignment per patch).
+ *   out        (C, I, J, K) device accumulator, same dtype as the patches
+ *   weight_sum (C, I, J, K) device, same dtype; NULL for TIO_OVERLAP_CROP
+ *   patches    (n_patches, C, pi, pj, pk) device
+ *   window_*   HANN only: the three 1-D windows torch.hann_window(size + 2,
+ *              periodic=False)[1:-1] as float32 (device); the 3-D weight of a voxel
+ *              is (wi * wj) * wk in float32, the rounding of _build_hann_3d
+ *              (aggregator.py:237-245).
+ * Every volume voxel applies the patches that cover it IN PATCH ORDER, so overlaps
+ * accumulate in the reference's order (float addition does not commute) and 'crop'
+ * keeps the last writer.  Arithmetic: float64 for TIO_F64, otherwise float32 rounded to
+ * the storage dtype after every patch - what the in-place `+=` on a half tensor does.
+ * CROP copies elements and takes every dtype; AVERAGE / HANN need a floating dtype.
+ */
+int tio_patch_accumulate(void* out, void* weight_sum, int32_t dtype, int32_t channels,
+                         const int32_t vol_shape[3], const void* patches, int32_t n_patches,
+                         const int32_t patch_shape[3], const tio_patch_placement* placements_host,
+                         int32_t mode, const float* window_i_dev, const float* window_j_dev,
+                         const float* window_k_dev, void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* Introspection                                                             */
 /* ------------------------------------------------------------------------ */
 int tio_abi_version(void);

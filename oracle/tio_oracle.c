@@ -716,6 +716,72 @@ int tio_oracle_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch,
   return TIO_OK;
 }
 
+/* ------------------------------------------------------------------------ */
+/* PatchAggregator.add_batch: aggregator.py:76-232, one patch after the other  */
+/* ------------------------------------------------------------------------ */
+static inline float round_storage_f(float v, int dtype) {
+  if (dtype == TIO_F16) return half_to_float(float_to_half(v));
+  if (dtype == TIO_BF16) return bf16_to_float(float_to_bf16(v));
+  return v;
+}
+
+int tio_oracle_patch_accumulate(void* out, void* weight_sum, int32_t dtype, int32_t channels,
+                                const int32_t vol_shape[3], const void* patches, int32_t n_patches,
+                                const int32_t patch_shape[3], const tio_patch_placement* placements,
+                                int32_t mode, const float* window_i, const float* window_j,
+                                const float* window_k, void* stream) {
+  (void)stream;
+  if (!out || !patches || !placements || n_patches < 0 || n_patches > TIO_MAX_PATCHES) return TIO_ERR_INVALID_ARGUMENT;
+  const size_t es = dtype_size(dtype);
+  if (es == 0) return TIO_ERR_UNSUPPORTED_DTYPE;
+  const int is_float = dtype == TIO_F32 || dtype == TIO_F64 || dtype == TIO_F16 || dtype == TIO_BF16;
+  if (mode != TIO_OVERLAP_CROP && (!is_float || !weight_sum)) return TIO_ERR_UNSUPPORTED_DTYPE;
+  const int64_t vol_n = (int64_t)vol_shape[0] * vol_shape[1] * vol_shape[2];
+  const int64_t patch_n = (int64_t)patch_shape[0] * patch_shape[1] * patch_shape[2];
+  for (int32_t p = 0; p < n_patches; p++) { /* for idx, loc in enumerate(locations): _add_patch */
+    const tio_patch_placement* q = &placements[p];
+    for (int32_t c = 0; c < channels; c++)
+      for (int32_t di = 0; di < q->extent[0]; di++)
+        for (int32_t dj = 0; dj < q->extent[1]; dj++)
+          for (int32_t dk = 0; dk < q->extent[2]; dk++) {
+            const int32_t si = q->src_ini[0] + di, sj = q->src_ini[1] + dj, sk = q->src_ini[2] + dk;
+            const int64_t p_idx = ((int64_t)p * channels + c) * patch_n + ((int64_t)si * patch_shape[1] + sj) * patch_shape[2] + sk;
+            const int64_t v_idx = (int64_t)c * vol_n +
+                                  ((int64_t)(q->dst_ini[0] + di) * vol_shape[1] + (q->dst_ini[1] + dj)) * vol_shape[2] +
+                                  (q->dst_ini[2] + dk);
+            if (mode == TIO_OVERLAP_CROP) { /* outputs[...] = cropped */
+              memcpy((char*)out + v_idx * es, (const char*)patches + p_idx * es, es);
+            } else if (dtype == TIO_F64) {
+              double* o = (double*)out + v_idx;
+              double* n = (double*)weight_sum + v_idx;
+              const double value = ((const double*)patches)[p_idx];
+              if (mode == TIO_OVERLAP_AVERAGE) {
+                *o += value;
+                *n += 1.0;
+              } else {
+                const double w = (double)((window_i[si] * window_j[sj]) * window_k[sk]);
+                *o += value * w;
+                *n += w;
+              }
+            } else { /* float32 arithmetic, rounded to the storage dtype by the in-place op */
+              const float value = load_as_float(patches, dtype, p_idx);
+              float o = load_as_float(out, dtype, v_idx), n = load_as_float(weight_sum, dtype, v_idx);
+              if (mode == TIO_OVERLAP_AVERAGE) {
+                o = round_storage_f(o + value, dtype);
+                n = round_storage_f(n + 1.0f, dtype);
+              } else {
+                const float w = (window_i[si] * window_j[sj]) * window_k[sk];
+                o = round_storage_f(o + value * w, dtype);
+                n = round_storage_f(n + w, dtype);
+              }
+              store_from_float(out, dtype, v_idx, o);
+              store_from_float(weight_sum, dtype, v_idx, n);
+            }
+          }
+  }
+  return TIO_OK;
+}
+
 int tio_oracle_abi_version(void) { return TIO_ABI_VERSION; }
 
 int tio_oracle_num_threads(void) {

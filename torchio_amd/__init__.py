@@ -8,6 +8,13 @@ history/inverse behaviour; the compute under ``apply_transform`` runs as
 hand-written HIP kernels behind the C ABI of ``include/tio_hip.h``.
 """
 from .data import AffineMatrix
+from .data import GridSampler
+from .data import LabelSampler
+from .data import PatchAggregator
+from .data import PatchLocation
+from .data import PatchSampler
+from .data import UniformSampler
+from .data import WeightedSampler
 from .data import Image
 from .data import ImagesBatch
 from .data import LabelMap
@@ -35,6 +42,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "Affine", "AffineMatrix", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation",
-    "Gamma", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "Noise", "Resample", "ScalarImage",
-    "Spatial", "SpatialTransform", "Subject", "SubjectsBatch", "Transform", "get_noise_rng", "set_noise_rng",
+    "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise",
+    "PatchAggregator", "PatchLocation", "PatchSampler", "Resample", "ScalarImage", "Spatial", "SpatialTransform", "Subject",
+    "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "get_noise_rng", "set_noise_rng",
 ]

@@ -57,6 +57,16 @@ class ResampleImage(C.Structure):
     ]
 
 
+class PatchPlacement(C.Structure):
+    """``tio_patch_placement`` (host memory)."""
+
+    _fields_ = [("dst_ini", C.c_int32 * 3), ("src_ini", C.c_int32 * 3), ("extent", C.c_int32 * 3)]
+
+
+MAX_PATCHES = 32
+# tio_overlap_mode
+OVERLAP_CROP, OVERLAP_AVERAGE, OVERLAP_HANN = 0, 1, 2
+
 _I32x3 = C.POINTER(C.c_int32)
 
 #: name -> (restype, argtypes); names are given without the library prefix.
@@ -84,6 +94,11 @@ PROTOTYPES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_void_p,
          C.c_int32, C.c_void_p],
+    ),
+    "patch_accumulate": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, _I32x3,
+         C.POINTER(PatchPlacement), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "abi_version": (C.c_int, []),
 }

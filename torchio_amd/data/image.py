@@ -74,6 +74,27 @@ class Image:
     def dtype(self) -> torch.dtype:
         return self._data.dtype
 
+    def __getitem__(self, item):
+        """Metadata lookup (``str``) or a crop along ``(C, I, J, K)`` with the affine origin moved (image.py:832-899).
+
+        Integers keep their axis (size 1), one ``Ellipsis`` expands to full slices and missing
+        trailing indices are full slices (``normalize_index``, data/backends.py:52-106).  The
+        result is a view of the same storage on the same device - what the patch samplers
+        hand to a ``DataLoader`` or ``Queue``.
+        """
+        if isinstance(item, str):
+            if item in self.metadata:
+                return self.metadata[item]
+            raise KeyError(f"{type(self).__name__} has no metadata key {item!r}")
+        sc, si, sj, sk = _normalize_index(item)
+        cropped = self._data[sc, si, sj, sk]
+        matrix = self._affine.data.clone()
+        starts = [axis.indices(size)[0] for axis, size in zip((si, sj, sk), self.shape[1:], strict=True)]
+        matrix[:3, 3] += matrix[:3, :3] @ torch.tensor(starts, dtype=torch.float64, device=matrix.device)
+        new = type(self)(cropped, affine=AffineMatrix(matrix), **_copy.deepcopy(self.metadata))
+        new.applied_transforms = list(self.applied_transforms)
+        return new
+
     def to(self, *args, **kwargs) -> "Image":
         self._data = self._data.to(*args, **kwargs)
         return self
@@ -88,6 +109,34 @@ class Image:
 
     def __repr__(self) -> str:
         return f"{type(self).__name__}(shape={self.shape}, dtype={self.dtype}, device={self.device})"
+
+
+def _normalize_index(item, ndim: int = 4) -> tuple[slice, ...]:
+    """An index as exactly ``ndim`` slices (data/backends.py:52-106)."""
+    if isinstance(item, (int, slice)) or item is Ellipsis:
+        items = (item,)
+    elif isinstance(item, tuple):
+        items = item
+    else:
+        raise TypeError(f"Index type {type(item).__name__} not understood")
+    if sum(1 for entry in items if entry is Ellipsis) > 1:
+        raise IndexError("an index can only have a single ellipsis ('...')")
+    if any(entry is Ellipsis for entry in items):
+        position = next(index for index, entry in enumerate(items) if entry is Ellipsis)
+        fill = max(ndim - (len(items) - 1), 0)
+        items = (*items[:position], *([slice(None)] * fill), *items[position + 1 :])
+    if len(items) > ndim:
+        raise IndexError(f"Too many indices: expected at most {ndim} (C, I, J, K), got {len(items)}")
+    parsed = []
+    for entry in items:
+        if isinstance(entry, bool) or not isinstance(entry, (int, slice)):
+            raise TypeError(f"Index type {type(entry).__name__} not understood")
+        if isinstance(entry, int):  # keep the axis; slice(-1, 0) would be empty
+            parsed.append(slice(entry, None) if entry == -1 else slice(entry, entry + 1))
+        else:
+            parsed.append(entry)
+    parsed += [slice(None)] * (ndim - len(parsed))
+    return tuple(parsed)
 
 
 class ScalarImage(Image):

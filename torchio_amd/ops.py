@@ -396,6 +396,51 @@ class Engine:
         return out
 
 
+    # -- feeding side -------------------------------------------------------
+    def patch_accumulate(
+        self,
+        out: Tensor,
+        weight_sum: Tensor | None,
+        patches: Tensor,
+        placements: Sequence[tuple[Sequence[int], Sequence[int], Sequence[int]]],
+        mode: str,
+        windows: Sequence[Tensor] | None = None,
+    ) -> None:
+        """Add ``patches`` ``(N, C, pi, pj, pk)`` into the ``(C, I, J, K)`` accumulators IN PLACE, in patch order.
+
+        ``placements[n] = (dst_ini, src_ini, extent)``; ``mode`` is ``"crop"`` (element copy),
+        ``"average"`` or ``"hann"`` (then ``windows`` = three float32 1-D windows on the device).
+        """
+        if patches.ndim != 5 or out.ndim != 4 or patches.shape[1] != out.shape[0]:
+            raise ValueError(f"expected patches (N, C, i, j, k) and out (C, I, J, K), got {tuple(patches.shape)} / {tuple(out.shape)}")
+        if patches.dtype != out.dtype or (weight_sum is not None and weight_sum.dtype != out.dtype):
+            raise TypeError("patches and accumulators must share one dtype")
+        if not out.is_contiguous() or (weight_sum is not None and not weight_sum.is_contiguous()):
+            raise ValueError("accumulators must be contiguous")
+        if len(placements) != patches.shape[0]:
+            raise ValueError("one placement per patch")
+        code = {"crop": _abi.OVERLAP_CROP, "average": _abi.OVERLAP_AVERAGE, "hann": _abi.OVERLAP_HANN}[mode]
+        if code != _abi.OVERLAP_CROP and out.dtype not in FLOAT_DTYPES:
+            raise TypeError(f"overlap_mode {mode!r} needs floating-point patches, got {out.dtype}")
+        patches = patches.contiguous()
+        window_tensors = [None, None, None]
+        if code == _abi.OVERLAP_HANN:
+            window_tensors = [w.to(device=out.device, dtype=torch.float32).contiguous() for w in windows]
+        self._check("patch_accumulate", out, weight_sum, patches, *window_tensors)
+        for start in range(0, patches.shape[0], _abi.MAX_PATCHES):
+            chunk = patches[start : start + _abi.MAX_PATCHES]
+            table = (_abi.PatchPlacement * chunk.shape[0])()
+            for slot, (dst_ini, src_ini, extent) in enumerate(placements[start : start + chunk.shape[0]]):
+                table[slot].dst_ini = _i32x3(dst_ini)
+                table[slot].src_ini = _i32x3(src_ini)
+                table[slot].extent = _i32x3(extent)
+            self._call(
+                "patch_accumulate", out, _ptr(out), _ptr(weight_sum), dtype_code(out.dtype), out.shape[0],
+                _i32x3(out.shape[1:]), _ptr(chunk), chunk.shape[0], _i32x3(chunk.shape[2:]), table, code,
+                _ptr(window_tensors[0]), _ptr(window_tensors[1]), _ptr(window_tensors[2]), self._stream(out),
+            )
+
+
 _ENGINE: Engine | None = None
 
 
