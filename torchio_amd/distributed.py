@@ -41,7 +41,17 @@ def init_process_group(backend: str | None = None) -> RankInfo:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=info.rank, world_size=info.world_size)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        if backend == "nccl":
+            # bind the rank to its GPU before RCCL creates the communicator, so that barriers and
+            # collectives never have to guess the device
+            torch.cuda.set_device(info.local_rank)
+            dist.init_process_group(
+                backend=backend, rank=info.rank, world_size=info.world_size,
+                device_id=torch.device("cuda", info.local_rank),
+            )
+        else:
+            dist.init_process_group(backend=backend, rank=info.rank, world_size=info.world_size)
     return info
 
 
@@ -78,4 +88,7 @@ def aggregate_throughput(counters: torch.Tensor) -> dict:
 
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
