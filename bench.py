@@ -150,8 +150,8 @@ def load_traffic() -> float | None:
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=20)
-    parser.add_argument("--warmup", type=int, default=3)
+    parser.add_argument("--steps", type=int, default=50)
+    parser.add_argument("--warmup", type=int, default=5)
     parser.add_argument("--size", type=int, default=256)
     parser.add_argument("--batch", type=int, default=8, help="volumes per GPU per step")
     parser.add_argument("--noise-rng", choices=["reference", "philox"], default="philox")
@@ -174,6 +174,15 @@ def main() -> None:
     batch = make_batch(args.size, args.batch, 1234 + info.rank, device)
     torch.manual_seed(4321 + info.rank)
 
+    # Host-side pre-warm on tiny volumes (untimed set-up, same transforms and parameter paths): the pinned
+    # staging allocator, the dispatcher and Python's caches reach their steady state here, so the W warm-up
+    # steps below only have to warm the GPU side.  The first ~100 calls of a fresh process are 30 % slower.
+    tiny = make_batch(32, args.batch, 4321, device)
+    for _ in range(80):
+        transform(tiny)
+    del tiny
+    torch.cuda.synchronize()
+    torch.manual_seed(4321 + info.rank)
     for _ in range(args.warmup):
         transform(batch)
     torch.cuda.synchronize()

@@ -7,6 +7,7 @@
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 constexpr int ITERS = 4096;
 
 template <int OP>
@@ -14,8 +15,10 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, int i
   float a[8];
   float2_t p[8];
   int n[8];
+  unsigned long long q[8];
+  float4_t v4[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) { a[i] = seed + i + threadIdx.x; p[i] = float2_t{a[i], a[i] + 1.0f}; n[i] = iseed + i * 3 + threadIdx.x; }
+  for (int i = 0; i < 8; i++) { q[i] = i; v4[i] = float4_t{0, 0, 0, 0}; a[i] = seed + i + threadIdx.x; p[i] = float2_t{a[i], a[i] + 1.0f}; n[i] = iseed + i * 3 + threadIdx.x; }
   const float b = seed * 0.5f, c = seed * 0.25f;
   const float2_t pb = {b, b}, pc = {c, c};
   for (int it = 0; it < ITERS; it++) {
@@ -60,12 +63,20 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, int i
       if constexpr (OP == 37) asm volatile("v_med3_i32 %0, %0, %1, %1" : "+v"(n[i]) : "v"(iseed));
       if constexpr (OP == 38) asm volatile("v_max_i32 %0, %0, %1" : "+v"(n[i]) : "v"(iseed));
       if constexpr (OP == 14) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(b), "v"(c));
+      if constexpr (OP == 39) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(n[i]), "v"(iseed) : "vcc");
+      if constexpr (OP == 40) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(n[i]) : "v"(iseed));
+      if constexpr (OP == 41) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
+      if constexpr (OP == 42) asm volatile("v_sin_f32 %0, %0" : "+v"(a[i]));
+      if constexpr (OP == 43) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
+      if constexpr (OP == 44) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pb));
+      if constexpr (OP == 45) asm volatile("ds_read_b128 %0, %1" : "=v"(v4[i]) : "v"((n[i] & 255) * 16));
+      if constexpr (OP == 46) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)");
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + static_cast<float>(n[i]);
+  for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + static_cast<float>(n[i]) + static_cast<float>(q[i]) + v4[i].x + v4[i].w;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -103,6 +114,9 @@ int main() {
     run<27>("v_lshl_add_u32", d_out, w); run<29>("v_readlane_b32", d_out, w); run<37>("v_med3_i32", d_out, w); run<38>("v_max_i32", d_out, w);
     run<30>("v_mul_f32 + s_nop", d_out, w); run<31>("v_mul_f32 + s_add", d_out, w); run<34>("v_mul_f32 + v_add_u32", d_out, w);
     run<32>("ds_read2_b32", d_out, w); run<33>("ds_read_b32", d_out, w);
+    run<39>("v_mad_u64_u32", d_out, w); run<4>("v_mul_hi_u32", d_out, w); run<2>("v_mul_lo_u32", d_out, w); run<40>("v_xor_b32", d_out, w);
+    run<41>("v_log_f32", d_out, w); run<42>("v_sin_f32", d_out, w); run<43>("v_sqrt_f32", d_out, w); run<46>("v_exp_f32", d_out, w);
+    run<44>("v_pk_add_f32", d_out, w);
   }
   return 0;
 }

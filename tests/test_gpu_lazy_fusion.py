@@ -19,6 +19,14 @@ from parity_harness import use_engine
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _philox_noise():
+    """These tests draw the noise on the device; the process-wide mode is restored afterwards."""
+    previous = tio.get_noise_rng()
+    yield
+    tio.set_noise_rng(previous)
+
+
 def _run(transform, batch, seed, *, lazy: bool):
     previous = os.environ.get("TIO_NO_LAZY_FUSION")
     os.environ["TIO_NO_LAZY_FUSION"] = "0" if lazy else "1"
@@ -48,7 +56,6 @@ CHAINS = {
 @pytest.mark.parametrize("name", list(CHAINS))
 @pytest.mark.parametrize("size,batch", [(48, 3), (20, 1)])
 def test_lazy_fusion_is_bit_identical_to_separate_launches(hip, name, size, batch):
-    tio.set_noise_rng("philox")
     subjects = make_subjects(size, batch, seed=11, with_label=True)
     gpu_batch = tio.SubjectsBatch.from_subjects(subjects).to("cuda")
     transform = tio.Compose(CHAINS[name]())
@@ -61,7 +68,6 @@ def test_lazy_fusion_is_bit_identical_to_separate_launches(hip, name, size, batc
 
 
 def test_lazy_fusion_matches_oracle_and_is_invisible(oracle, hip):
-    tio.set_noise_rng("philox")
     subjects = make_subjects(32, 2, seed=13)
     transform = tio.Compose([tio.BiasField(), tio.Blur(std=(0.5, 2)), tio.Noise()])
     cpu_batch = tio.SubjectsBatch.from_subjects(copy.deepcopy(subjects))

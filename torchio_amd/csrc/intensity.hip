@@ -83,6 +83,7 @@ struct ConvArgs {
   int orig_dtype;
   int last_pass;
   int tiles_a;  // tiles along the stencil axis (axes I, J) / row groups (axis K)
+  int bcs;      // B * C (register-window marching kernel: strips are enumerated per wave)
   int radius_k;  // > 0: the J pass also applies the K taps to every row it produces (fused J+K)
   // tio_blur_fused: BiasField folded into the loads of the I pass, Noise into the stores of the last pass
   const float* bias_coarse;          // (B, C, ci, cj, ck) or nullptr
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void conv_line_kernel(const ConvArgs a) {
   const int other = blockIdx.z % n_other;
   const int bc = blockIdx.z / n_other;
   const int b = bc / a.channels;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR
   const int k = blockIdx.x * 64 + lane;
   const int n = a.axis == 0 ? a.I : a.J;        // length of the stencil axis
   const int p0 = blockIdx.y * kConvLine;         // first output position along the axis
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void conv_k_kernel(const ConvArgs a) {
   const int r = a.radius, ntaps = 2 * r + 1;
   float* s_taps = s_mem;
   const int pitch = kConvKSpan + 2 * r;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR
   float* s_row = s_mem + ((ntaps + 3) & ~3) + wave * pitch;
   const int i = blockIdx.z % a.I;
   const int bc = blockIdx.z / a.I;
@@ -218,12 +219,12 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   float* s_taps = s_mem;                                                   // ntaps
   float4* s_ring = reinterpret_cast<float4*>(s_mem + ((ntaps + 3) & ~3));  // ring x 64 float4
   // fused J+K: every wave owns one staged row (8 + 256 + 8 floats) behind the ring
-  float* s_krow = reinterpret_cast<float*>(s_ring + ring * 64) + (threadIdx.x >> 6) * 272;
+  float* s_krow = reinterpret_cast<float*>(s_ring + ring * 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 272;
   const int n_other = a.axis == 0 ? a.J : a.I;
   const int other = blockIdx.z % n_other;
   const int bc = blockIdx.z / n_other;
   const int b = bc / a.channels;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR
   const int k = blockIdx.x * 256 + 4 * lane;
   const int n = a.axis == 0 ? a.I : a.J;
   const int seg = (n + gridDim.y - 1) / gridDim.y;                 // outputs per segment (multiple of kConvStep except the last)
@@ -425,6 +426,196 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
 
 #undef TIO_FETCH_ROWS
 
+// ---- float32 fast path for radii <= 8: the stencil window lives in registers ---------------
+// Along I or J a lane only ever needs ITS OWN column's history, so nothing has to be shared:
+// every wave marches alone down one (other, b, c) strip of 256 K positions (one float4 per
+// lane) with the last 2R+1 rows in VGPRs.  The marching loop is unrolled by the window length,
+// which turns the rotating window into compile-time register names (no moves, no LDS ring, no
+// block barrier); two rows of 16-byte loads are in flight per lane.  Arithmetic and tap order
+// are those of the generic kernels.  LDS is only used by the fused K stage (one row per wave).
+constexpr int kMarchMaxRadius = 8;
+#ifndef TIO_MARCH_AHEAD
+#define TIO_MARCH_AHEAD 2
+#endif
+constexpr int kMarchAhead = TIO_MARCH_AHEAD;
+
+template <int R, bool FUSE_K, bool PRE_BIAS, bool POST_NOISE>
+__global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
+  constexpr int W = 2 * R + 1;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(4))) const float* const_float_ptr;
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* s_krow = s_mem + wave * 272;  // fused J+K: 8 + 256 + 8 floats per wave
+  (void)s_krow;
+  const int n_other = a.axis == 0 ? a.J : a.I;
+  const int strip = blockIdx.z * (kBlock / 64) + wave;
+  if (strip >= n_other * a.bcs) return;  // waves are independent: no barrier anywhere below
+  const int other = strip % n_other;
+  const int bc = strip / n_other;
+  const int b = bc / a.channels;
+  const int k = blockIdx.x * 256 + 4 * lane;
+  const int n = a.axis == 0 ? a.I : a.J;
+  const int seg = (n + gridDim.y - 1) / gridDim.y;
+  const int p_begin = blockIdx.y * seg, p_end = min(p_begin + seg, n);
+  const int64_t n_spatial = static_cast<int64_t>(a.I) * a.J * a.K;
+  const int64_t stride = a.axis == 0 ? static_cast<int64_t>(a.J) * a.K : a.K;
+  const int64_t other_stride = a.axis == 0 ? a.K : static_cast<int64_t>(a.J) * a.K;
+  const int64_t line = static_cast<int64_t>(bc) * n_spatial + other * other_stride + k;
+  const float* src = static_cast<const float*>(a.src);
+  float* dst = static_cast<float*>(a.dst);
+  if (p_begin >= p_end || k >= a.K) return;
+
+  if (a.skip != nullptr && a.skip[b] != 0) {  // rows with no blur: emitted unchanged by the last pass
+    if (a.last_pass) {
+      const float* orig = static_cast<const float*>(a.x_orig);
+      for (int p = p_begin; p < p_end; p++) {
+        const int64_t e = line + static_cast<int64_t>(p) * stride;
+        *reinterpret_cast<v4f*>(dst + e) = *reinterpret_cast<const v4f*>(orig + e);
+      }
+    }
+    return;
+  }
+  const int64_t tap_base = a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0;
+  const_float_ptr tc = (const_float_ptr)(a.taps + tap_base + static_cast<int64_t>(a.axis) * a.tap_stride);
+  const_float_ptr tk = (const_float_ptr)(a.taps + tap_base + 2 * a.tap_stride);
+  (void)tk;
+  float tw[W];  // scalar registers
+#pragma unroll
+  for (int t = 0; t < W; t++) tw[t] = tc[t];
+
+  // PRE_BIAS: the arithmetic of bias_kernel, coarse planes cached while the row stays in a cell
+  Lerp1D b_lk[4];
+  Lerp1D b_lj{0, 0, 1.0f, 0.0f};
+  float b_p0[4] = {0.f, 0.f, 0.f, 0.f}, b_p1[4] = {0.f, 0.f, 0.f, 0.f};
+  int b_cur0 = -1, b_cur1 = -1;
+  const float* b_fg = nullptr;
+  if constexpr (PRE_BIAS) {
+    b_fg = a.bias_coarse + static_cast<int64_t>(bc) * (a.bias_ci * a.bias_cj * a.bias_ck);
+    b_lj = lerp_index(other, a.bias_cj, a.J, a.bias_sj);
+#pragma unroll
+    for (int e = 0; e < 4; e++) b_lk[e] = lerp_index(min(k + e, a.K - 1), a.bias_ck, a.K, a.bias_sk);
+  }
+  auto bias_row = [&](v4f v, int pos) -> v4f {
+    if constexpr (PRE_BIAS) {
+      const Lerp1D li = lerp_index(pos, a.bias_ci, a.I, a.bias_si);
+      const int s_i = a.bias_cj * a.bias_ck, s_j = a.bias_ck;
+      auto plane = [&](int ii, float (&out)[4]) {
+        const float* r0 = b_fg + ii * s_i + b_lj.i0 * s_j;
+        const float* r1 = b_fg + ii * s_i + b_lj.i1 * s_j;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          out[e] = lerp2(lerp2(r0[b_lk[e].i0], b_lk[e].l0, r0[b_lk[e].i1], b_lk[e].l1), b_lj.l0,
+                         lerp2(r1[b_lk[e].i0], b_lk[e].l0, r1[b_lk[e].i1], b_lk[e].l1), b_lj.l1);
+      };
+      if (li.i0 != b_cur0) {
+        if (li.i0 == b_cur1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) b_p0[e] = b_p1[e];
+        } else {
+          plane(li.i0, b_p0);
+        }
+        b_cur0 = li.i0;
+      }
+      if (li.i1 != b_cur1) {
+        if (li.i1 == b_cur0) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) b_p1[e] = b_p0[e];
+        } else {
+          plane(li.i1, b_p1);
+        }
+        b_cur1 = li.i1;
+      }
+      v.x = __fmul_rn(v.x, expf(lerp2(b_p0[0], li.l0, b_p1[0], li.l1)));  // bias_field.py:341, :130
+      v.y = __fmul_rn(v.y, expf(lerp2(b_p0[1], li.l0, b_p1[1], li.l1)));
+      v.z = __fmul_rn(v.z, expf(lerp2(b_p0[2], li.l0, b_p1[2], li.l1)));
+      v.w = __fmul_rn(v.w, expf(lerp2(b_p0[3], li.l0, b_p1[3], li.l1)));
+    }
+    return v;
+  };
+#define TIO_ROW_POS(P) min(max((P), 0), n - 1) /* replicate padding == clamp */
+#define TIO_ROW_LOAD(P) (*reinterpret_cast<const v4f*>(src + line + static_cast<int64_t>(TIO_ROW_POS(P)) * stride))
+  v4f win[W];
+#pragma unroll
+  for (int t = 0; t < 2 * R; t++) win[t] = bias_row(TIO_ROW_LOAD(p_begin - R + t), TIO_ROW_POS(p_begin - R + t));
+  win[2 * R] = win[0];
+  // kMarchAhead rows of 16-byte loads in flight per lane (4 measured no faster than 2: the passes
+  // are not latency bound)
+  v4f nxt[kMarchAhead];
+#pragma unroll
+  for (int d = 0; d < kMarchAhead; d++) nxt[d] = TIO_ROW_LOAD(p_begin + R + d);
+  for (int p0 = p_begin; p0 < p_end; p0 += W) {
+#pragma unroll
+    for (int u = 0; u < W; u++) {
+      const int p = p0 + u;
+      if (p >= p_end) return;  // wave uniform
+      __builtin_amdgcn_sched_barrier(0);  // keep the rows apart: no hoisting of later rows' work into this one
+      // the newest row (p + R) replaces the oldest one; the window of output p is slots u .. u + 2R (mod W)
+      win[(2 * R + u) % W] = bias_row(nxt[0], TIO_ROW_POS(p + R));
+#pragma unroll
+      for (int d = 0; d + 1 < kMarchAhead; d++) nxt[d] = nxt[d + 1];
+      nxt[kMarchAhead - 1] = TIO_ROW_LOAD(p + R + kMarchAhead);
+      float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+      for (int t = 0; t < W; t++) {
+        const v4f v = win[(u + t) % W];
+        acc.x = __fadd_rn(acc.x, __fmul_rn(tw[t], v.x));
+        acc.y = __fadd_rn(acc.y, __fmul_rn(tw[t], v.y));
+        acc.z = __fadd_rn(acc.z, __fmul_rn(tw[t], v.z));
+        acc.w = __fadd_rn(acc.w, __fmul_rn(tw[t], v.w));
+      }
+      if constexpr (FUSE_K) {
+        // the register-window K filter of conv_k_v4_kernel on the row this wave just produced
+        const int rk = a.radius_k;
+        const float edge_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc.x), 0));
+        const float edge_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc.w), a.K / 4 - 1));
+        *reinterpret_cast<float4*>(s_krow + 8 + 4 * lane) = acc;
+        for (int h = lane; h < 2 * rk; h += a.K / 4) {  // only the K/4 lanes that own data are active here
+          if (h < rk) s_krow[8 - rk + h] = edge_l;         // replicate padding, left
+          else s_krow[8 + a.K + (h - rk)] = edge_r;        // right
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float4* rv = reinterpret_cast<const float4*>(s_krow + 8) + lane;
+        float w[20];
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+          const float4 c = rv[d - 2];
+          w[4 * d] = c.x; w[4 * d + 1] = c.y; w[4 * d + 2] = c.z; w[4 * d + 3] = c.w;
+        }
+        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int jj = 0; jj < 17; jj++) {
+          if (jj >= 8 - rk && jj <= 8 + rk) {
+            const float tv = tk[jj - (8 - rk)];
+            out.x = __fadd_rn(out.x, __fmul_rn(tv, w[jj]));
+            out.y = __fadd_rn(out.y, __fmul_rn(tv, w[jj + 1]));
+            out.z = __fadd_rn(out.z, __fmul_rn(tv, w[jj + 2]));
+            out.w = __fadd_rn(out.w, __fmul_rn(tv, w[jj + 3]));
+          }
+        }
+        acc = out;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (POST_NOISE) {  // the arithmetic of noise_kernel's 16-byte path
+          const int64_t e0 = line + static_cast<int64_t>(p) * stride;
+          float z[4];
+          philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
+          const float mu = a.noise_batched ? a.noise_mean_b[b] : a.noise_mean;
+          const float sd = a.noise_batched ? a.noise_std_b[b] : a.noise_std;
+          acc.x = __fadd_rn(acc.x, __fadd_rn(mu, __fmul_rn(sd, z[0])));
+          acc.y = __fadd_rn(acc.y, __fadd_rn(mu, __fmul_rn(sd, z[1])));
+          acc.z = __fadd_rn(acc.z, __fadd_rn(mu, __fmul_rn(sd, z[2])));
+          acc.w = __fadd_rn(acc.w, __fadd_rn(mu, __fmul_rn(sd, z[3])));
+        }
+      }
+      *reinterpret_cast<float4*>(dst + line + static_cast<int64_t>(p) * stride) = acc;
+    }
+  }
+#undef TIO_ROW_LOAD
+#undef TIO_ROW_POS
+}
+
 constexpr int kConvKRows = 16;  // rows per wave per block (axis K)
 
 __global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
@@ -438,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
   const int r4 = max((r + 3) & ~3, 8);           // aligned offset of the main part inside a staged row (>= 8: window path)
   const int pitch = kConvKSpan + 2 * r4;         // floats per wave row (multiple of 4)
   float* s_taps = s_mem;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in an SGPR
   float* s_row = s_mem + ((ntaps + 3) & ~3) + wave * (pitch + kConvKSpan);
   float* s_out = s_row + pitch;
   const int i = blockIdx.z % a.I;
@@ -642,6 +833,39 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
           a.noise_on = 1; a.noise_batched = fuse.noise_batched; a.noise_mean = fuse.noise_mean; a.noise_std = fuse.noise_std;
           a.noise_mean_b = fuse.noise_mean_b; a.noise_std_b = fuse.noise_std_b; a.noise_seed = fuse.noise_seed;
         }
+        // (the bias variant needs > 240 VGPRs beyond radius 6: the LDS ring kernel is the better choice there)
+        if (radius[axis] <= (pre_bias ? 6 : kMarchMaxRadius) && getenv("TIO_CONV_RING") == nullptr) {
+          // register-window marching: one strip per wave, enough segments for >= 8 waves per SIMD
+          a.bcs = bcs;
+          const int64_t strips = lines;
+          int want = static_cast<int>((8192 + strips - 1) / strips);
+          want = std::max(1, std::min(want, std::max(1, n / 32)));
+          if (const char* env = getenv("TIO_MARCH_SEGS")) want = std::max(1, atoi(env));  // experiments
+          const int len = (n + want - 1) / want;
+          grid.y = static_cast<unsigned>((n + len - 1) / len);
+          grid.z = static_cast<unsigned>((static_cast<int64_t>(other) * bcs + kBlock / 64 - 1) / (kBlock / 64));
+          lds = fused ? 4 * 272 * sizeof(float) : 0;
+#define TIO_MARCH_VARIANT(RR)                                                                              \
+  {                                                                                                        \
+    if (fused && post_noise) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, true>), grid, dim3(kBlock), lds, stream, a);  \
+    else if (fused) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, false>), grid, dim3(kBlock), lds, stream, a);          \
+    else if (pre_bias) hipLaunchKernelGGL((conv_march_kernel<RR, false, true, false>), grid, dim3(kBlock), lds, stream, a);       \
+    else hipLaunchKernelGGL((conv_march_kernel<RR, false, false, false>), grid, dim3(kBlock), lds, stream, a);                    \
+  }
+          switch (radius[axis]) {
+            case 1: TIO_MARCH_VARIANT(1) break;
+            case 2: TIO_MARCH_VARIANT(2) break;
+            case 3: TIO_MARCH_VARIANT(3) break;
+            case 4: TIO_MARCH_VARIANT(4) break;
+            case 5: TIO_MARCH_VARIANT(5) break;
+            case 6: TIO_MARCH_VARIANT(6) break;
+            case 7: TIO_MARCH_VARIANT(7) break;
+            default: TIO_MARCH_VARIANT(8) break;
+          }
+#undef TIO_MARCH_VARIANT
+          src = dst;
+          continue;
+        }
         lds = (((ntaps + 3) & ~3) + (2 * kConvStep + 2 * radius[axis]) * 256 + (fused ? 4 * 272 : 0)) * sizeof(float);
 #define TIO_LINE_LAUNCH(FK, PB, PN)                                                                                   \
   {                                                                                                                   \
@@ -700,7 +924,7 @@ __global__ __launch_bounds__(kBlock) void bias_kernel(const void* __restrict__ x
     __syncthreads();
   }
   const int k = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int j = blockIdx.y * (kBlock / 64) + (threadIdx.x >> 6);
+  const int j = blockIdx.y * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (k >= K || j >= J) return;
   const int i_begin = it * kBiasTileI, i_end = min(i_begin + kBiasTileI, I);
   using T = typename Elem<DT>::type;

@@ -81,7 +81,12 @@ class AffineMatrix:
         return self
 
     def clone(self) -> "AffineMatrix":
-        return AffineMatrix(self._matrix)
+        new = AffineMatrix.__new__(AffineMatrix)
+        new._matrix = self._matrix.clone()
+        cached = self._spacing_cache
+        # the copy starts at tensor version 0 with the same values: the spacing carries over
+        new._spacing_cache = (0, cached[1]) if cached is not None and cached[0] == self._matrix._version else None
+        return new
 
     def inverse(self) -> "AffineMatrix":
         return AffineMatrix(torch.linalg.inv(self._matrix))

@@ -17,6 +17,7 @@ from __future__ import annotations
 import copy as _copy
 from typing import Any
 
+import numpy as np
 from torch import Tensor
 
 
@@ -25,6 +26,8 @@ def _to_lists(value):
         return None
     if isinstance(value, Tensor):
         return value.detach().cpu().tolist()
+    if isinstance(value, np.ndarray):
+        return value.tolist()
     return [_to_lists(v) for v in value]  # per-instance list of tensors / None
 
 

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Any
 
+import math
+
 import numpy as np
 import torch
 from torch import Tensor
@@ -115,6 +117,17 @@ def _gaussian_smooth(data: Tensor, sigmas) -> Tensor:
     return result
 
 
+_OFFSETS: dict[int, Tensor] = {}
+
+
+def _tap_offsets(r: int) -> Tensor:
+    """``arange(2r + 1) - r`` as float32 (read-only, cached per radius)."""
+    offsets = _OFFSETS.get(r)
+    if offsets is None:
+        offsets = _OFFSETS[r] = torch.arange(2 * r + 1, dtype=torch.float32) - r
+    return offsets
+
+
 def _stacked_gaussian_taps(sigmas: np.ndarray, per_element: bool = False):
     """Normalised 1-D kernels for every (element, axis): ``(n, 3, stride)`` float32 taps.
 
@@ -123,30 +136,37 @@ def _stacked_gaussian_taps(sigmas: np.ndarray, per_element: bool = False):
     three sigmas are all <= 0 (restored bit-exactly, blur.py:249-251).
     """
     n = sigmas.shape[0]
-    radii = np.zeros((n, 3), dtype=np.int64)
-    positive = sigmas > 0
-    radii[positive] = np.maximum(np.ceil(3 * sigmas[positive]).astype(np.int64), 1)
-    radius = [int(radii[:, axis].max()) for axis in range(3)]
+    rows = sigmas.tolist()  # a handful of values: plain Python beats numpy's per-call overhead here
+    radii_rows = [[max(math.ceil(3 * value), 1) if value > 0 else 0 for value in row] for row in rows]
+    radius = [max(row[axis] for row in radii_rows) for axis in range(3)]
     stride = 2 * max(radius) + 1
     taps = torch.zeros(n, 3, stride, dtype=torch.float32)
+    radii = positive = None
+    if per_element:
+        radii = np.asarray(radii_rows, dtype=np.int64)
+        positive = radii > 0
     for axis in range(3):
         r = radius[axis]
         if r == 0:
             continue
-        offsets = torch.arange(2 * r + 1, dtype=torch.float32) - r
+        offsets = _tap_offsets(r)
         if not per_element:
             sigma = float(sigmas[0, axis])
             kernel = torch.exp(-0.5 * (offsets / sigma) ** 2)
             taps[0, axis, : 2 * r + 1] = kernel / kernel.sum()
             continue
         sigma_column = torch.as_tensor(sigmas[:, axis], dtype=torch.float32)[:, None]
-        radius_column = torch.as_tensor(radii[:, axis])[:, None]
-        safe = torch.where(sigma_column > 0, sigma_column, torch.ones_like(sigma_column))
+        all_active = bool(positive[:, axis].all())
+        # (the selects below are identities when every element blurs this axis / shares the radius: skipped then)
+        safe = sigma_column if all_active else torch.where(sigma_column > 0, sigma_column, torch.ones_like(sigma_column))
         kernels = torch.exp(-0.5 * (offsets[None, :] / safe) ** 2)
-        kernels = torch.where(offsets[None, :].abs() <= radius_column, kernels, torch.zeros_like(kernels))
-        delta = torch.zeros_like(kernels)
-        delta[:, r] = 1.0
-        kernels = torch.where(sigma_column > 0, kernels, delta)
+        if int(radii[:, axis].min()) != r:
+            radius_column = torch.as_tensor(radii[:, axis])[:, None]
+            kernels = torch.where(offsets[None, :].abs() <= radius_column, kernels, torch.zeros_like(kernels))
+        if not all_active:
+            delta = torch.zeros_like(kernels)
+            delta[:, r] = 1.0
+            kernels = torch.where(sigma_column > 0, kernels, delta)
         taps[:, axis, : 2 * r + 1] = kernels / kernels.sum(dim=1, keepdim=True)
     skip = None
     if per_element:

@@ -9,6 +9,9 @@ from __future__ import annotations
 
 from collections.abc import Sequence
 
+import math
+
+import numpy as np
 import torch
 from torch.distributions import Distribution
 
@@ -61,6 +64,78 @@ def _draw(spec, n: int | None, generator):
         return float(low) if n is None else torch.full((n,), float(low))
     drawn = torch.empty(1 if n is None else n).uniform_(float(low), float(high), generator=generator)
     return drawn.item() if n is None else drawn
+
+
+def _fma32(x: float, slope: float, offset: float) -> float:
+    """``fmaf(x, slope, offset)`` for float32 values held in Python floats.
+
+    ATen's CPU ``uniform_(lo, hi)`` is ``fma(u, hi - lo, lo)`` in float32 (pinned against torch
+    2.10 on 20 000 random ranges).  The product of two float32 values is exact in float64; the
+    float64 sum and its exact error (TwoSum) then decide the float32 rounding: the only case
+    where rounding the float64 sum again could disagree with a true fma is a sum that sits
+    exactly on a float32 midpoint while the error term is non-zero (the 24-bit uniforms make
+    exact midpoints common, so this path is real).
+    """
+    product = x * slope
+    total = product + offset
+    rounded = float(np.float32(total))
+    if rounded != total:
+        virtual = total - product
+        error = (product - (total - virtual)) + (offset - virtual)  # exact: product + offset == total + error
+        if error != 0.0:
+            neighbour = float(np.nextafter(np.float32(rounded), np.float32(math.inf if total > rounded else -math.inf)))
+            if (rounded + neighbour) / 2 == total:  # float64 sum on a float32 midpoint: the error term breaks the tie
+                return max(rounded, neighbour) if error > 0 else min(rounded, neighbour)
+    return rounded
+
+
+class ScalarDrawPlan:
+    """Several ``_ParameterRange.sample()`` calls in a row as ONE small ``uniform_`` call.
+
+    ``torch.empty(n).uniform_(0, 1)`` for ``n < 16`` consumes the CPU generator exactly like
+    ``n`` successive one-element draws (ATen's serial path), and ``uniform_(lo, hi)`` is
+    ``fma(u, hi - lo, lo)``; so the values - and the generator state afterwards - are those of
+    the reference's one-draw-per-axis sequence (parameter_range.py:97-106) at a fraction of the
+    Python / dispatcher cost.  Only number and ``(lo, hi)`` axis specs qualify.
+    """
+
+    def __init__(self, axes: list) -> None:
+        self.entries = []  # (constant, slope, offset): constant is None for a random axis
+        for axis in axes:
+            if _is_number(axis):
+                self.entries.append((float(axis), 0.0, 0.0))
+            else:
+                low, high = axis
+                if low == high:
+                    self.entries.append((float(low), 0.0, 0.0))
+                else:
+                    low32, high32 = np.float32(low), np.float32(high)
+                    self.entries.append((None, float(np.float32(high32 - low32)), float(low32)))
+        self.n_random = sum(1 for constant, _, _ in self.entries if constant is None)
+
+    @staticmethod
+    def build(ranges: list, counts: list[int]) -> "ScalarDrawPlan | None":
+        """Plan for the first ``counts[i]`` axes of each range, or ``None`` if any spec needs the general path."""
+        axes = []
+        for parameter_range, count in zip(ranges, counts, strict=True):
+            for axis in parameter_range._axes[:count]:
+                if not (_is_number(axis) or isinstance(axis, tuple)):
+                    return None
+                axes.append(axis)
+        plan = ScalarDrawPlan(axes)
+        return plan if plan.n_random < 16 else None  # >= 16 values take ATen's vectorised path: different stream
+
+    def sample(self) -> list[float]:
+        uniforms = torch.empty(self.n_random).uniform_(0.0, 1.0).tolist() if self.n_random else []
+        position = 0
+        values = []
+        for constant, slope, offset in self.entries:
+            if constant is not None:
+                values.append(constant)
+            else:
+                values.append(_fma32(uniforms[position], slope, offset))
+                position += 1
+        return values
 
 
 def _parse_axis(spec):

@@ -20,6 +20,7 @@ Not implemented on the engine (raise, never fall back): interpolation orders
 """
 from __future__ import annotations
 
+import math
 import warnings
 from dataclasses import dataclass
 from numbers import Number
@@ -39,6 +40,7 @@ from ..data.image import Image
 from ..data.image import LabelMap
 from .blur import _stacked_gaussian_taps
 from .parameter_range import Choice
+from .parameter_range import ScalarDrawPlan
 from .parameter_range import _ParameterRange
 from ._lazy_params import LazyParams
 from .transform import SpatialTransform
@@ -135,14 +137,38 @@ class Spatial(SpatialTransform):
 
     # -- sampling: global-RNG order is scales, degrees, translation, max_displacement,
     #    control points (spatial.py:382-434) ----------------------------------
-    def _sample_one(self, shape, affine):
-        if self.isotropic:
-            value = self.scales.sample_1d()
-            scales = (value, value, value)
+    def _scalar_plan(self):
+        """All scalar draws of one element as one small ``uniform_`` call (same values, same RNG state)."""
+        draw_displacement = self.control_points is None
+        key = (id(self.scales), id(self.degrees), id(self.translation), id(self.max_displacement), self.isotropic, draw_displacement)
+        cached = self.__dict__.get("_scalar_plan_cache")
+        if cached is None or cached[0] != key:
+            ranges = [self.scales, self.degrees, self.translation] + ([self.max_displacement] if draw_displacement else [])
+            counts = [1 if self.isotropic else 3, 3, 3] + ([3] if draw_displacement else [])
+            cached = (key, ScalarDrawPlan.build(ranges, counts))
+            self.__dict__["_scalar_plan_cache"] = cached
+        return cached[1]
+
+    def _sample_one(self, shape, affine, *, build: bool = True):
+        """Parameters of one element; with ``build=False`` the affine is returned as its three tuples."""
+        plan = self._scalar_plan()
+        displacement = None
+        if plan is not None:
+            values = plan.sample()
+            n_scale = 1 if self.isotropic else 3
+            scales = (values[0],) * 3 if self.isotropic else tuple(values[:3])
+            degrees = tuple(values[n_scale : n_scale + 3])
+            translation = tuple(values[n_scale + 3 : n_scale + 6])
+            if self.control_points is None:
+                displacement = tuple(values[n_scale + 6 : n_scale + 9])
         else:
-            scales = self.scales.sample()
-        degrees = self.degrees.sample()
-        translation = self.translation.sample()
+            if self.isotropic:
+                value = self.scales.sample_1d()
+                scales = (value, value, value)
+            else:
+                scales = self.scales.sample()
+            degrees = self.degrees.sample()
+            translation = self.translation.sample()
         has_affine = not (
             _all_close(scales, 1.0) and _all_close(degrees, 0.0) and _all_close(translation, 0.0)
         )
@@ -150,16 +176,19 @@ class Spatial(SpatialTransform):
             field = self.control_points.clone()
             displacement = _max_abs_displacement(field)
         else:
-            displacement = self.max_displacement.sample()
+            if displacement is None:
+                displacement = self.max_displacement.sample()
             if all(value == 0.0 for value in displacement):
                 field, displacement = None, None
             else:
                 field = _sample_control_points(self.num_control_points, displacement, self.locked_borders)
         forward = None
         if has_affine:
-            forward = _build_forward_affine(
-                scales=scales, degrees=degrees, translation=translation, center=self.center, shape=shape, affine=affine
-            )
+            forward = (scales, degrees, translation)
+            if build:
+                forward = _build_forward_affine(
+                    scales=scales, degrees=degrees, translation=translation, center=self.center, shape=shape, affine=affine
+                )
         return forward, field, displacement, (has_affine or field is not None)
 
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
@@ -198,15 +227,18 @@ class Spatial(SpatialTransform):
             if keep is not None and not bool(keep[index]):
                 matrices.append(None), fields.append(None), displacements.append(None)
                 continue
-            forward, field, displacement, has_geometry = self._sample_one(shape, affine)
+            forward, field, displacement, has_geometry = self._sample_one(shape, affine, build=False)
             any_geometry = any_geometry or has_geometry
-            matrices.append(None if forward is None else forward.tolist())
+            matrices.append(forward)
             fields.append(None if field is None else field.detach().to(device="cpu", dtype=torch.float32))
             displacements.append(list(displacement) if displacement else None)
         if any_geometry:
             _check_shared_space(images, shape, affine)
         params["target"] = _serialize_space(_resolve_target_space(self.target, batch, shape, affine))
-        params["affine_matrix"] = matrices
+        # all elements' world affines in one vectorised pass; nested lists only if somebody reads the history
+        built = _build_forward_affines([m for m in matrices if m is not None], center=self.center, shape=shape, affine=affine)
+        rows = iter(built)
+        params.set_lazy("affine_matrix", _MatrixList([None if m is None else next(rows) for m in matrices]))
         params.set_lazy("control_points", fields)  # nested lists only if somebody reads the history
         params["max_displacement"] = displacements
         self._tag_batched(params, batch, n, keep, ["affine_matrix", "control_points", "max_displacement"])
@@ -464,12 +496,14 @@ def _apply_spatial_to_batch(
         matrices, fields, displacements = per_sample.affine_matrices, per_sample.control_points, per_sample.max_displacements
 
     # output voxel -> input voxel: inv(A_in) @ inv(T) @ A_out in float64, cast to float32 (spatial.py:1582-1601)
+    # (stacked: numpy runs the same LAPACK / BLAS routine per 4x4 slice as the one-at-a-time form)
     in_inverse = np.linalg.inv(in_affine.numpy())
     out_matrix = out_affine.numpy()
-    mapping = np.empty((len(matrices), 3, 4), dtype=np.float32)
-    for index, matrix in enumerate(matrices):
-        transform_inverse = np.eye(4) if matrix is None else np.linalg.inv(np.asarray(matrix, dtype=np.float64))
-        mapping[index] = (in_inverse @ transform_inverse @ out_matrix)[:3].astype(np.float32)
+    world = np.stack([np.eye(4) if matrix is None else np.asarray(matrix, dtype=np.float64) for matrix in matrices])
+    present = [index for index, matrix in enumerate(matrices) if matrix is not None]
+    if present:
+        world[present] = np.linalg.inv(world[present])
+    mapping = ((in_inverse @ world) @ out_matrix)[:, :3].astype(np.float32)
 
     out_spacing = np.asarray(out_affine.spacing, dtype=np.float64)
     field_tensor = None
@@ -581,7 +615,10 @@ def _apply_spatial_to_batch(
         originals = list(img_batch.affines)
         img_batch.data = finished[name]
         img_batch.affines[:] = [
-            originals[index] if flags[index] else out_affine.clone() for index in range(len(originals))
+            # every resampled element adopts the output grid (spatial.py:1100-1107); when that IS the element's
+            # grid already (no target: the shared-space check has passed) the object is kept instead of cloned
+            originals[index] if flags[index] or (target_space is None and originals[index] is out_affine) else out_affine.clone()
+            for index in range(len(originals))
         ]
 
 
@@ -754,6 +791,49 @@ def _build_forward_affine(*, scales, degrees, translation, center, shape, affine
     return transform
 
 
+def _build_forward_affines(parameters: list, *, center, shape, affine: AffineMatrix) -> np.ndarray:
+    """``_build_forward_affine`` for a list of ``(scales, degrees, translation)`` at once -> ``(n, 4, 4)`` float64.
+
+    Same float64 operations per element (numpy's stacked ``@`` runs the same 3x3 / 4x4
+    products), so each matrix equals the one-at-a-time result bit for bit.
+    """
+    n = len(parameters)
+    if n == 0:
+        return np.zeros((0, 4, 4), dtype=np.float64)
+    scaling = np.array([p[0] for p in parameters], dtype=np.float64)
+    rotation = np.array([p[1] for p in parameters], dtype=np.float64)
+    shift = np.array([p[2] for p in parameters], dtype=np.float64)
+    if shape[-1] == 1:  # 2-D slice: suppress out-of-plane components
+        scaling[:, 2] = 1.0
+        rotation[:, :2] = 0.0
+        shift[:, 2] = 0.0
+    radians = np.radians(rotation)
+    cos, sin = np.cos(radians), np.sin(radians)
+    zeros, ones = np.zeros(n), np.ones(n)
+    rx = np.stack([ones, zeros, zeros, zeros, cos[:, 0], -sin[:, 0], zeros, sin[:, 0], cos[:, 0]], axis=1).reshape(n, 3, 3)
+    ry = np.stack([cos[:, 1], zeros, sin[:, 1], zeros, ones, zeros, -sin[:, 1], zeros, cos[:, 1]], axis=1).reshape(n, 3, 3)
+    rz = np.stack([cos[:, 2], -sin[:, 2], zeros, sin[:, 2], cos[:, 2], zeros, zeros, zeros, ones], axis=1).reshape(n, 3, 3)
+    diagonal = np.zeros((n, 3, 3), dtype=np.float64)
+    diagonal[:, [0, 1, 2], [0, 1, 2]] = scaling
+    rotation_scale = ((rz @ ry) @ rx) @ diagonal
+    transform = np.zeros((n, 4, 4), dtype=np.float64)
+    transform[:, 3, 3] = 1.0
+    transform[:, :3, :3] = rotation_scale
+    if center == "image":
+        matrix = affine.numpy()
+        center_world = matrix[:3, 3] + matrix[:3, :3] @ ((np.asarray(shape, dtype=np.float64) - 1) / 2)
+        transform[:, :3, 3] = center_world - (rotation_scale @ center_world[:, None])[:, :, 0]
+    transform[:, :3, 3] += shift
+    return transform
+
+
+class _MatrixList(list):
+    """Per-element 4x4 world affines (``np.ndarray`` or ``None``) that serialise as nested lists."""
+
+    def tolist(self) -> list:
+        return [None if m is None else m.tolist() for m in self]
+
+
 def _all_close(values, target: float) -> bool:
     """``np.allclose(values, target)`` (rtol 1e-5, atol 1e-8) for a short tuple of Python floats."""
     bound = 1e-8 + 1e-5 * abs(target)
@@ -780,6 +860,19 @@ def _interior_mask(grid_shape, locked_borders: int) -> Tensor:
     return mask
 
 
+_SCALES: dict[tuple, Tensor] = {}
+
+
+def _displacement_scale(max_displacement: tuple) -> Tensor:
+    """``2 * max_displacement`` as a float32 tensor (read-only; constant ranges hit the cache every time)."""
+    scale = _SCALES.get(max_displacement)
+    if scale is None:
+        if len(_SCALES) > 256:
+            _SCALES.clear()
+        scale = _SCALES[max_displacement] = torch.tensor([2.0 * m for m in max_displacement], dtype=torch.float32)
+    return scale
+
+
 def _sample_control_points(grid_shape, max_displacement, locked_borders: int) -> Tensor:
     """``U(-max, +max)`` per axis from ONE ``torch.rand(ni, nj, nk, 3)`` draw; outer layers zeroed.
 
@@ -789,7 +882,7 @@ def _sample_control_points(grid_shape, max_displacement, locked_borders: int) ->
     """
     field = torch.rand(*grid_shape, 3, dtype=torch.float32)
     field -= 0.5
-    field *= torch.tensor([2.0 * float(m) for m in max_displacement], dtype=torch.float32)
+    field *= _displacement_scale(tuple(float(m) for m in max_displacement))
     if locked_borders > 0:
         field = torch.where(_interior_mask(grid_shape, locked_borders), field, torch.zeros((), dtype=torch.float32))
     return field
@@ -802,14 +895,16 @@ def _max_abs_displacement(control_points: Tensor) -> tuple[float, float, float]:
 
 def _check_folding(control_points: np.ndarray, max_displacement, shape, spacing: np.ndarray) -> None:
     """Warn when the displacement exceeds half the coarse-grid spacing (spatial.py:2192-2216)."""
-    mesh = np.array(control_points.shape[:-1], dtype=np.float64) - _SPLINE_ORDER
-    grid_spacing = np.array(shape, dtype=np.float64) * spacing / mesh
-    conflicts = np.array(max_displacement, dtype=np.float64) > grid_spacing / 2
-    if np.any(conflicts):
-        (where,) = np.where(conflicts)
+    where = []
+    for axis in range(3):  # plain floats with numpy's division-by-zero results (a 3-point grid has mesh 0)
+        extent, mesh = float(shape[axis]) * float(spacing[axis]), float(control_points.shape[axis]) - _SPLINE_ORDER
+        grid_spacing = extent / mesh if mesh != 0 else (math.copysign(math.inf, extent) if extent != 0 else math.nan)
+        if float(max_displacement[axis]) > grid_spacing / 2:
+            where.append(axis)
+    if where:
         warnings.warn(
             "The maximum displacement is larger than half the coarse-grid"
-            f" spacing for dimensions {where.tolist()}, so folding may occur",
+            f" spacing for dimensions {where}, so folding may occur",
             RuntimeWarning,
             stacklevel=4,
         )
@@ -849,7 +944,8 @@ def _resolve_spatial_params(params: dict[str, Any]):
             displacement_of(params["max_displacement"]),
             None,
         )
-    matrices = [matrix_of(m) for m in params["affine_matrix"]]
+    parked_matrices, raw_matrices = params.raw("affine_matrix") if isinstance(params, LazyParams) else (False, None)
+    matrices = list(raw_matrices) if parked_matrices else [matrix_of(m) for m in params["affine_matrix"]]
     fields = list(raw_fields) if parked else [field_of(c) for c in params["control_points"]]
     displacements = [displacement_of(d) for d in params["max_displacement"]]
     if all(m is None for m in matrices) and all(f is None for f in fields):
