@@ -449,12 +449,16 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
   float* s_krow = s_mem + wave * 272;  // fused J+K: 8 + 256 + 8 floats per wave
   (void)s_krow;
   const int n_other = a.axis == 0 ? a.J : a.I;
-  const int strip = blockIdx.z * (kBlock / 64) + wave;
+  // block order (tiles_a): 1 = strips along grid.x (consecutive blocks work on adjacent strips of the
+  // same segment: their rows are adjacent in memory), 0 = strips along grid.z
+  const int strip_block = a.tiles_a ? blockIdx.x : blockIdx.z;
+  const int k_tile = a.tiles_a ? blockIdx.z : blockIdx.x;
+  const int strip = strip_block * (kBlock / 64) + wave;
   if (strip >= n_other * a.bcs) return;  // waves are independent: no barrier anywhere below
   const int other = strip % n_other;
   const int bc = strip / n_other;
   const int b = bc / a.channels;
-  const int k = blockIdx.x * 256 + 4 * lane;
+  const int k = k_tile * 256 + 4 * lane;
   const int n = a.axis == 0 ? a.I : a.J;
   const int seg = (n + gridDim.y - 1) / gridDim.y;
   const int p_begin = blockIdx.y * seg, p_end = min(p_begin + seg, n);
@@ -845,6 +849,9 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
           grid.y = static_cast<unsigned>((n + len - 1) / len);
           grid.z = static_cast<unsigned>((static_cast<int64_t>(other) * bcs + kBlock / 64 - 1) / (kBlock / 64));
           lds = fused ? 4 * 272 * sizeof(float) : 0;
+          a.tiles_a = 0;
+          if (const char* env = getenv("TIO_MARCH_ORDER")) a.tiles_a = atoi(env) != 0;  // experiments
+          if (a.tiles_a) std::swap(grid.x, grid.z);
 #define TIO_MARCH_VARIANT(RR)                                                                              \
   {                                                                                                        \
     if (fused && post_noise) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, true>), grid, dim3(kBlock), lds, stream, a);  \
