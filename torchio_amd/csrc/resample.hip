@@ -358,24 +358,14 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
     }
     const int64_t o_idx = io * slab + row;
     if constexpr (LABEL_PV) {
-      const bool bx0 = (x0 >= 0.0f) & (x0 <= hx), bx1 = (x1 >= 0.0f) & (x1 <= hx);
-      const bool by0 = (y0 >= 0.0f) & (y0 <= hy), by1 = (y1 >= 0.0f) & (y1 <= hy);
-      const bool bz0 = (z0 >= 0.0f) & (z0 <= hz), bz1 = (z1 >= 0.0f) & (z1 <= hz);
-      const int ix0 = static_cast<int>(fminf(fmaxf(x0, 0.0f), hx)), ix1 = static_cast<int>(fminf(fmaxf(x1, 0.0f), hx));
-      const int iy0 = static_cast<int>(fminf(fmaxf(y0, 0.0f), hy)), iy1 = static_cast<int>(fminf(fmaxf(y1, 0.0f), hy));
-      const int iz0 = static_cast<int>(fminf(fmaxf(z0, 0.0f), hz)), iz1 = static_cast<int>(fminf(fmaxf(z1, 0.0f), hz));
-      int off[8];
-      unsigned okbits = 0;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const bool ok = ((k & 1) ? bx1 : bx0) & ((k & 2) ? by1 : by0) & ((k & 4) ? bz1 : bz0);
-        off[k] = (((k & 1) ? ix1 : ix0) * a.J + ((k & 2) ? iy1 : iy0)) * a.K + ((k & 4) ? iz1 : iz0);
-        okbits |= ok ? (1u << k) : 0u;
-      }
       for (int im = 0; im < a.n_images; im++) {
         const ImgArgs& g = a.img[im];
-        label_pv_voxel(g.in, g.out, g.dtype, g.labels, g.n_labels, g.pad_label, static_cast<int64_t>(b) * n_in,
-                       static_cast<int64_t>(b) * n_out + o_idx, w, off, okbits);
+        LabelSite site;
+        site.in = g.in; site.out = g.out; site.labels = g.labels; site.pad_label = g.pad_label;
+        site.in_base = static_cast<int64_t>(b) * n_in; site.out_index = static_cast<int64_t>(b) * n_out + o_idx;
+        site.dtype = g.dtype; site.n_labels = g.n_labels; site.J = a.J; site.K = a.K;
+        site.hx = hx; site.hy = hy; site.hz = hz;
+        label_pv_voxel(site, x, y, z);
       }
       continue;
     }

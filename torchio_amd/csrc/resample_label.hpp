@@ -100,15 +100,116 @@ struct CascadeSum {
   }
 };
 
-// w / off / okbits: the 8 trilinear taps exactly as the boundary path of the intensity
-// sampler computes them (weights, clamped element offsets, in-bounds bits).
-__device__ __noinline__ void label_pv_voxel(const void* in, void* out, int dtype, const double* labels, int n_labels,
-                                            double pad_label, int64_t in_base, int64_t out_index, const float* w8,
-                                            const int* off8, unsigned okbits) {
+__device__ __forceinline__ uint64_t label_bits(const void* p, int es, int64_t i) {
+  switch (es) {
+    case 1: return static_cast<const uint8_t*>(p)[i];
+    case 2: return static_cast<const uint16_t*>(p)[i];
+    case 4: return static_cast<const uint32_t*>(p)[i];
+    default: return static_cast<const uint64_t*>(p)[i];
+  }
+}
+
+// Everything a voxel needs besides its coordinates (plain scalars: nothing lives in memory,
+// so the call to the general path below does not force the caller's arrays into scratch).
+struct LabelSite {
+  const void* in;
+  void* out;
+  const double* labels;
+  double pad_label;
+  int64_t in_base, out_index;
+  int dtype, n_labels;
+  int J, K;
+  float hx, hy, hz;  // input size - 1 per axis
+};
+
+// the 8 trilinear taps of ATen's grid_sampler_3d at (x, y, z): weights, clamped element offsets,
+// in-bounds bits — the boundary path of the intensity sampler (resample.hip)
+__device__ __forceinline__ unsigned label_taps(const LabelSite& s, float x, float y, float z, float (&w)[8], int (&off)[8]) {
+  const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+  const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+  const float wx0 = x1 - x, wx1 = x - x0;
+  const float wy0 = y1 - y, wy1 = y - y0;
+  const float wz0 = z1 - z, wz1 = z - z0;
+  w[0] = __fmul_rn(__fmul_rn(wx0, wy0), wz0);
+  w[1] = __fmul_rn(__fmul_rn(wx1, wy0), wz0);
+  w[2] = __fmul_rn(__fmul_rn(wx0, wy1), wz0);
+  w[3] = __fmul_rn(__fmul_rn(wx1, wy1), wz0);
+  w[4] = __fmul_rn(__fmul_rn(wx0, wy0), wz1);
+  w[5] = __fmul_rn(__fmul_rn(wx1, wy0), wz1);
+  w[6] = __fmul_rn(__fmul_rn(wx0, wy1), wz1);
+  w[7] = __fmul_rn(__fmul_rn(wx1, wy1), wz1);
+  const bool bx0 = (x0 >= 0.0f) & (x0 <= s.hx), bx1 = (x1 >= 0.0f) & (x1 <= s.hx);
+  const bool by0 = (y0 >= 0.0f) & (y0 <= s.hy), by1 = (y1 >= 0.0f) & (y1 <= s.hy);
+  const bool bz0 = (z0 >= 0.0f) & (z0 <= s.hz), bz1 = (z1 >= 0.0f) & (z1 <= s.hz);
+  const int ix0 = static_cast<int>(fminf(fmaxf(x0, 0.0f), s.hx)), ix1 = static_cast<int>(fminf(fmaxf(x1, 0.0f), s.hx));
+  const int iy0 = static_cast<int>(fminf(fmaxf(y0, 0.0f), s.hy)), iy1 = static_cast<int>(fminf(fmaxf(y1, 0.0f), s.hy));
+  const int iz0 = static_cast<int>(fminf(fmaxf(z0, 0.0f), s.hz)), iz1 = static_cast<int>(fminf(fmaxf(z1, 0.0f), s.hz));
+  unsigned okbits = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const bool ok = ((k & 1) ? bx1 : bx0) & ((k & 2) ? by1 : by0) & ((k & 4) ? bz1 : bz0);
+    off[k] = (((k & 1) ? ix1 : ix0) * s.J + ((k & 2) ? iy1 : iy0)) * s.K + ((k & 4) ? iz1 : iz0);
+    okbits |= ok ? (1u << k) : 0u;
+  }
+  return okbits;
+}
+
+__device__ __forceinline__ void label_pv_voxel_general(LabelSite s, float x, float y, float z);
+
+// Fast path: every in-bounds tap carries the same element (the interior of a label region,
+// i.e. almost every voxel).  Then exactly one one-hot channel is non-zero, its value is the
+// tap-order sum of the in-bounds weights, it wins the argmax, and the channel sum IS that
+// value (a single non-zero term survives every level of the cascade unchanged).
+template <typename RAW>
+__device__ __forceinline__ void label_pv_voxel_sized(const LabelSite& s, float x, float y, float z) {
+  float w[8];
+  int off[8];
+  const unsigned okbits = label_taps(s, x, y, z, w, off);
+  const RAW* p = static_cast<const RAW*>(s.in) + s.in_base;
+  RAW bits[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) bits[k] = p[off[k]];  // offsets are clamped into the volume: all 8 loads issue together
+  RAW first = 0;
+  bool have = false, uniform = true;
+  float value = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const bool ok = (okbits >> k) & 1u;
+    first = (ok && !have) ? bits[k] : first;
+    have |= ok;
+    uniform &= !ok || bits[k] == first;  // (+0.0 / -0.0 float labels differ in bits: they take the general path)
+    value = ok ? __fadd_rn(value, w[k]) : value;
+  }
+  if (!uniform) {
+    label_pv_voxel_general(s, x, y, z);
+    return;
+  }
+  if (have && value > 0.5f) {
+    static_cast<RAW*>(s.out)[s.out_index] = first;
+  } else {
+    store_pad_label(s.out, s.dtype, s.out_index, s.pad_label);
+  }
+}
+
+__device__ __forceinline__ void label_pv_voxel(const LabelSite& s, float x, float y, float z) {
+  switch (dtype_size(s.dtype)) {  // launch uniform: one scalar branch, then straight-line loads
+    case 1: label_pv_voxel_sized<uint8_t>(s, x, y, z); break;
+    case 2: label_pv_voxel_sized<uint16_t>(s, x, y, z); break;
+    case 4: label_pv_voxel_sized<uint32_t>(s, x, y, z); break;
+    default: label_pv_voxel_sized<uint64_t>(s, x, y, z); break;
+  }
+}
+
+// General path (mixed neighbourhood).  Everything is indexed statically — the 8 keys, values and
+// offsets stay in registers — and the call is inlined into the dedicated label kernel.
+__device__ __forceinline__ void label_pv_voxel_general(LabelSite s, float x, float y, float z) {
+  float w8[8];
+  int off8[8];
+  const unsigned okbits = label_taps(s, x, y, z, w8, off8);
   double key[8];
   float value[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) key[k] = ((okbits >> k) & 1u) ? label_key(in, dtype, in_base + off8[k]) : 0.0;
+  for (int k = 0; k < 8; k++) key[k] = ((okbits >> k) & 1u) ? label_key(s.in, s.dtype, s.in_base + off8[k]) : 0.0;
   // channel value of tap k's label: in-bounds weights of equal-label taps, tap order, from 0
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -121,39 +222,50 @@ __device__ __noinline__ void label_pv_voxel(const void* in, void* out, int dtype
     value[k] = v;
   }
   // argmax over the channels: first maximum = smallest label among the maximal ones
-  int best = -1;
+  bool have_best = false;
+  float best_value = 0.0f;
+  double best_key = 0.0;
+  int best_off = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    if (!((okbits >> k) & 1u)) continue;
-    if (best < 0 || value[k] > value[best] || (value[k] == value[best] && key[k] < key[best])) best = k;
+    const bool ok = (okbits >> k) & 1u;
+    const bool better = ok && (!have_best || value[k] > best_value || (value[k] == best_value && key[k] < best_key));
+    best_value = better ? value[k] : best_value;
+    best_key = better ? key[k] : best_key;
+    best_off = better ? off8[k] : best_off;
+    have_best |= ok;
   }
-  // channel sum over the distinct labels in ascending order
+  // channel sum over the distinct labels in ascending order; positions only matter once the
+  // cascade dumps (16 channels or more)
   CascadeSum sum;
-  sum.init(n_labels > 0 ? n_labels : 1);
+  sum.init(s.n_labels > 0 ? s.n_labels : 1);
+  const bool ranked = s.labels != nullptr && s.n_labels >= 16;
   double last = 0.0;
   bool have_last = false;
+#pragma unroll 1
   for (int round = 0; round < 8; round++) {
-    int next = -1;
+    bool found = false;
+    double next_key = 0.0;
+    float next_value = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      if (!((okbits >> k) & 1u)) continue;
-      if (have_last && !(key[k] > last)) continue;
-      if (next < 0 || key[k] < key[next]) next = k;
+      const bool candidate = ((okbits >> k) & 1u) && (!have_last || key[k] > last) && (!found || key[k] < next_key);
+      next_key = candidate ? key[k] : next_key;
+      next_value = candidate ? value[k] : next_value;
+      found |= candidate;
     }
-    if (next < 0) break;
-    const int64_t position = (labels != nullptr && n_labels > 0) ? label_rank(labels, n_labels, key[next]) : round;
-    sum.add(position, value[next]);
-    last = key[next];
+    if (!found) break;
+    sum.add(ranked ? label_rank(s.labels, s.n_labels, next_key) : round, next_value);
+    last = next_key;
     have_last = true;
   }
-  const bool in_bounds = best >= 0 && sum.total() > 0.5f;
-  const int es = dtype_size(dtype);
-  if (in_bounds) {  // the winner's element, bit for bit
-    const char* s = static_cast<const char*>(in) + (in_base + off8[best]) * es;
-    char* d = static_cast<char*>(out) + out_index * es;
-    for (int e = 0; e < es; e++) d[e] = s[e];
+  const int es = dtype_size(s.dtype);
+  if (have_best && sum.total() > 0.5f) {  // the winner's element, bit for bit
+    const char* src = static_cast<const char*>(s.in) + (s.in_base + best_off) * es;
+    char* dst = static_cast<char*>(s.out) + s.out_index * es;
+    for (int e = 0; e < es; e++) dst[e] = src[e];
   } else {
-    store_pad_label(out, dtype, out_index, pad_label);
+    store_pad_label(s.out, s.dtype, s.out_index, s.pad_label);
   }
 }
 
