@@ -313,3 +313,41 @@ def test_separable_conv_float4_radius_classes(oracle, hip, sigmas):
     taps, radius = _taps(1, [sigmas], 48)
     cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, radius))
     assert torch.equal(cpu, gpu.cpu())
+
+
+# -- degenerate sizes: empty batch, one-voxel axes, one-voxel volumes -------------------------
+def test_empty_batch_is_a_no_op_everywhere(hip):
+    """B = 0: every entry point returns an empty tensor of the right shape and launches nothing."""
+    empty = torch.zeros(0, 2, 8, 8, 8, device=DEV)
+    out = hip.resample3d([empty], out_shape=(6, 7, 8), mapping=torch.eye(3, 4, device=DEV)[None], control_points=None,
+                         in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["linear"], fills=[None])[0]
+    assert out.shape == (0, 2, 6, 7, 8)
+    taps = torch.full((1, 3, 3), 1 / 3, device=DEV)
+    assert hip.separable_conv3d(empty, taps, [1, 1, 1]).shape == empty.shape
+    assert hip.gamma_pow(empty, 1.5).shape == empty.shape
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("in_shape,out_shape", [((1, 1, 1), (1, 1, 1)), ((1, 9, 1), (3, 4, 2)), ((5, 1, 7), (5, 1, 7)), ((2, 2, 2), (1, 1, 1))])
+@pytest.mark.parametrize("interp", ["linear", "nearest", "label"])
+def test_resample_degenerate_shapes_match_oracle(oracle, hip, in_shape, out_shape, interp):
+    """Axes of length 1 (2-D slices, single voxels): max(S - 1, 1) in the normalisation, taps on the border."""
+    batch = 2
+    dtype = torch.float32 if interp == "linear" else torch.int16
+    data = _data((batch, 1, *in_shape), dtype, 81)
+    kwargs = dict(
+        out_shape=out_shape, mapping=_mapping(batch, 82, scale=0.3, shift=0.4), control_points=None, in_spacing=(1, 1, 1),
+        out_spacing=(1, 1, 1), affine_first=True, interps=[interp], fills=[torch.tensor([9.0]) if interp != "label" else None],
+    )
+    if interp == "label":
+        kwargs.update(label_tables=[torch.unique(data).double()], pad_labels=[5.0])
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_blur_on_one_voxel_axes_matches_oracle(oracle, hip):
+    """Replicate padding over an axis of length 1 (every tap reads the same voxel)."""
+    data = _data((2, 1, 1, 6, 4), torch.float32, 83)
+    taps = torch.tensor([[0.25, 0.5, 0.25]]).repeat(3, 1)[None].contiguous()
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, [1, 1, 1]))
+    assert torch.equal(cpu, gpu.cpu())

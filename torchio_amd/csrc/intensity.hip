@@ -1226,6 +1226,7 @@ extern "C" int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t d
                                     int32_t channels, const int32_t shape[3], const float* taps_dev,
                                     int32_t taps_batched, int32_t tap_stride, const int32_t radius[3],
                                     const uint8_t* skip_dev, void* stream) {
+  if (batch == 0) return TIO_OK;  // an empty batch has no data pointers to speak of
   if (x == nullptr || y == nullptr || shape == nullptr || radius == nullptr)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d: null argument");
   if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_separable_conv3d: dtype %d", dtype);
@@ -1265,6 +1266,7 @@ extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, 
                               const int32_t radius[3], const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],
                               int32_t noise_on, float noise_mean, float noise_std, const float* noise_mean_dev,
                               const float* noise_std_dev, int32_t noise_batched, uint64_t philox_seed, void* stream) {
+  if (batch == 0) return TIO_OK;
   if (x == nullptr || y == nullptr || tmp == nullptr || shape == nullptr || radius == nullptr || taps_dev == nullptr)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: null argument");
   if (dtype != TIO_F32) return TIO_ERR_UNSUPPORTED_CONFIG;
@@ -1300,6 +1302,7 @@ extern "C" int tio_bias_field_apply(const void* x, void* y, int32_t dtype, int32
                                     const int32_t shape[3], const float* coarse_dev,
                                     const int32_t coarse_shape[3], int32_t divide, const uint8_t* skip_dev,
                                     void* stream) {
+  if (batch == 0) return TIO_OK;
   if (x == nullptr || y == nullptr || shape == nullptr || coarse_dev == nullptr || coarse_shape == nullptr)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bias_field_apply: null argument");
   if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_bias_field_apply: dtype %d", dtype);
@@ -1327,6 +1330,7 @@ extern "C" int tio_add_noise(const void* x, void* y, int32_t dtype, int32_t batc
                              float mean, float std, const float* mean_dev, const float* std_dev,
                              int32_t params_batched, int32_t rician, const float* base1_dev,
                              const float* base2_dev, uint64_t philox_seed, const uint8_t* keep_dev, void* stream) {
+  if (batch == 0 || n_per_element == 0) return TIO_OK;
   if (x == nullptr || y == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_add_noise: null argument");
   if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_add_noise: dtype %d", dtype);
   if (batch < 0 || n_per_element < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_add_noise: negative size");
@@ -1357,6 +1361,7 @@ extern "C" int tio_philox_normal(float* out_dev, int64_t n, uint64_t philox_seed
 
 extern "C" int tio_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch, int64_t n_per_element,
                              float gamma, const float* gamma_dev, int32_t params_batched, void* stream) {
+  if (batch == 0 || n_per_element == 0) return TIO_OK;
   if (x == nullptr || y == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_gamma_pow: null argument");
   if (!is_float_dtype(dtype)) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_gamma_pow: dtype %d", dtype);
   if (batch < 0 || n_per_element < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_gamma_pow: negative size");

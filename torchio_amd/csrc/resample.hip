@@ -429,8 +429,9 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
   if (geom == nullptr || images == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: null argument");
   if (n_images < 1 || n_images > TIO_MAX_IMAGES)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: n_images=%d not in [1, %d]", n_images, TIO_MAX_IMAGES);
-  if (geom->mapping_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: mapping_dev is null");
   if (geom->batch < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: negative batch");
+  if (geom->batch == 0) return TIO_OK;  // an empty batch has no data pointers to speak of
+  if (geom->mapping_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: mapping_dev is null");
   for (int d = 0; d < 3; d++) {
     if (geom->in_shape[d] < 1 || geom->out_shape[d] < 1)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: shapes must be >= 1");
