@@ -112,3 +112,81 @@ def test_grid_sampler_then_aggregator_round_trip():
             covered = aggregator._counts["__default__"] >= 1
             assert bool(covered.any())
             torch.testing.assert_close(restored[covered], volume[covered], rtol=1e-5, atol=1e-6)
+
+
+# -- Queue ---------------------------------------------------------------------------------
+def _queue_subjects(n=5, size=12):
+    g = torch.Generator().manual_seed(7)
+    return [
+        tio.Subject(t1=tio.ScalarImage(torch.rand(1, size, size, size, generator=g) + index), seg=tio.LabelMap(torch.full((1, size, size, size), index, dtype=torch.int16)), index=index)
+        for index in range(n)
+    ]
+
+
+@pytest.mark.parametrize("num_workers", [0, 3])
+def test_queue_yields_every_patch_once_and_respects_the_buffer(num_workers):
+    import random
+
+    subjects = _queue_subjects()
+    sampler = tio.UniformSampler(subjects[0], patch_size=4)
+    queue = tio.Queue(subjects, sampler, max_length=6, patches_per_volume=3, num_workers=num_workers)
+    assert queue.num_subjects == 5 and queue.patches_per_epoch == 15
+    assert queue.max_memory == 4 * 2 * 64 * 6 and queue.max_memory_pretty == "3.0 KiB"
+    random.seed(3)
+    torch.manual_seed(3)
+    patches = list(queue)
+    assert len(patches) == 15
+    counts = {}
+    for patch in patches:
+        assert patch.t1.shape == (1, 4, 4, 4) and isinstance(patch.patch_location, tio.PatchLocation)
+        source = subjects[patch.index]
+        i, j, k = patch.patch_location.index
+        assert torch.equal(patch.t1.data, source.t1.data[:, i : i + 4, j : j + 4, k : k + 4])  # a crop of its own subject
+        assert bool((patch.seg.data == patch.index).all())
+        counts[patch.index] = counts.get(patch.index, 0) + 1
+    assert counts == {index: 3 for index in range(5)}
+
+
+def test_queue_applies_the_transform_before_sampling_and_shuffles_reproducibly():
+    import random
+
+    subjects = _queue_subjects(4)
+    transform = tio.Affine(degrees=(20, 20, 20), default_pad_value=0.0)
+    sampler = tio.GridSampler(subjects[0], patch_size=6)
+
+    class WholeGrid(tio.PatchSampler):
+        def __call__(self, subject, num_patches=None):
+            grid = tio.GridSampler(subject, self.patch_size)
+            return (grid[i] for i in range(len(grid)))
+
+    def epoch(seed):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        queue = tio.Queue(subjects, WholeGrid(6), max_length=100, patches_per_volume=8, transform=transform, shuffle_subjects=True)
+        return list(queue)
+
+    first, again, other = epoch(1), epoch(1), epoch(2)
+    assert len(first) == 32 and len(sampler) == 8
+    assert [p.index for p in first] == [p.index for p in again]
+    assert all(torch.equal(a.t1.data, b.t1.data) for a, b in zip(first, again, strict=True))
+    assert [p.index for p in first] != [p.index for p in other]
+    # the patches come from the TRANSFORMED subjects (history recorded, values differ from the raw crop)
+    patch = first[0]
+    raw = subjects[patch.index]
+    i, j, k = patch.patch_location.index
+    assert not torch.equal(patch.t1.data, raw.t1.data[:, i : i + 6, j : j + 6, k : k + 6])
+
+
+def test_queue_with_distributed_sampler_splits_the_subjects():
+    from torch.utils.data import DistributedSampler
+
+    subjects = _queue_subjects(6)
+    seen = []
+    for rank in range(2):
+        split = DistributedSampler(subjects, num_replicas=2, rank=rank, shuffle=False)
+        queue = tio.Queue(subjects, tio.UniformSampler(subjects[0], 4), patches_per_volume=2, shuffle_subjects=False, subject_sampler=split)
+        assert queue.num_subjects == 3 and queue.patches_per_epoch == 6
+        seen.append(sorted({patch.index for patch in queue}))
+    assert seen == [[0, 2, 4], [1, 3, 5]]
+    with pytest.raises(ValueError, match="shuffle_subjects must be False"):
+        tio.Queue(subjects, tio.UniformSampler(subjects[0], 4), subject_sampler=DistributedSampler(subjects, num_replicas=2, rank=0))

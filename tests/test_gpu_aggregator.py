@@ -69,3 +69,28 @@ def test_bad_placement_is_rejected(hip):
     aggregator = tio.PatchAggregator((8, 8, 8), overlap_mode="average")
     with pytest.raises(RuntimeError, match="leaves the patch or the volume"):
         aggregator.add_batch(torch.ones(1, 1, 4, 4, 4, device="cuda"), [tio.PatchLocation(index=(6, 0, 0), size=(4, 4, 4))])
+
+
+@pytest.mark.parametrize("num_workers", [0, 2])
+def test_queue_feeds_device_resident_patches(hip, num_workers):
+    """Subjects on the GPU -> transform on the GPU (worker threads included) -> patches that never left the device."""
+    import random
+
+    g = torch.Generator().manual_seed(9)
+    subjects = [
+        tio.Subject(t1=tio.ScalarImage(torch.rand(1, 32, 32, 32, generator=g)), seg=tio.LabelMap(torch.randint(0, 4, (1, 32, 32, 32), generator=g).to(torch.int16)), index=i).to("cuda")
+        for i in range(4)
+    ]
+    transform = tio.Compose([tio.Affine(degrees=(-10, 10), translation=(-2, 2)), tio.Blur(std=(0.5, 1.0)), tio.Noise(std=(0.01, 0.02))])
+    queue = tio.Queue(subjects, tio.UniformSampler(subjects[0], 16), max_length=8, patches_per_volume=4, num_workers=num_workers, transform=transform)
+    random.seed(0)
+    torch.manual_seed(0)
+    patches = list(queue)
+    torch.cuda.synchronize()
+    assert len(patches) == 16
+    for patch in patches:
+        assert patch.t1.data.is_cuda and patch.seg.data.is_cuda and patch.t1.shape == (1, 16, 16, 16)
+        assert torch.isfinite(patch.t1.data).all()
+        assert set(patch.seg.data.unique().tolist()) <= {0, 1, 2, 3}
+    assert sorted(p.index for p in patches) == [0] * 4 + [1] * 4 + [2] * 4 + [3] * 4
+    assert all(not s.t1.applied_transforms for s in subjects)  # the queue's subjects are left untouched (copy=True)

@@ -13,6 +13,7 @@ from .data import LabelSampler
 from .data import PatchAggregator
 from .data import PatchLocation
 from .data import PatchSampler
+from .data import Queue
 from .data import UniformSampler
 from .data import WeightedSampler
 from .data import Image
@@ -43,6 +44,6 @@ __version__ = "0.1.0"
 __all__ = [
     "Affine", "AffineMatrix", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation",
     "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise",
-    "PatchAggregator", "PatchLocation", "PatchSampler", "Resample", "ScalarImage", "Spatial", "SpatialTransform", "Subject",
+    "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "ScalarImage", "Spatial", "SpatialTransform", "Subject",
     "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "get_noise_rng", "set_noise_rng",
 ]

@@ -6,6 +6,7 @@ from .image import Image
 from .image import LabelMap
 from .image import ScalarImage
 from .patch import PatchLocation
+from .queue import Queue
 from .sampler import GridSampler
 from .sampler import LabelSampler
 from .sampler import PatchSampler
@@ -15,5 +16,5 @@ from .subject import Subject
 
 __all__ = [
     "AffineMatrix", "GridSampler", "Image", "ImagesBatch", "LabelMap", "LabelSampler", "PatchAggregator", "PatchLocation",
-    "PatchSampler", "ScalarImage", "Subject", "SubjectsBatch", "UniformSampler", "WeightedSampler",
+    "PatchSampler", "Queue", "ScalarImage", "Subject", "SubjectsBatch", "UniformSampler", "WeightedSampler",
 ]
