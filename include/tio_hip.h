@@ -246,6 +246,35 @@ int tio_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch,
                   int32_t params_batched, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* F.interpolate users: Resize, Anisotropy                */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * F.interpolate(x.float(), size=out_shape, mode=...).to(x.dtype) on a dense
+ * (N, I, J, K) stack of volumes (N = B * C):
+ *   mode TIO_NEAREST: the legacy "nearest" — src = min(floor(dst * float(in) / float(out)), in - 1)
+ *                     (resize.py:70-76, anisotropy.py:380-384), an element move for every dtype;
+ *   mode TIO_LINEAR:  "trilinear" with align_corners=True (resize.py:70-76,
+ *                     anisotropy.py:386-391): ATen's source index / lambda per axis and the
+ *                     K-, J-, I-nested fma(t0, w0, t1 * w1), computed in float32.
+ */
+int tio_interpolate3d(const void* x, void* y, int32_t dtype, int64_t n_batch_channels,
+                      const int32_t in_shape[3], const int32_t out_shape[3], int32_t mode, void* stream);
+
+/*
+ * Anisotropy with per-element parameters (_simulate_anisotropy_fixed_axis,
+ * anisotropy.py:180-208): along `axis`, y[b, c, .., p, ..] = x[.., lower[b, p], ..] (upper_dev
+ * NULL: nearest) or x[.., lower[b, p], ..] * (1 - w[b, p]) + x[.., upper[b, p], ..] * w[b, p] with
+ * every product and the sum rounded separately like the reference's three tensor ops.  The
+ * (B, length) index / weight tables are the reference's own integer arithmetic, done on the
+ * host.  active_dev (B bytes or NULL): 0 = the element is copied unchanged (factor <= 1).
+ */
+int tio_axis_gather_lerp(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels,
+                         const int32_t shape[3], int32_t axis, const int32_t* lower_dev,
+                         const int32_t* upper_dev, const float* weight_dev, const uint8_t* active_dev,
+                         void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* Feeding side: dense-inference patch aggregation        */
 /* ------------------------------------------------------------------------ */
 

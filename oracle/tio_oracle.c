@@ -782,6 +782,88 @@ int tio_oracle_patch_accumulate(void* out, void* weight_sum, int32_t dtype, int3
   return TIO_OK;
 }
 
+/* ------------------------------------------------------------------------ */
+/* F.interpolate users: resize.py:57-82, anisotropy.py:128-392                */
+/* ------------------------------------------------------------------------ */
+int tio_oracle_interpolate3d(const void* x, void* y, int32_t dtype, int64_t n_bc, const int32_t in_shape[3],
+                             const int32_t out_shape[3], int32_t mode, void* stream) {
+  (void)stream;
+  const size_t es = dtype_size(dtype);
+  if (es == 0) return TIO_ERR_UNSUPPORTED_DTYPE;
+  const int64_t n_in = (int64_t)in_shape[0] * in_shape[1] * in_shape[2];
+  const int64_t n_out = (int64_t)out_shape[0] * out_shape[1] * out_shape[2];
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t bc = 0; bc < n_bc; bc++)
+    for (int32_t i = 0; i < out_shape[0]; i++)
+      for (int32_t j = 0; j < out_shape[1]; j++)
+        for (int32_t k = 0; k < out_shape[2]; k++) {
+          const int64_t o = bc * n_out + ((int64_t)i * out_shape[1] + j) * out_shape[2] + k;
+          if (mode == TIO_NEAREST) { /* nearest_neighbor_compute_source_index: floor(dst * scale), scale = in / out in float */
+            int32_t src[3];
+            const int32_t dst[3] = {i, j, k};
+            for (int d = 0; d < 3; d++) {
+              const float scale = (float)in_shape[d] / (float)out_shape[d];
+              int32_t v = (int32_t)floorf((float)dst[d] * scale);
+              src[d] = v < in_shape[d] - 1 ? v : in_shape[d] - 1;
+            }
+            const int64_t from = bc * n_in + ((int64_t)src[0] * in_shape[1] + src[1]) * in_shape[2] + src[2];
+            memcpy((char*)y + o * es, (const char*)x + from * es, es);
+            continue;
+          }
+          const lerp1d li = lerp_index(i, in_shape[0], out_shape[0]);
+          const lerp1d lj = lerp_index(j, in_shape[1], out_shape[1]);
+          const lerp1d lk = lerp_index(k, in_shape[2], out_shape[2]);
+          float corner[2][2][2];
+          for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++)
+              for (int c = 0; c < 2; c++)
+                corner[a][b][c] = load_as_float(x, dtype, bc * n_in + ((int64_t)(a ? li.i1 : li.i0) * in_shape[1] + (b ? lj.i1 : lj.i0)) * in_shape[2] + (c ? lk.i1 : lk.i0));
+          const float a00 = lerp2(corner[0][0][0], lk.l0, corner[0][0][1], lk.l1);
+          const float a01 = lerp2(corner[0][1][0], lk.l0, corner[0][1][1], lk.l1);
+          const float a10 = lerp2(corner[1][0][0], lk.l0, corner[1][0][1], lk.l1);
+          const float a11 = lerp2(corner[1][1][0], lk.l0, corner[1][1][1], lk.l1);
+          store_from_float(y, dtype, o, lerp2(lerp2(a00, lj.l0, a01, lj.l1), li.l0, lerp2(a10, lj.l0, a11, lj.l1), li.l1));
+        }
+  return TIO_OK;
+}
+
+int tio_oracle_axis_gather_lerp(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels, const int32_t shape[3],
+                                int32_t axis, const int32_t* lower, const int32_t* upper, const float* weight,
+                                const uint8_t* active, void* stream) {
+  (void)stream;
+  const size_t es = dtype_size(dtype);
+  if (es == 0) return TIO_ERR_UNSUPPORTED_DTYPE;
+  if (axis < 0 || axis > 2) return TIO_ERR_INVALID_ARGUMENT;
+  const int64_t n = (int64_t)shape[0] * shape[1] * shape[2];
+  const int32_t length = shape[axis];
+  const int64_t stride = axis == 0 ? (int64_t)shape[1] * shape[2] : (axis == 1 ? shape[2] : 1);
+  for (int32_t b = 0; b < batch; b++)
+    for (int32_t c = 0; c < channels; c++) {
+      const int64_t base = ((int64_t)b * channels + c) * n;
+      if (active && !active[b]) {
+        memcpy((char*)y + base * es, (const char*)x + base * es, (size_t)n * es);
+        continue;
+      }
+      for (int64_t r = 0; r < n; r++) {
+        const int32_t k = (int32_t)(r % shape[2]), j = (int32_t)((r / shape[2]) % shape[1]), i = (int32_t)(r / ((int64_t)shape[1] * shape[2]));
+        const int32_t p = axis == 0 ? i : (axis == 1 ? j : k);
+        const int64_t line = base + r - (int64_t)p * stride;
+        const int32_t lo = lower[(int64_t)b * length + p];
+        if (!upper) { /* torch.gather(data.float(), ...).to(dtype) */
+          memcpy((char*)y + (base + r) * es, (const char*)x + (line + lo * stride) * es, es);
+          continue;
+        }
+        const int32_t hi = upper[(int64_t)b * length + p];
+        const float w = weight[(int64_t)b * length + p];
+        const float one_minus = 1.0f - w;
+        const float lower_term = load_as_float(x, dtype, line + lo * stride) * one_minus;
+        const float upper_term = load_as_float(x, dtype, line + hi * stride) * w;
+        store_from_float(y, dtype, base + r, lower_term + upper_term);
+      }
+    }
+  return TIO_OK;
+}
+
 int tio_oracle_abi_version(void) { return TIO_ABI_VERSION; }
 
 int tio_oracle_num_threads(void) {

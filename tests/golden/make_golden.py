@@ -104,6 +104,16 @@ CASES = [
     ("affine_label_pv_nearest_one_hot", "Affine", dict(degrees=(-10, 10), label_interpolation="label", one_hot_label_interpolation="nearest"), (12, 12, 12), 1, "identity", "float32", "int16"),
     ("affine_label_pv_multichannel_int", "Affine", dict(degrees=(-10, 10), translation=(-3, 3), label_interpolation="label"), (12, 12, 12), 2, "identity", "float32", "uint8", "onehot"),
     ("affine_label_pv_multichannel_f64", "Affine", dict(degrees=(-10, 10), label_interpolation="label", default_pad_label=2), (10, 10, 10), 1, "identity", "float32", "float64", "onehot"),
+    # F.interpolate users: Resize, Anisotropy
+    ("resize_mixed", "Resize", dict(target_shape=(20, 9, 17)), (12, 14, 10), 2, "aniso", "float32", "int16"),
+    ("resize_down_cube_nearest_image", "Resize", dict(target_shape=7, image_interpolation="nearest"), (12, 14, 10), 1, "identity", "float32", "uint8"),
+    ("resize_f16_to_one_voxel_axis", "Resize", dict(target_shape=(9, 1, 12)), (6, 5, 8), 1, "oblique", "float16", "int32"),
+    ("resize_f64_many_labels", "Resize", dict(target_shape=(24, 20, 11)), (16, 16, 16), 1, "identity", "float64", "int64", "many"),
+    ("anisotropy", "Anisotropy", dict(downsampling=(1.5, 5)), (16, 14, 12), 1, "identity", "float32", "int16"),
+    ("anisotropy_batch_p", "Anisotropy", dict(axes=(0, 2), downsampling=(1.5, 4), p=0.6), (12, 14, 16), 4, "identity", "float32", "int16"),
+    ("anisotropy_batch_nearest_image", "Anisotropy", dict(downsampling=(2, 6), image_interpolation="nearest"), (12, 10, 14), 3, "aniso", "float32", "uint8"),
+    ("anisotropy_batch_shared", "Anisotropy", dict(axes=(1,), downsampling=(2, 3), per_instance=False), (10, 16, 12), 3, "identity", "float32", "int16"),
+    ("anisotropy_f16_extreme_factor", "Anisotropy", dict(downsampling=40), (12, 12, 12), 2, "identity", "float16", "int16"),
 ]
 
 COMPOSE = [

@@ -26,6 +26,8 @@ BIT_EXACT_FLOAT = {
     "affine_nearest_image", "affine_f64", "affine_f16", "affine_p_gate", "elastic", "elastic_batch",
     "spatial_fused", "spatial_elastic_first_batch_p", "spatial_target_and_affine", "resample_2mm",
     "resample_random_spacing", "noise", "noise_f64",
+    "resize_mixed", "resize_down_cube_nearest_image", "resize_f16_to_one_voxel_axis", "resize_f64_many_labels", "anisotropy",
+    "anisotropy_batch_p", "anisotropy_batch_nearest_image", "anisotropy_batch_shared", "anisotropy_f16_extreme_factor",
 }
 
 

@@ -351,3 +351,41 @@ def test_blur_on_one_voxel_axes_matches_oracle(oracle, hip):
     taps = torch.tensor([[0.25, 0.5, 0.25]]).repeat(3, 1)[None].contiguous()
     cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, [1, 1, 1]))
     assert torch.equal(cpu, gpu.cpu())
+
+
+# -- F.interpolate users (Resize / Anisotropy) ----------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.uint8, torch.int16, torch.int64])
+@pytest.mark.parametrize("mode", ["nearest", "linear"])
+def test_interpolate3d_matches_oracle_bit_exact(oracle, hip, dtype, mode):
+    data = _data((2, 2, 13, 9, 20), dtype, 91)
+    for out_shape in [(20, 9, 7), (5, 18, 33), (13, 9, 20), (1, 1, 1)]:
+        cpu, gpu = _both(oracle, hip, "interpolate3d", (data, out_shape, mode))
+        assert gpu.dtype == dtype and tuple(gpu.shape[2:]) == out_shape
+        assert torch.equal(cpu, gpu.cpu())
+
+
+def test_interpolate3d_equals_stock_aten_on_the_device(hip):
+    """The semantic anchor: torch's own F.interpolate on the same GPU (nearest exactly; trilinear within 1 ulp of the fma order)."""
+    import torch.nn.functional as F
+
+    data = torch.rand(2, 3, 40, 36, 44, device=DEV)
+    for out_shape in [(64, 20, 44), (17, 50, 90)]:
+        assert torch.equal(hip.interpolate3d(data, out_shape, "nearest"), F.interpolate(data, size=out_shape, mode="nearest"))
+        ours = hip.interpolate3d(data, out_shape, "linear")
+        torch.testing.assert_close(ours, F.interpolate(data, size=out_shape, mode="trilinear", align_corners=True), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.int16])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("blend", [False, True])
+def test_axis_gather_lerp_matches_oracle_bit_exact(oracle, hip, dtype, axis, blend):
+    data = _data((3, 2, 10, 12, 14), dtype, 92)
+    length = data.shape[2 + axis]
+    g = torch.Generator().manual_seed(93)
+    lower = torch.randint(0, length, (3, length), generator=g, dtype=torch.int32)
+    upper = torch.randint(0, length, (3, length), generator=g, dtype=torch.int32) if blend else None
+    weight = torch.rand(3, length, generator=g) if blend else None
+    active = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    cpu, gpu = _both(oracle, hip, "axis_gather_lerp", (data, axis, lower, upper, weight, active))
+    assert torch.equal(cpu, gpu.cpu())
+    assert torch.equal(gpu[1].cpu(), data[1])  # inactive element: untouched

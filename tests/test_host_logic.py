@@ -427,3 +427,45 @@ def test_lazy_params_reads_like_the_eager_dict(oracle):
     with use_engine(oracle):
         restored = out.apply_inverse_transform()
     assert restored.t1.data.shape == batch.t1.data.shape
+
+
+# -- Resize / Anisotropy (F.interpolate users) ----------------------------------------------------
+def test_resize_keeps_the_field_of_view_and_rescales_the_affines():
+    s = subject(size=12)
+    s.t1.affine = tio.AffineMatrix(np.diag([2.0, 3.0, 4.0, 1.0]))
+    s.seg.affine = tio.AffineMatrix(np.diag([2.0, 3.0, 4.0, 1.0]))
+    out = tio.Resize((6, 24, 12))(s)
+    assert out.t1.shape == (1, 6, 24, 12) and out.seg.shape == (1, 6, 24, 12)
+    assert out.t1.spacing == (4.0, 1.5, 4.0)  # old / new per axis: same physical extent
+    assert s.t1.spacing == (2.0, 3.0, 4.0)  # the input is a copy: untouched
+    assert set(out.seg.data.unique().tolist()) <= set(s.seg.data.unique().tolist())  # nearest for label maps
+    assert tio.Resize(5)(s).t1.shape == (1, 5, 5, 5)
+    same = tio.Resize(12)(s)
+    assert torch.equal(same.t1.data, s.t1.data) and torch.equal(same.seg.data, s.seg.data)
+
+
+def test_anisotropy_parameters_gating_and_errors():
+    with pytest.raises(ValueError, match="upper bound must be >= 1"):
+        tio.Anisotropy(downsampling=(0.2, 0.8))
+    with pytest.warns(UserWarning, match="no-op"):
+        tio.Anisotropy()
+    s = subject(size=12)
+    torch.manual_seed(4)
+    out = tio.Anisotropy(axes=(2,), downsampling=(2, 4))(s)
+    params = out.applied_transforms[-1].params
+    assert params["axis"] == 2 and 2.0 <= params["factor"] <= 4.0
+    assert out.t1.shape == s.t1.shape and not torch.equal(out.t1.data, s.t1.data)
+    # along the untouched axes nothing is mixed: every (i, j) line is a function of the same line of the input
+    assert set(out.seg.data.unique().tolist()) <= set(s.seg.data.unique().tolist())
+    # per-instance: lists of axes / factors; gated-out elements are exact no-ops with factor 1
+    b = batch(n=6, size=10)
+    torch.manual_seed(5)
+    result = tio.Anisotropy(downsampling=(1.5, 3), p=0.5)(b)
+    params = result.applied_transforms[-1].params
+    assert len(params["axis"]) == len(params["factor"]) == 6 and params["_batched_keys"] == ["axis", "factor"]
+    for index, keep in enumerate(params["_keep"]):
+        unchanged = torch.equal(result.images["t1"].data[index], b.images["t1"].data[index])
+        assert unchanged == (not keep) and (keep or params["factor"][index] == 1.0)
+    # shared parameters on a batch: one axis, one factor
+    shared = tio.Anisotropy(downsampling=(2, 3), per_instance=False)(b)
+    assert isinstance(shared.applied_transforms[-1].params["axis"], int)

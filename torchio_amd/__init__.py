@@ -23,6 +23,7 @@ from .data import ScalarImage
 from .data import Subject
 from .data import SubjectsBatch
 from .transforms import Affine
+from .transforms import Anisotropy
 from .transforms import AppliedTransform
 from .transforms import BiasField
 from .transforms import Blur
@@ -33,6 +34,7 @@ from .transforms import Gamma
 from .transforms import IntensityTransform
 from .transforms import Noise
 from .transforms import Resample
+from .transforms import Resize
 from .transforms import Spatial
 from .transforms import SpatialTransform
 from .transforms import Transform
@@ -42,8 +44,8 @@ from .transforms import set_noise_rng
 __version__ = "0.1.0"
 
 __all__ = [
-    "Affine", "AffineMatrix", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation",
+    "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation",
     "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise",
-    "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "ScalarImage", "Spatial", "SpatialTransform", "Subject",
+    "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "Spatial", "SpatialTransform", "Subject",
     "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "get_noise_rng", "set_noise_rng",
 ]

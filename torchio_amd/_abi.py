@@ -100,6 +100,12 @@ PROTOTYPES = {
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, _I32x3,
          C.POINTER(PatchPlacement), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "interpolate3d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, _I32x3, _I32x3, C.c_int32, C.c_void_p]),
+    "axis_gather_lerp": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_void_p],
+    ),
     "abi_version": (C.c_int, []),
 }
 

@@ -55,6 +55,10 @@ struct Elem<TIO_F16> {
     return static_cast<float>(static_cast<const _Float16*>(p)[i]);
   }
   static __device__ __forceinline__ void store(void* p, int64_t i, float v) {
+    // The value is a finished float32 result that `.to(float16)` rounds a SECOND time.  Without the
+    // barrier the backend folds a preceding fma into v_fma_mixlo_f16 (one rounding from the exact
+    // product-sum), which differs from the reference in near-tie cases.
+    asm volatile("" : "+v"(v));
     static_cast<_Float16*>(p)[i] = static_cast<_Float16>(v);  // v_cvt_f16_f32: RNE
   }
 };

@@ -1,0 +1,192 @@
+// tio_interpolate3d / tio_axis_gather_lerp — F.interpolate users on the augmentation path
+// (SURVEY §8f rank 3): Resize (transforms/spatial/resize.py:57-82) and Anisotropy
+// (transforms/spatial/anisotropy.py:128-392).
+//
+// Both are pure streaming kernels (HBM bound: read the input once, write the output once),
+// one thread per output voxel with lanes along K.  The arithmetic is ATen's:
+//   nearest (legacy "nearest"): src = min(floor(dst * float(in) / float(out)), in - 1)
+//   trilinear, align_corners=True: lerp_index() per axis and the K-, J-, I-nested lerp2()
+//   (common.hpp; pinned bit for bit against F.interpolate by the oracle's golden vectors).
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace tio {
+
+struct InterpArgs {
+  const void* x;
+  void* y;
+  int64_t n_bc;
+  int in[3], out[3];
+  float scale[3];  // nearest: float(in) / float(out); linear: (in - 1) / (out - 1)
+  int mode;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void interpolate_kernel(const InterpArgs a) {
+  const int64_t n_out = static_cast<int64_t>(a.out[0]) * a.out[1] * a.out[2];
+  const int64_t n_in = static_cast<int64_t>(a.in[0]) * a.in[1] * a.in[2];
+  const int64_t total = n_out * a.n_bc;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t bc = t / n_out;
+    int64_t r = t - bc * n_out;
+    const int k = static_cast<int>(r % a.out[2]);
+    r /= a.out[2];
+    const int j = static_cast<int>(r % a.out[1]);
+    const int i = static_cast<int>(r / a.out[1]);
+    const int64_t base = bc * n_in;
+    float value;
+    if (a.mode == TIO_NEAREST) {
+      const int si = min(static_cast<int>(floorf(__fmul_rn(static_cast<float>(i), a.scale[0]))), a.in[0] - 1);
+      const int sj = min(static_cast<int>(floorf(__fmul_rn(static_cast<float>(j), a.scale[1]))), a.in[1] - 1);
+      const int sk = min(static_cast<int>(floorf(__fmul_rn(static_cast<float>(k), a.scale[2]))), a.in[2] - 1);
+      // a pure element move: copy the bits (no float round trip for 64-bit types)
+      const int es = dtype_size(DT);
+      const char* s = static_cast<const char*>(a.x) + (base + (static_cast<int64_t>(si) * a.in[1] + sj) * a.in[2] + sk) * es;
+      char* d = static_cast<char*>(a.y) + t * es;
+      for (int e = 0; e < es; e++) d[e] = s[e];
+      continue;
+    }
+    const Lerp1D li = lerp_index(i, a.in[0], a.out[0], a.scale[0]);
+    const Lerp1D lj = lerp_index(j, a.in[1], a.out[1], a.scale[1]);
+    const Lerp1D lk = lerp_index(k, a.in[2], a.out[2], a.scale[2]);
+    const int64_t r00 = base + (static_cast<int64_t>(li.i0) * a.in[1] + lj.i0) * a.in[2];
+    const int64_t r01 = base + (static_cast<int64_t>(li.i0) * a.in[1] + lj.i1) * a.in[2];
+    const int64_t r10 = base + (static_cast<int64_t>(li.i1) * a.in[1] + lj.i0) * a.in[2];
+    const int64_t r11 = base + (static_cast<int64_t>(li.i1) * a.in[1] + lj.i1) * a.in[2];
+    const float a00 = lerp2(Elem<DT>::load(a.x, r00 + lk.i0), lk.l0, Elem<DT>::load(a.x, r00 + lk.i1), lk.l1);
+    const float a01 = lerp2(Elem<DT>::load(a.x, r01 + lk.i0), lk.l0, Elem<DT>::load(a.x, r01 + lk.i1), lk.l1);
+    const float a10 = lerp2(Elem<DT>::load(a.x, r10 + lk.i0), lk.l0, Elem<DT>::load(a.x, r10 + lk.i1), lk.l1);
+    const float a11 = lerp2(Elem<DT>::load(a.x, r11 + lk.i0), lk.l0, Elem<DT>::load(a.x, r11 + lk.i1), lk.l1);
+    value = lerp2(lerp2(a00, lj.l0, a01, lj.l1), li.l0, lerp2(a10, lj.l0, a11, lj.l1), li.l1);
+    Elem<DT>::store(a.y, t, value);
+  }
+}
+
+struct AxisArgs {
+  const void* x;
+  void* y;
+  const int32_t* lower;   // (B, length) source index along the axis
+  const int32_t* upper;   // (B, length) or nullptr (nearest: a gather)
+  const float* weight;    // (B, length) weight of `upper`
+  const uint8_t* active;  // (B) 0 = copy the element unchanged; nullptr = all active
+  int batch, channels;
+  int shape[3];
+  int axis;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void axis_gather_lerp_kernel(const AxisArgs a) {
+  const int64_t n = static_cast<int64_t>(a.shape[0]) * a.shape[1] * a.shape[2];
+  const int64_t total = n * a.batch * a.channels;
+  const int length = a.shape[a.axis];
+  const int64_t stride = a.axis == 0 ? static_cast<int64_t>(a.shape[1]) * a.shape[2] : (a.axis == 1 ? a.shape[2] : 1);
+  const int es = dtype_size(DT);
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t bc = t / n;
+    const int b = static_cast<int>(bc / a.channels);
+    const int64_t r = t - bc * n;
+    const int k = static_cast<int>(r % a.shape[2]);
+    const int j = static_cast<int>((r / a.shape[2]) % a.shape[1]);
+    const int i = static_cast<int>(r / (static_cast<int64_t>(a.shape[1]) * a.shape[2]));
+    const int p = a.axis == 0 ? i : (a.axis == 1 ? j : k);
+    if (a.active != nullptr && a.active[b] == 0) {  // elements with factor <= 1: bit-exact copy
+      const char* s = static_cast<const char*>(a.x) + t * es;
+      char* d = static_cast<char*>(a.y) + t * es;
+      for (int e = 0; e < es; e++) d[e] = s[e];
+      continue;
+    }
+    const int64_t line = t - static_cast<int64_t>(p) * stride;  // position 0 of this voxel's line along the axis
+    const int lo = a.lower[static_cast<int64_t>(b) * length + p];
+    if (a.upper == nullptr) {  // nearest: gather(data.float()).to(dtype) == an element move
+      const char* s = static_cast<const char*>(a.x) + (line + lo * stride) * es;
+      char* d = static_cast<char*>(a.y) + t * es;
+      for (int e = 0; e < es; e++) d[e] = s[e];
+      continue;
+    }
+    const int hi = a.upper[static_cast<int64_t>(b) * length + p];
+    const float w = a.weight[static_cast<int64_t>(b) * length + p];
+    // lower * (1.0 - w) + upper * w: three tensor ops in the reference, every one rounds (anisotropy.py:207)
+    const float lower_term = __fmul_rn(Elem<DT>::load(a.x, line + lo * stride), __fsub_rn(1.0f, w));
+    const float upper_term = __fmul_rn(Elem<DT>::load(a.x, line + hi * stride), w);
+    Elem<DT>::store(a.y, t, __fadd_rn(lower_term, upper_term));
+  }
+}
+
+template <typename Kernel, typename Args>
+static int launch_stream(Kernel kernel, const Args& a, int64_t total, hipStream_t s, const char* what) {
+  if (total == 0) return TIO_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  return check_launch(what);
+}
+
+}  // namespace tio
+
+#define TIO_DISPATCH_DTYPE(DTYPE, CALL) \
+  switch (DTYPE) {                      \
+    case TIO_F32: CALL(TIO_F32); break; \
+    case TIO_F64: CALL(TIO_F64); break; \
+    case TIO_F16: CALL(TIO_F16); break; \
+    case TIO_BF16: CALL(TIO_BF16); break; \
+    case TIO_U8: CALL(TIO_U8); break;   \
+    case TIO_I8: CALL(TIO_I8); break;   \
+    case TIO_I16: CALL(TIO_I16); break; \
+    case TIO_I32: CALL(TIO_I32); break; \
+    default: CALL(TIO_I64); break;      \
+  }
+
+extern "C" int tio_interpolate3d(const void* x, void* y, int32_t dtype, int64_t n_batch_channels, const int32_t in_shape[3],
+                                 const int32_t out_shape[3], int32_t mode, void* stream) {
+  using namespace tio;
+  if (in_shape == nullptr || out_shape == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_interpolate3d: null shape");
+  if (mode != TIO_NEAREST && mode != TIO_LINEAR) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_interpolate3d: mode %d", mode);
+  if (dtype_size(dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_interpolate3d: dtype %d", dtype);
+  if (n_batch_channels < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_interpolate3d: negative batch");
+  InterpArgs a{};
+  a.x = x; a.y = y; a.n_bc = n_batch_channels; a.mode = mode;
+  for (int d = 0; d < 3; d++) {
+    if (in_shape[d] < 1 || out_shape[d] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_interpolate3d: shapes must be >= 1");
+    a.in[d] = in_shape[d];
+    a.out[d] = out_shape[d];
+    a.scale[d] = mode == TIO_NEAREST ? static_cast<float>(in_shape[d]) / static_cast<float>(out_shape[d])
+                                     : lerp_scale(in_shape[d], out_shape[d]);
+  }
+  if (n_batch_channels == 0) return TIO_OK;
+  if (x == nullptr || y == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_interpolate3d: null data");
+  const int64_t total = static_cast<int64_t>(out_shape[0]) * out_shape[1] * out_shape[2] * n_batch_channels;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define TIO_CALL(DT) return launch_stream(interpolate_kernel<DT>, a, total, s, "tio_interpolate3d")
+  TIO_DISPATCH_DTYPE(dtype, TIO_CALL)
+#undef TIO_CALL
+  return TIO_OK;
+}
+
+extern "C" int tio_axis_gather_lerp(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels, const int32_t shape[3],
+                                    int32_t axis, const int32_t* lower_dev, const int32_t* upper_dev, const float* weight_dev,
+                                    const uint8_t* active_dev, void* stream) {
+  using namespace tio;
+  if (shape == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_axis_gather_lerp: null shape");
+  if (axis < 0 || axis > 2) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_axis_gather_lerp: axis %d", axis);
+  if (dtype_size(dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_axis_gather_lerp: dtype %d", dtype);
+  if (batch < 0 || channels < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_axis_gather_lerp: bad batch / channels");
+  if (batch == 0) return TIO_OK;
+  if (x == nullptr || y == nullptr || lower_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_axis_gather_lerp: null argument");
+  if (upper_dev != nullptr && weight_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_axis_gather_lerp: upper without weights");
+  AxisArgs a{};
+  a.x = x; a.y = y; a.lower = lower_dev; a.upper = upper_dev; a.weight = weight_dev; a.active = active_dev;
+  a.batch = batch; a.channels = channels; a.axis = axis;
+  for (int d = 0; d < 3; d++) {
+    if (shape[d] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_axis_gather_lerp: shapes must be >= 1");
+    a.shape[d] = shape[d];
+  }
+  const int64_t total = static_cast<int64_t>(shape[0]) * shape[1] * shape[2] * batch * channels;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define TIO_CALL(DT) return launch_stream(axis_gather_lerp_kernel<DT>, a, total, s, "tio_axis_gather_lerp")
+  TIO_DISPATCH_DTYPE(dtype, TIO_CALL)
+#undef TIO_CALL
+  return TIO_OK;
+}

@@ -396,6 +396,49 @@ class Engine:
         return out
 
 
+    # -- F.interpolate users ---------------------------------------------------
+    def interpolate3d(self, data: Tensor, out_shape: Sequence[int], mode: str) -> Tensor:
+        """``F.interpolate(data.float(), size=out_shape, mode).to(data.dtype)``: ``"nearest"`` or ``"linear"`` (trilinear, align_corners)."""
+        if data.ndim != 5:
+            raise ValueError(f"expected a (B, C, I, J, K) tensor, got {tuple(data.shape)}")
+        data = data.contiguous()
+        self._check("interpolate3d", data)
+        out_shape = tuple(int(s) for s in out_shape)
+        out = torch.empty((*data.shape[:2], *out_shape), dtype=data.dtype, device=data.device)
+        self._call(
+            "interpolate3d", data, _ptr(data), _ptr(out), dtype_code(data.dtype), data.shape[0] * data.shape[1],
+            _i32x3(data.shape[2:]), _i32x3(out_shape), INTERP_CODES[mode], self._stream(data),
+        )
+        return out
+
+    def axis_gather_lerp(self, data: Tensor, axis: int, lower: Tensor, upper: Tensor | None = None,
+                         weight: Tensor | None = None, active: Tensor | None = None) -> Tensor:
+        """Per-element gather (``upper is None``) or two-point blend along one spatial axis; tables are ``(B, length)``."""
+        if data.ndim != 5:
+            raise ValueError(f"expected a (B, C, I, J, K) tensor, got {tuple(data.shape)}")
+        data = data.contiguous()
+        batch, length = data.shape[0], data.shape[2 + axis]
+
+        def table(t, dtype):
+            if t is None:
+                return None
+            t = h2d(t.to(dtype).contiguous(), data.device)
+            if tuple(t.shape) != (batch, length):
+                raise ValueError(f"index / weight tables must be (B, length) = {(batch, length)}, got {tuple(t.shape)}")
+            return t
+
+        lower, upper, weight = table(lower, torch.int32), table(upper, torch.int32), table(weight, torch.float32)
+        active = self._flags(active, batch, "active")
+        if active is not None:
+            active = h2d(active, data.device)
+        self._check("axis_gather_lerp", data, lower, upper, weight, active)
+        out = torch.empty_like(data)
+        self._call(
+            "axis_gather_lerp", data, _ptr(data), _ptr(out), dtype_code(data.dtype), batch, data.shape[1], _i32x3(data.shape[2:]),
+            int(axis), _ptr(lower), _ptr(upper), _ptr(weight), _ptr(active), self._stream(data),
+        )
+        return out
+
     # -- feeding side -------------------------------------------------------
     def patch_accumulate(
         self,

@@ -1,3 +1,4 @@
+from .anisotropy import Anisotropy
 from .bias_field import BiasField
 from .blur import Blur
 from .compose import Compose
@@ -7,6 +8,7 @@ from .noise import Noise
 from .noise import get_noise_rng
 from .noise import set_noise_rng
 from .parameter_range import Choice
+from .resize import Resize
 from .spatial import Affine
 from .spatial import ElasticDeformation
 from .spatial import Resample
@@ -17,7 +19,7 @@ from .transform import SpatialTransform
 from .transform import Transform
 
 __all__ = [
-    "Affine", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Gamma",
-    "IntensityTransform", "Noise", "Resample", "Spatial", "SpatialTransform", "Transform",
+    "Affine", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Gamma",
+    "IntensityTransform", "Noise", "Resample", "Resize", "Spatial", "SpatialTransform", "Transform",
     "get_inverse_transform", "get_noise_rng", "set_noise_rng",
 ]
