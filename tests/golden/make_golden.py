@@ -140,6 +140,23 @@ def label_map(shape, dtype, seg_kind, element):
     raise ValueError(seg_kind)
 
 
+CONTAINER_STEPS = [
+    ("Affine", dict(degrees=(-10, 10), translation=(-2, 2))),
+    ("Gamma", dict(log_gamma=(-0.3, 0.3))),
+    ("Noise", dict(std=(0.05, 0.1))),
+    ("Blur", dict(std=(0.5, 1.5))),
+]
+# name, class, container kwargs, batch size
+CONTAINERS = [
+    ("oneof_single", "OneOf", dict(), 1),
+    ("oneof_weights_p_batch", "OneOf", dict(weights=[0.1, 0.4, 0.3, 0.2], p=0.7), 4),
+    ("oneof_batch_shared", "OneOf", dict(per_instance=False), 3),
+    ("someof_single_range", "SomeOf", dict(num_transforms=(1, 3)), 1),
+    ("someof_batch_replace_p", "SomeOf", dict(num_transforms=(2, 4), replace=True, p=0.8), 3),
+    ("someof_batch_shared", "SomeOf", dict(num_transforms=2, per_instance=False), 2),
+]
+
+
 def make_inputs(shape, batch, kind, t1_dtype, seg_dtype, seed, seg_kind="spheres"):
     g = torch.Generator().manual_seed(seed)
     items = []
@@ -174,6 +191,8 @@ def run(lib, transform, items, seed):
         "t1": torch.stack([o.t1.data.contiguous() for o in outs]),
         "seg": torch.stack([o.seg.data.contiguous() for o in outs]),
         "affines": torch.stack([o.t1.affine.data.clone() for o in outs]),
+        # what each unbatched element carries (per-element branches of OneOf / SomeOf live only here)
+        "element_history": [[{"name": t.name, "params": t.params} for t in o.applied_transforms] for o in outs],
     }
     return out, result
 
@@ -201,6 +220,18 @@ def main():
         cases.append({"name": f"compose6_b{batch}", "cls": "Compose", "kwargs": {"steps": COMPOSE}, "seed": 6000 + batch,
                       "inputs": items, "expected": result})
         print(f"compose6_b{batch} history={[h['name'] for h in result['history']]}")
+    # OneOf / SomeOf (compose.py:101-280): the containers only draw gates / choices and delegate
+    for index, (name, cls, extra, batch) in enumerate(CONTAINERS):
+        items = make_inputs((12, 12, 12), batch, "identity", "float32", "int16", seed=7000 + index)
+        children = [getattr(tio, c)(**kw) for c, kw in CONTAINER_STEPS]
+        if cls == "OneOf" and "weights" in extra:
+            transform = tio.OneOf(dict(zip(children, extra["weights"])), **{k: v for k, v in extra.items() if k != "weights"})
+        else:
+            transform = getattr(tio, cls)(children, **extra)
+        _, result = run(tio, transform, items, seed=8000 + index)
+        cases.append({"name": name, "cls": cls, "kwargs": {"steps": CONTAINER_STEPS, "extra": extra}, "seed": 8000 + index,
+                      "inputs": items, "expected": result})
+        print(f"{name:32s} history={[h['name'] for h in result['history']]}")
     path = os.path.join(HERE, "transforms_golden.pt")
     torch.save({"torch": str(torch.__version__), "torchio": str(tio.__version__), "cases": cases}, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

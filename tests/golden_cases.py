@@ -42,6 +42,12 @@ def case_ids():
 def build_transform(case):
     if case["cls"] == "Compose":
         return tio.Compose([getattr(tio, cls)(**kwargs) for cls, kwargs in case["kwargs"]["steps"]])
+    if case["cls"] in ("OneOf", "SomeOf"):
+        children = [getattr(tio, cls)(**kwargs) for cls, kwargs in case["kwargs"]["steps"]]
+        extra = dict(case["kwargs"]["extra"])
+        if case["cls"] == "OneOf" and "weights" in extra:
+            return tio.OneOf(dict(zip(children, extra.pop("weights"), strict=True)), **extra)
+        return getattr(tio, case["cls"])(children, **extra)
     return getattr(tio, case["cls"])(**case["kwargs"])
 
 
@@ -74,6 +80,9 @@ def check_case(case, device: str) -> None:
     history = [{"name": t.name, "params": t.params} for t in out.applied_transforms]
     assert history == expected["history"], f"{case['name']}: sampled params differ from the reference"
     assert rng_probe == expected["rng_probe"], f"{case['name']}: global RNG consumed differently"
+    if "element_history" in expected:
+        element_history = [[{"name": t.name, "params": t.params} for t in o.applied_transforms] for o in outs]
+        assert element_history == expected["element_history"], f"{case['name']}: per-element histories differ"
 
     t1 = torch.stack([o.t1.data for o in outs]).cpu()
     seg = torch.stack([o.seg.data for o in outs]).cpu()

@@ -33,6 +33,8 @@ from .transforms import ElasticDeformation
 from .transforms import Gamma
 from .transforms import IntensityTransform
 from .transforms import Noise
+from .transforms import OneOf
+from .transforms import SomeOf
 from .transforms import Resample
 from .transforms import Resize
 from .transforms import Spatial
@@ -45,7 +47,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation",
-    "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise",
-    "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "Spatial", "SpatialTransform", "Subject",
+    "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise", "OneOf",
+    "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
     "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "get_noise_rng", "set_noise_rng",
 ]

@@ -2,6 +2,8 @@ from .anisotropy import Anisotropy
 from .bias_field import BiasField
 from .blur import Blur
 from .compose import Compose
+from .compose import OneOf
+from .compose import SomeOf
 from .gamma import Gamma
 from .inverse import get_inverse_transform
 from .noise import Noise
@@ -20,6 +22,6 @@ from .transform import Transform
 
 __all__ = [
     "Affine", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Gamma",
-    "IntensityTransform", "Noise", "Resample", "Resize", "Spatial", "SpatialTransform", "Transform",
+    "IntensityTransform", "Noise", "OneOf", "Resample", "Resize", "SomeOf", "Spatial", "SpatialTransform", "Transform",
     "get_inverse_transform", "get_noise_rng", "set_noise_rng",
 ]

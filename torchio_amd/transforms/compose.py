@@ -1,4 +1,4 @@
-"""``Compose`` (mirror of reference ``transforms/compose.py:38-93``).
+"""``Compose``, ``OneOf``, ``SomeOf`` (mirror of reference ``transforms/compose.py``).
 
 A plain sequential loop: the input is deep-copied once, wrapped once, every
 child runs with ``copy=False`` and appends its own history record.  ``Compose``
@@ -13,6 +13,11 @@ from collections.abc import Mapping
 from collections.abc import Sequence
 from typing import Any
 
+import contextlib
+
+import torch
+
+from ..data.batch import SubjectsBatch
 from .transform import Transform
 from .transform import _wrap
 
@@ -55,3 +60,143 @@ class Compose(Transform):
     def __repr__(self) -> str:
         inner = ", ".join(repr(t) for t in self.transforms)
         return f"Compose([{inner}])"
+
+
+@contextlib.contextmanager
+def _disabled_copy(transforms: Sequence[Transform]):
+    """Children of a container apply without copying: the container copied the input once (compose.py:18-35)."""
+    previous = [transform.copy for transform in transforms]
+    for transform in transforms:
+        transform.copy = False
+    try:
+        yield
+    finally:
+        for transform, value in zip(transforms, previous, strict=True):
+            transform.copy = value
+
+
+class OneOf(Transform):
+    """Apply one of the given transforms, chosen at random (compose.py:101-181).
+
+    ``transforms`` is a sequence (equal probabilities) or a ``dict`` transform -> relative weight.
+    On a batch with ``per_instance=True`` (the default) every element draws its own gate and its
+    own choice — global-RNG order per element: ``torch.rand(1)`` then ``torch.multinomial`` —
+    which needs shape- and schema-preserving children so that the elements can be re-stacked.
+    """
+
+    def __init__(self, transforms: Sequence[Transform] | dict[Transform, float], **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        if isinstance(transforms, dict):
+            self.transforms = list(transforms.keys())
+            weights = list(transforms.values())
+            total = sum(weights)
+            self.weights = [weight / total for weight in weights]
+        else:
+            self.transforms = list(transforms)
+            self.weights = [1.0 / len(self.transforms)] * len(self.transforms)
+
+    def _forward(self, data: Any) -> Any:
+        batch, unwrap = _wrap(data)
+        with _disabled_copy(self.transforms):
+            if self.per_instance and batch.batch_size > 1:
+                return unwrap(self._forward_per_element(batch))
+            if torch.rand(1).item() >= self.p:
+                return unwrap(batch)
+            index = int(torch.multinomial(torch.tensor(self.weights), num_samples=1).item())
+            return unwrap(self.transforms[index](batch))
+
+    def _forward_per_element(self, batch: SubjectsBatch) -> SubjectsBatch:
+        if self.p == 0:
+            return batch
+        weights = torch.tensor(self.weights)
+        subjects, any_applied = [], False
+        for subject in batch.unbatch():
+            if torch.rand(1).item() < self.p:
+                any_applied = True
+                index = int(torch.multinomial(weights, num_samples=1).item())
+                subject = _apply_to_element(subject, self.transforms[index])
+            subjects.append(subject)
+        return _rebatch_with_history(subjects, "OneOf") if any_applied else batch
+
+
+class SomeOf(Transform):
+    """Apply a random subset of the given transforms (compose.py:184-280).
+
+    ``num_transforms`` is a count or a ``(min, max)`` range drawn with ``torch.randint``; the
+    subset is ``torch.randperm(n)[:count]`` (or ``torch.randint`` indices with ``replace=True``).
+    """
+
+    def __init__(self, transforms: Sequence[Transform] | None = None, *, num_transforms: int | tuple[int, int] = 1,
+                 replace: bool = False, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.transforms = list(transforms) if transforms else []
+        self.num_transforms = num_transforms
+        self.replace = replace
+
+    @property
+    def _min_n(self) -> int:
+        return self.num_transforms if isinstance(self.num_transforms, int) else self.num_transforms[0]
+
+    @property
+    def _max_n(self) -> int:
+        return self.num_transforms if isinstance(self.num_transforms, int) else self.num_transforms[1]
+
+    def _forward(self, data: Any) -> Any:
+        batch, unwrap = _wrap(data)
+        with _disabled_copy(self.transforms):
+            if self.per_instance and batch.batch_size > 1:
+                return unwrap(self._forward_per_element(batch))
+            if torch.rand(1).item() >= self.p:
+                return unwrap(batch)
+            return unwrap(self._apply_subset(batch))
+
+    def _apply_subset(self, batch: SubjectsBatch) -> SubjectsBatch:
+        count = int(torch.randint(self._min_n, self._max_n + 1, size=(1,)).item())
+        available = len(self.transforms)
+        if self.replace:
+            indices = torch.randint(0, available, (count,))
+        else:
+            indices = torch.randperm(available)[: min(count, available)]
+        for index in indices:
+            batch = self.transforms[index](batch)
+        return batch
+
+    def _forward_per_element(self, batch: SubjectsBatch) -> SubjectsBatch:
+        if self.p == 0:
+            return batch
+        subjects, any_applied = [], False
+        for subject in batch.unbatch():
+            if torch.rand(1).item() < self.p:
+                any_applied = True
+                subject = _apply_to_element(subject, self._apply_subset)
+            subjects.append(subject)
+        return _rebatch_with_history(subjects, "SomeOf") if any_applied else batch
+
+
+def _apply_to_element(subject: Any, apply_fn: Any) -> Any:
+    """One element as a one-element batch seeded with its own history (compose.py:283-303)."""
+    element = SubjectsBatch.from_subjects([subject])
+    element.applied_transforms = list(subject.applied_transforms)
+    return apply_fn(element).unbatch()[0]
+
+
+def _rebatch_with_history(subjects: list[Any], transform_name: str) -> SubjectsBatch:
+    """Re-stack per-element results and freeze their distinct histories (compose.py:306-362)."""
+    reference = {name: type(image) for name, image in subjects[0].images.items()}
+    for subject in subjects[1:]:
+        if {name: type(image) for name, image in subject.images.items()} != reference:
+            raise RuntimeError(
+                f"Per-instance {transform_name} produced batch elements with different image names or types, which cannot"
+                f" be re-stacked. Use only schema-preserving transforms with per-instance {transform_name}, or pass"
+                " per_instance=False."
+            )
+    try:
+        batch = SubjectsBatch.from_subjects(subjects)
+    except (RuntimeError, KeyError, ValueError) as error:
+        raise RuntimeError(
+            f"Per-instance {transform_name} produced batch elements with different shapes or schemas, which cannot be"
+            f" re-stacked. Use only shape- and schema-preserving transforms with per-instance {transform_name}, or pass"
+            " per_instance=False."
+        ) from error
+    batch.set_per_element_history([subject.applied_transforms for subject in subjects])
+    return batch
