@@ -110,6 +110,12 @@ typedef struct tio_resample_geom {
   const uint8_t* passthrough_dev;
   float in_spacing[3];  /* AffineMatrix.spacing of the input grid, as float32    */
   float out_spacing[3]; /* ... of the output grid                                */
+  /* Shape whose (S - 1) normalises the voxel coordinates before grid_sample un-normalises
+   * them with the image's own (S - 1).  The reference builds ONE grid from the first selected
+   * image and samples every image with it (spatial.py:1136-1191, 1704), so an image of another
+   * shape (Resample("t1") on a multi-resolution subject) sees g = 2 v / (S_first - 1) - 1 but
+   * x = ((g + 1) / 2) (S_own - 1).  All zeros = in_shape (the usual case: every image shares it). */
+  int32_t norm_shape[3];
 } tio_resample_geom;
 
 /* One image tensor resampled with the shared geometry
@@ -273,6 +279,14 @@ int tio_axis_gather_lerp(const void* x, void* y, int32_t dtype, int32_t batch, i
                          const int32_t shape[3], int32_t axis, const int32_t* lower_dev,
                          const int32_t* upper_dev, const float* weight_dev, const uint8_t* active_dev,
                          void* stream);
+
+/*
+ * Flip (transforms/spatial/flip.py:182-236): y = torch.flip(x, axes) as one element move.
+ * axes_mask: bit a = flip spatial axis a for every element; flags_dev (B x 3 bytes, or NULL)
+ * overrides it per element (_flip_per_element: a flip + torch.where per axis in the reference).
+ */
+int tio_flip3d(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels,
+               const int32_t shape[3], int32_t axes_mask, const uint8_t* flags_dev, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Feeding side: dense-inference patch aggregation        */

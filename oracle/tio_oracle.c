@@ -238,10 +238,10 @@ static inline float affine_row(const float* m, float a, float b, float c) {
 
 /* g = 2 v / max(S-1,1) - 1  (spatial.py:1638-1646), then ATen
  * grid_sampler_unnormalize(align_corners=True): ((g + 1) / 2) * (S - 1). */
-static inline float normalise_roundtrip(float v, int32_t size) {
-  float denom = (float)((size - 1 > 1) ? size - 1 : 1);
+static inline float normalise_roundtrip(float v, int32_t norm_size, int32_t size) {
+  float denom = (float)((norm_size - 1 > 1) ? norm_size - 1 : 1); /* the grid's shape: the first image's */
   float g = 2.0f * v / denom - 1.0f;
-  return ((g + 1.0f) / 2.0f) * (float)(size - 1);
+  return ((g + 1.0f) / 2.0f) * (float)(size - 1); /* grid_sample un-normalises with the sampled image's own size */
 }
 
 static inline int in_bounds(float f, int32_t n) { return f >= 0.0f && f <= (float)(n - 1); }
@@ -399,9 +399,9 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
             vk = affine_row(m + 8, ci, cj, ck);
           }
           /* torchio axis i ≡ grid x ≡ ATen W; j ≡ y ≡ H; k ≡ z ≡ D */
-          const float x = normalise_roundtrip(vi, I);
-          const float y = normalise_roundtrip(vj, J);
-          const float z = normalise_roundtrip(vk, K);
+          const float x = normalise_roundtrip(vi, g->norm_shape[0] > 0 ? g->norm_shape[0] : I, I);
+          const float y = normalise_roundtrip(vj, g->norm_shape[1] > 0 ? g->norm_shape[1] : J, J);
+          const float z = normalise_roundtrip(vk, g->norm_shape[2] > 0 ? g->norm_shape[2] : K, K);
 
           /* trilinear corner indices and weights (ATen grid_sampler_3d) */
           const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
@@ -861,6 +861,29 @@ int tio_oracle_axis_gather_lerp(const void* x, void* y, int32_t dtype, int32_t b
         store_from_float(y, dtype, base + r, lower_term + upper_term);
       }
     }
+  return TIO_OK;
+}
+
+/* flip.py:182-236 */
+int tio_oracle_flip3d(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels, const int32_t shape[3],
+                      int32_t axes_mask, const uint8_t* flags, void* stream) {
+  (void)stream;
+  const size_t es = dtype_size(dtype);
+  if (es == 0) return TIO_ERR_UNSUPPORTED_DTYPE;
+  const int64_t n = (int64_t)shape[0] * shape[1] * shape[2];
+  for (int32_t b = 0; b < batch; b++) {
+    const int mask = flags ? ((flags[b * 3] ? 1 : 0) | (flags[b * 3 + 1] ? 2 : 0) | (flags[b * 3 + 2] ? 4 : 0)) : axes_mask;
+    for (int32_t c = 0; c < channels; c++) {
+      const int64_t base = ((int64_t)b * channels + c) * n;
+      for (int32_t i = 0; i < shape[0]; i++)
+        for (int32_t j = 0; j < shape[1]; j++)
+          for (int32_t k = 0; k < shape[2]; k++) {
+            const int32_t si = (mask & 1) ? shape[0] - 1 - i : i, sj = (mask & 2) ? shape[1] - 1 - j : j, sk = (mask & 4) ? shape[2] - 1 - k : k;
+            memcpy((char*)y + (base + ((int64_t)i * shape[1] + j) * shape[2] + k) * es,
+                   (const char*)x + (base + ((int64_t)si * shape[1] + sj) * shape[2] + sk) * es, es);
+          }
+    }
+  }
   return TIO_OK;
 }
 

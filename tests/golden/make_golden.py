@@ -114,6 +114,9 @@ CASES = [
     ("anisotropy_batch_nearest_image", "Anisotropy", dict(downsampling=(2, 6), image_interpolation="nearest"), (12, 10, 14), 3, "aniso", "float32", "uint8"),
     ("anisotropy_batch_shared", "Anisotropy", dict(axes=(1,), downsampling=(2, 3), per_instance=False), (10, 16, 12), 3, "identity", "float32", "int16"),
     ("anisotropy_f16_extreme_factor", "Anisotropy", dict(downsampling=40), (12, 12, 12), 2, "identity", "float16", "int16"),
+    # images of different shapes resampled onto a named image: the reference samples all of them with the first image's grid
+    ("resample_named_target_multires", "Resample", dict(target="t1"), (8, 10, 12), 1, "aniso", "float32", "int16", "multires"),
+    ("resample_spacing_multires_batch", "Resample", dict(target=(1.5, 2.0, 1.0)), (8, 10, 12), 2, "identity", "float32", "uint8", "multires"),
 ]
 
 COMPOSE = [
@@ -137,6 +140,8 @@ def label_map(shape, dtype, seg_kind, element):
     if seg_kind == "onehot":  # an already one-hot map: three channels
         base = spheres(shape, torch.int16)[0]
         return torch.stack([(base == 0), (base == 1) | (base == 2), (base >= 3)]).to(dtype)
+    if seg_kind == "multires":  # the label map at twice the resolution of the intensity image (same field of view)
+        return spheres(tuple(2 * n for n in shape), dtype)
     raise ValueError(seg_kind)
 
 
@@ -163,7 +168,12 @@ def make_inputs(shape, batch, kind, t1_dtype, seg_dtype, seed, seg_kind="spheres
     for element in range(batch):
         t1 = (torch.rand(2, *shape, generator=g) * 2 - 0.5).to(getattr(torch, t1_dtype))
         seg = label_map(shape, getattr(torch, seg_dtype), seg_kind, element)
-        items.append({"t1": t1, "seg": seg, "affine": affine_matrix(kind)})
+        item = {"t1": t1, "seg": seg, "affine": affine_matrix(kind)}
+        if seg_kind == "multires":
+            finer = affine_matrix(kind).clone()
+            finer[:3, :3] *= 0.5
+            item["seg_affine"] = finer
+        items.append(item)
     return items
 
 
@@ -171,7 +181,7 @@ def to_subjects(lib, items):
     return [
         lib.Subject(
             t1=lib.ScalarImage(it["t1"].clone(), affine=lib.AffineMatrix(it["affine"])),
-            seg=lib.LabelMap(it["seg"].clone(), affine=lib.AffineMatrix(it["affine"])),
+            seg=lib.LabelMap(it["seg"].clone(), affine=lib.AffineMatrix(it.get("seg_affine", it["affine"]))),
         )
         for it in items
     ]

@@ -28,6 +28,7 @@ BIT_EXACT_FLOAT = {
     "resample_random_spacing", "noise", "noise_f64",
     "resize_mixed", "resize_down_cube_nearest_image", "resize_f16_to_one_voxel_axis", "resize_f64_many_labels", "anisotropy",
     "anisotropy_batch_p", "anisotropy_batch_nearest_image", "anisotropy_batch_shared", "anisotropy_f16_extreme_factor",
+    "resample_named_target_multires", "resample_spacing_multires_batch",
 }
 
 
@@ -55,7 +56,7 @@ def build_input(case, device):
     subjects = [
         tio.Subject(
             t1=tio.ScalarImage(item["t1"].clone(), affine=tio.AffineMatrix(item["affine"])),
-            seg=tio.LabelMap(item["seg"].clone(), affine=tio.AffineMatrix(item["affine"])),
+            seg=tio.LabelMap(item["seg"].clone(), affine=tio.AffineMatrix(item.get("seg_affine", item["affine"]))),
         ).to(device)
         for item in case["inputs"]
     ]

@@ -30,6 +30,7 @@ from .transforms import Blur
 from .transforms import Choice
 from .transforms import Compose
 from .transforms import ElasticDeformation
+from .transforms import Flip
 from .transforms import Gamma
 from .transforms import IntensityTransform
 from .transforms import Noise
@@ -40,14 +41,16 @@ from .transforms import Resize
 from .transforms import Spatial
 from .transforms import SpatialTransform
 from .transforms import Transform
+from .transforms import apply_inverse_transform
+from .transforms import get_inverse_transform
 from .transforms import get_noise_rng
 from .transforms import set_noise_rng
 
 __version__ = "0.1.0"
 
 __all__ = [
-    "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation",
+    "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Flip",
     "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise", "OneOf",
     "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
-    "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "get_noise_rng", "set_noise_rng",
+    "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "set_noise_rng",
 ]

@@ -38,6 +38,7 @@ class ResampleGeom(C.Structure):
         ("passthrough_dev", C.c_void_p),
         ("in_spacing", C.c_float * 3),
         ("out_spacing", C.c_float * 3),
+        ("norm_shape", C.c_int32 * 3),
     ]
 
 
@@ -106,6 +107,7 @@ PROTOTYPES = {
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_void_p],
     ),
+    "flip3d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_int32, C.c_void_p, C.c_void_p]),
     "abi_version": (C.c_int, []),
 }
 

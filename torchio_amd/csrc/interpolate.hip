@@ -9,6 +9,8 @@
 //   (common.hpp; pinned bit for bit against F.interpolate by the oracle's golden vectors).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace tio {
@@ -115,6 +117,36 @@ __global__ __launch_bounds__(256) void axis_gather_lerp_kernel(const AxisArgs a)
   }
 }
 
+struct FlipArgs {
+  const void* x;
+  void* y;
+  const uint8_t* flags;  // (B, 3) per-element flags or nullptr (then `mask` applies to every element)
+  int batch, channels, shape[3];
+  int mask;              // bit a: flip spatial axis a
+};
+
+template <int ES>
+__global__ __launch_bounds__(256) void flip_kernel(const FlipArgs a) {
+  using RAW = typename std::conditional<ES == 1, uint8_t, typename std::conditional<ES == 2, uint16_t,
+              typename std::conditional<ES == 4, uint32_t, uint64_t>::type>::type>::type;
+  const int64_t n = static_cast<int64_t>(a.shape[0]) * a.shape[1] * a.shape[2];
+  const int64_t total = n * a.batch * a.channels;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t bc = t / n;
+    const int b = static_cast<int>(bc / a.channels);
+    const int64_t r = t - bc * n;
+    int k = static_cast<int>(r % a.shape[2]);
+    int j = static_cast<int>((r / a.shape[2]) % a.shape[1]);
+    int i = static_cast<int>(r / (static_cast<int64_t>(a.shape[1]) * a.shape[2]));
+    const int mask = a.flags != nullptr ? ((a.flags[b * 3] ? 1 : 0) | (a.flags[b * 3 + 1] ? 2 : 0) | (a.flags[b * 3 + 2] ? 4 : 0)) : a.mask;
+    if (mask & 1) i = a.shape[0] - 1 - i;
+    if (mask & 2) j = a.shape[1] - 1 - j;
+    if (mask & 4) k = a.shape[2] - 1 - k;
+    static_cast<RAW*>(a.y)[t] = static_cast<const RAW*>(a.x)[bc * n + (static_cast<int64_t>(i) * a.shape[1] + j) * a.shape[2] + k];
+  }
+}
+
 template <typename Kernel, typename Args>
 static int launch_stream(Kernel kernel, const Args& a, int64_t total, hipStream_t s, const char* what) {
   if (total == 0) return TIO_OK;
@@ -189,4 +221,29 @@ extern "C" int tio_axis_gather_lerp(const void* x, void* y, int32_t dtype, int32
   TIO_DISPATCH_DTYPE(dtype, TIO_CALL)
 #undef TIO_CALL
   return TIO_OK;
+}
+
+extern "C" int tio_flip3d(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels, const int32_t shape[3],
+                          int32_t axes_mask, const uint8_t* flags_dev, void* stream) {
+  using namespace tio;
+  if (shape == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_flip3d: null shape");
+  const int es = dtype_size(dtype);
+  if (es == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_flip3d: dtype %d", dtype);
+  if (batch < 0 || channels < 1 || axes_mask < 0 || axes_mask > 7) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_flip3d: bad argument");
+  if (batch == 0) return TIO_OK;
+  if (x == nullptr || y == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_flip3d: null data");
+  FlipArgs a{};
+  a.x = x; a.y = y; a.flags = flags_dev; a.batch = batch; a.channels = channels; a.mask = axes_mask;
+  for (int d = 0; d < 3; d++) {
+    if (shape[d] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_flip3d: shapes must be >= 1");
+    a.shape[d] = shape[d];
+  }
+  const int64_t total = static_cast<int64_t>(shape[0]) * shape[1] * shape[2] * batch * channels;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (es) {
+    case 1: return launch_stream(flip_kernel<1>, a, total, s, "tio_flip3d");
+    case 2: return launch_stream(flip_kernel<2>, a, total, s, "tio_flip3d");
+    case 4: return launch_stream(flip_kernel<4>, a, total, s, "tio_flip3d");
+    default: return launch_stream(flip_kernel<8>, a, total, s, "tio_flip3d");
+  }
 }

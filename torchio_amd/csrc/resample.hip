@@ -467,13 +467,15 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     a.rsp[d] = 1.0f / sp[d];
     if (sp[d] != 1.0f) a.unit_spacing = 0;
     const int size = geom->in_shape[d];
-    a.den[d] = static_cast<float>(size - 1 > 1 ? size - 1 : 1);
+    const int norm = geom->norm_shape[d] > 0 ? geom->norm_shape[d] : size;  // the grid's normalisation (first image's shape)
+    a.den[d] = static_cast<float>(norm - 1 > 1 ? norm - 1 : 1);
     a.rden[d] = 1.0f / a.den[d];
     a.size_m1[d] = static_cast<float>(size - 1);
     a.dh[d] = 0.5f * a.den[d];
     a.rdh[d] = 1.0f / a.dh[d];
     a.half_h[d] = 0.5f * a.size_m1[d];
     if (a.den[d] > 8192.0f) a.short_div = 0;
+    if (geom->norm_shape[d] < 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: negative norm_shape");
   }
   if (a.cp != nullptr) {
     if (geom->control_points_dev != nullptr && !(sp[0] > 0.0f && sp[1] > 0.0f && sp[2] > 0.0f))

@@ -69,6 +69,33 @@ class AffineMatrix:
     def direction(self) -> Tensor:
         return self._matrix[:3, :3] / self._column_norms()
 
+    @property
+    def orientation(self) -> tuple[str, str, str]:
+        """Anatomical orientation codes such as ``('R', 'A', 'S')`` (reference affine.py:124-128).
+
+        The reference asks nibabel (``aff2axcodes``); this is the same published algorithm: the
+        closest orthogonal matrix to the zoom-normalised direction block (SVD), then every voxel
+        axis claims the world axis on which it has the largest absolute component, each world
+        axis being claimed at most once.
+        """
+        block = self._matrix[:3, :3].cpu().numpy().astype(np.float64)
+        zooms = np.sqrt(np.sum(block * block, axis=0))
+        zooms[zooms == 0] = 1.0
+        left, singular, right = np.linalg.svd(block / zooms)
+        keep = singular > singular.max() * 3 * np.finfo(singular.dtype).eps
+        rotation = left[:, keep] @ right[keep]
+        labels = (("L", "R"), ("P", "A"), ("I", "S"))
+        codes: list[str] = []
+        for axis in range(3):
+            column = rotation[:, axis]
+            if np.allclose(column, 0):
+                codes.append(None)  # type: ignore[arg-type]
+                continue
+            world = int(np.argmax(np.abs(column)))
+            codes.append(labels[world][0 if column[world] < 0 else 1])
+            rotation[world, :] = 0  # a world axis is assigned once
+        return (codes[0], codes[1], codes[2])
+
     def to(self, *args, **kwargs) -> "AffineMatrix":
         """Affines stay float64 and — unlike image data — on the host.
 
@@ -90,6 +117,20 @@ class AffineMatrix:
 
     def inverse(self) -> "AffineMatrix":
         return AffineMatrix(torch.linalg.inv(self._matrix))
+
+    def compose(self, other: "AffineMatrix") -> "AffineMatrix":
+        """``self @ other`` as a new ``AffineMatrix`` (reference affine.py:178-183)."""
+        return AffineMatrix(self._matrix @ other._matrix)
+
+    def apply(self, points) -> Tensor:
+        """Map an ``(N, 3)`` set of points through the affine, in float64 (reference affine.py:185-205)."""
+        if not isinstance(points, Tensor):
+            pts = torch.as_tensor(np.asarray(points, dtype=np.float64), dtype=torch.float64)
+        else:
+            pts = points.to(torch.float64)
+        pts = pts.to(self._matrix.device)
+        homogeneous = torch.cat([pts, torch.ones(pts.shape[0], 1, dtype=torch.float64, device=pts.device)], dim=1)
+        return (self._matrix @ homogeneous.T).T[:, :3]
 
     def numpy(self) -> np.ndarray:
         return self._matrix.cpu().numpy()

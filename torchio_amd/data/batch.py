@@ -147,6 +147,13 @@ class SubjectsBatch(_History):
         metadata = {key: [subject.metadata[key] for subject in subjects] for key in first.metadata}
         return cls(images, metadata=metadata)
 
+    def adopt_history(self, source: "SubjectsBatch", subjects: list[Any]) -> None:
+        """Carry the history of *source* over after its subjects were unbatched, processed and re-stacked (batch.py:269-284)."""
+        if source._per_element_history is not None:
+            self.set_per_element_history([subject.applied_transforms for subject in subjects])
+        else:
+            self.applied_transforms = list(source.applied_transforms)
+
     def set_per_element_history(self, histories: list[list[Any]]) -> None:
         if len(histories) != self.batch_size:
             raise ValueError(f"Expected {self.batch_size} per-element histories, got {len(histories)}")

@@ -128,6 +128,7 @@ class Engine:
         passthrough: Tensor | None = None,
         label_tables: Sequence[Tensor | None] | None = None,
         pad_labels: Sequence[float] | None = None,
+        norm_shape: Sequence[int] | None = None,
     ) -> list[Tensor]:
         """Resample every ``(B, C, I, J, K)`` tensor in *images* through one coordinate pass.
 
@@ -175,6 +176,8 @@ class Engine:
         geom.passthrough_dev = None if passthrough is None else passthrough.data_ptr()
         geom.in_spacing = (C.c_float * 3)(*[float(s) for s in in_spacing])
         geom.out_spacing = (C.c_float * 3)(*[float(s) for s in out_spacing])
+        if norm_shape is not None:  # the shape the coordinates are normalised with, when it is not the images' own
+            geom.norm_shape = _i32x3(norm_shape)
         self._check("resample3d", mapping, control_points, cp_skip, passthrough)
 
         outputs: list[Tensor] = []
@@ -437,6 +440,27 @@ class Engine:
             "axis_gather_lerp", data, _ptr(data), _ptr(out), dtype_code(data.dtype), batch, data.shape[1], _i32x3(data.shape[2:]),
             int(axis), _ptr(lower), _ptr(upper), _ptr(weight), _ptr(active), self._stream(data),
         )
+        return out
+
+    def flip3d(self, data: Tensor, axes: Sequence[int] | None = None, per_element: Tensor | None = None) -> Tensor:
+        """``torch.flip`` along spatial ``axes`` (0..2), or per element with a ``(B, 3)`` flag tensor."""
+        if data.ndim != 5:
+            raise ValueError(f"expected a (B, C, I, J, K) tensor, got {tuple(data.shape)}")
+        data = data.contiguous()
+        mask = 0
+        for axis in axes or ():
+            if axis not in (0, 1, 2):
+                raise ValueError(f"Axis must be 0, 1, or 2; got {axis}")
+            mask |= 1 << axis
+        flags = None
+        if per_element is not None:
+            if tuple(per_element.shape) != (data.shape[0], 3):
+                raise ValueError(f"per-element flags must be (B, 3), got {tuple(per_element.shape)}")
+            flags = h2d(per_element.to(torch.uint8).contiguous(), data.device)
+        self._check("flip3d", data, flags)
+        out = torch.empty_like(data)
+        self._call("flip3d", data, _ptr(data), _ptr(out), dtype_code(data.dtype), data.shape[0], data.shape[1],
+                   _i32x3(data.shape[2:]), mask, _ptr(flags), self._stream(data))
         return out
 
     # -- feeding side -------------------------------------------------------

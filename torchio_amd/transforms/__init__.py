@@ -4,7 +4,9 @@ from .blur import Blur
 from .compose import Compose
 from .compose import OneOf
 from .compose import SomeOf
+from .flip import Flip
 from .gamma import Gamma
+from .inverse import apply_inverse_transform
 from .inverse import get_inverse_transform
 from .noise import Noise
 from .noise import get_noise_rng
@@ -21,7 +23,7 @@ from .transform import SpatialTransform
 from .transform import Transform
 
 __all__ = [
-    "Affine", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Gamma",
+    "Affine", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Flip", "Gamma",
     "IntensityTransform", "Noise", "OneOf", "Resample", "Resize", "SomeOf", "Spatial", "SpatialTransform", "Transform",
-    "get_inverse_transform", "get_noise_rng", "set_noise_rng",
+    "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "set_noise_rng",
 ]

@@ -32,3 +32,20 @@ def get_inverse_transform(
         step.exclude = trace.exclude
         steps.append(step)
     return Compose(steps)
+
+
+def apply_inverse_transform(data, *, warn: bool = True, ignore_intensity: bool = False):
+    """Undo every recorded transform of *data* (anything with ``applied_transforms``); inverse.py:64-100.
+
+    Batches that carry per-element histories (per-instance ``OneOf`` / ``SomeOf``) invert each
+    element with its own history through their own method.
+    """
+    if not hasattr(data, "applied_transforms"):
+        return data
+    if getattr(data, "_per_element_history", None) is not None:
+        return data.apply_inverse_transform(warn=warn, ignore_intensity=ignore_intensity)
+    inverse = get_inverse_transform(data.applied_transforms, warn=warn, ignore_intensity=ignore_intensity)
+    result = inverse(data)
+    if hasattr(result, "applied_transforms"):
+        result.applied_transforms = []
+    return result

@@ -539,6 +539,23 @@ def _apply_spatial_to_batch(
     mapping_dev = ops.h2d(torch.from_numpy(mapping), device)
 
     def resample(tensors, interps, fills, **label_arguments):
+        # images of another shape than the first (Resample onto a named image of a multi-resolution subject) are
+        # sampled with the first image's grid like in the reference (spatial.py:1136-1191): one call per shape
+        shapes = [tuple(t.shape[2:]) for t in tensors]
+        if any(shape != shapes[0] for shape in shapes) or shapes[0] != tuple(in_shape):
+            outputs: list = [None] * len(tensors)
+            for shape in dict.fromkeys(shapes):
+                members = [n for n, s in enumerate(shapes) if s == shape]
+                extra = {key: [value[n] for n in members] for key, value in label_arguments.items()}
+                results = engine.resample3d(
+                    [tensors[n] for n in members], out_shape=out_shape, mapping=mapping_dev, control_points=field_tensor,
+                    in_spacing=in_affine.spacing, out_spacing=out_affine.spacing, affine_first=affine_first,
+                    interps=[interps[n] for n in members], fills=[fills[n] for n in members], cp_skip=cp_skip,
+                    passthrough=passthrough, norm_shape=in_shape, **extra,
+                )
+                for n, result in zip(members, results, strict=True):
+                    outputs[n] = result
+            return outputs
         return engine.resample3d(
             tensors,
             out_shape=out_shape,
