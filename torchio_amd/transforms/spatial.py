@@ -91,21 +91,16 @@ class Spatial(SpatialTransform):
     ) -> None:
         super().__init__(**kwargs)
         self.target = target
-        if isotropic and not isinstance(scales, Distribution) and isinstance(scales, tuple) and len(scales) in (3, 6):
-            raise ValueError("If isotropic=True, scales must be a single value or a 2-value range")
+        _validate_isotropic(scales, isotropic)
         self.scales = _positive_range(scales)
         self.degrees = _parameter_range(degrees)
         self.translation = _parameter_range(translation)
         self.isotropic = isotropic
-        if center not in ("image", "origin"):
-            raise ValueError(f'center must be "image" or "origin", got "{center}"')
-        self.center = center
+        self.center = _parse_center(center)
         self.control_points = None if control_points is None else _parse_control_points(control_points)
         self.num_control_points = _parse_num_control_points(num_control_points)
         self.max_displacement = _nonnegative_range(max_displacement)
-        if locked_borders not in (0, 1, 2):
-            raise ValueError(f"locked_borders must be 0, 1, or 2, got {locked_borders}")
-        self.locked_borders = locked_borders
+        self.locked_borders = _parse_locked_borders(locked_borders)
         if self.locked_borders == 2 and 4 in self.num_control_points:
             raise ValueError("locked_borders=2 with 4 control points along any axis yields an identity elastic field")
         self.affine_first = affine_first
@@ -1097,6 +1092,24 @@ def _parameter_range(value) -> _ParameterRange:
     return _ParameterRange(value)
 
 
+def _validate_isotropic(value, isotropic: bool) -> None:
+    """``isotropic=True`` takes one value or one range, not per-axis values (spatial.py:2674-2683)."""
+    if isotropic and not isinstance(value, Distribution) and isinstance(value, tuple) and len(value) in (3, 6):
+        raise ValueError("If isotropic=True, scales must be a single value or a 2-value range")
+
+
+def _parse_center(center: str) -> str:
+    if center not in ("image", "origin"):
+        raise ValueError(f'center must be "image" or "origin", got "{center}"')
+    return center
+
+
+def _parse_locked_borders(value: int) -> int:
+    if value not in (0, 1, 2):
+        raise ValueError(f"locked_borders must be 0, 1, or 2, got {value}")
+    return value
+
+
 def _positive_range(value) -> _ParameterRange:
     parsed = _parameter_range(value)
     if parsed._distribution is None and any(lo <= 0 or hi <= 0 for lo, hi in parsed._ranges):
@@ -1109,3 +1122,8 @@ def _nonnegative_range(value) -> _ParameterRange:
     if parsed._distribution is None and any(lo < 0 or hi < 0 for lo, hi in parsed._ranges):
         raise ValueError(f"Value must be non-negative, got {value}")
     return parsed
+
+
+# the reference's names for the two range validators (spatial.py:2661-2672, 2621-2632)
+_to_positive_range = _positive_range
+_to_nonnegative_parameter_range = _nonnegative_range
