@@ -494,11 +494,18 @@ def _apply_spatial_to_batch(
     # (stacked: numpy runs the same LAPACK / BLAS routine per 4x4 slice as the one-at-a-time form)
     in_inverse = np.linalg.inv(in_affine.numpy())
     out_matrix = out_affine.numpy()
-    world = np.stack([np.eye(4) if matrix is None else np.asarray(matrix, dtype=np.float64) for matrix in matrices])
-    present = [index for index, matrix in enumerate(matrices) if matrix is not None]
-    if present:
-        world[present] = np.linalg.inv(world[present])
-    mapping = ((in_inverse @ world) @ out_matrix)[:, :3].astype(np.float32)
+    present_matrices = [index for index, matrix in enumerate(matrices) if matrix is not None]
+    mapping = None
+    if not present_matrices:
+        # pure elastic / gated-out batch: every element maps through inv(A_in) @ I @ A_out; when that IS the identity
+        # in float32 (it need not be bit for bit: inv(A) @ A carries float64 rounding) one cached device tensor serves
+        shared = ((in_inverse @ np.eye(4)) @ out_matrix)[:3].astype(np.float32)
+        if not np.array_equal(shared, _EYE34):
+            mapping = np.repeat(shared[None], len(matrices), axis=0)
+    else:
+        world = np.stack([np.eye(4) if matrix is None else np.asarray(matrix, dtype=np.float64) for matrix in matrices])
+        world[present_matrices] = np.linalg.inv(world[present_matrices])
+        mapping = ((in_inverse @ world) @ out_matrix)[:, :3].astype(np.float32)
 
     out_spacing = np.asarray(out_affine.spacing, dtype=np.float64)
     field_tensor = None
@@ -531,7 +538,7 @@ def _apply_spatial_to_batch(
         flags = [False] * batch_size
 
     engine = ops.engine()
-    mapping_dev = ops.h2d(torch.from_numpy(mapping), device)
+    mapping_dev = _identity_mapping(device) if mapping is None else ops.h2d(torch.from_numpy(mapping), device)
 
     def resample(tensors, interps, fills, **label_arguments):
         # images of another shape than the first (Resample onto a named image of a multi-resolution subject) are
@@ -686,6 +693,19 @@ def _label_partial_volume_composite(
         if keep:  # the kernel copied the one-hot rows; the labels of a gated-out element are the input's
             out[index] = data[index]
     return out
+
+
+_IDENTITY_MAPPINGS: dict[str, Tensor] = {}
+_EYE34 = np.eye(3, 4, dtype=np.float32)
+
+
+def _identity_mapping(device) -> Tensor:
+    """The shared ``(1, 3, 4)`` identity mapping, uploaded once per device (read-only)."""
+    key = str(device)
+    mapping = _IDENTITY_MAPPINGS.get(key)
+    if mapping is None:
+        mapping = _IDENTITY_MAPPINGS[key] = ops.h2d(torch.eye(3, 4, dtype=torch.float32)[None].contiguous(), device)
+    return mapping
 
 
 def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pad_label: float) -> Tensor | None:
