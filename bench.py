@@ -178,7 +178,7 @@ def main() -> None:
     # calls of a fresh process are ~30 % slower on the host side (pinned staging allocator, dispatcher and
     # Python caches still growing).  Same batch and shapes as the timed steps, so a profiler's per-kernel
     # averages over the whole process stay comparable with the live numbers below.
-    for _ in range(60):
+    for _ in range(100):
         transform(batch)
     torch.cuda.synchronize()
     torch.manual_seed(4321 + info.rank)

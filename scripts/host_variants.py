@@ -1,3 +1,4 @@
+"""Host-side enqueue time per bench step on the GPU box: first vs warm calls, GC on / off, and the host-only floor (tiny volumes)."""
 import gc, os, sys, time, warnings
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
