@@ -155,6 +155,8 @@ def main() -> None:
     parser.add_argument("--size", type=int, default=256)
     parser.add_argument("--batch", type=int, default=8, help="volumes per GPU per step")
     parser.add_argument("--noise-rng", choices=["reference", "philox"], default="philox")
+    parser.add_argument("--resample-precision", choices=["exact", "fast"], default="exact",
+                        help="exact = the reference's float32 operation sequence bit for bit (default); fast = opt-in fma path, within 1e-4")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-volumes", type=int, default=8)
     parser.add_argument("--aten-baseline", action="store_true", help="also time the stock-ATen restatement of the pipeline")
@@ -168,6 +170,7 @@ def main() -> None:
     warnings.simplefilter("ignore")
 
     tio.set_noise_rng(args.noise_rng)
+    tio.set_resample_precision(args.resample_precision)
     engine = ops.engine()
     timer = KernelTimer(engine, "resample3d")
     transform = build_transform()
@@ -229,6 +232,7 @@ def main() -> None:
                 "batch_per_gpu": args.batch,
                 "global_batch": args.batch * args.gpus,
                 "noise_rng": args.noise_rng,
+                "resample_precision": args.resample_precision,
                 "parallelism": f"batch-split x{args.gpus} (no data-path collective)",
             },
             "pipeline_algorithmic_GBps": total["algorithmic_bytes"] / total["elapsed_s"] / 1e9,

@@ -56,6 +56,11 @@ typedef enum tio_dtype {
   TIO_I64 = 8
 } tio_dtype;
 
+typedef enum tio_precision {
+  TIO_PRECISION_EXACT = 0,
+  TIO_PRECISION_FAST = 1
+} tio_precision;
+
 typedef enum tio_interp {
   TIO_NEAREST = 0, /* grid_sample(mode="nearest"): nearbyint, half-to-even      */
   TIO_LINEAR = 1,  /* grid_sample(mode="bilinear"): 8-tap trilinear, zero pad   */
@@ -116,6 +121,13 @@ typedef struct tio_resample_geom {
    * shape (Resample("t1") on a multi-resolution subject) sees g = 2 v / (S_first - 1) - 1 but
    * x = ((g + 1) / 2) (S_own - 1).  All zeros = in_shape (the usual case: every image shares it). */
   int32_t norm_shape[3];
+  /* tio_precision.  TIO_PRECISION_EXACT (0, the default): the reference's float32 operation
+   * sequence, bit for bit.  TIO_PRECISION_FAST: launches whose images are all float32 and
+   * trilinear may skip the normalise / un-normalise round trip of the coordinates and
+   * interpolate with nested fma lerps — same interpolant, different rounding: within ~1e-5
+   * absolute of the exact result on unit-range data (the north_star bar for intensities is
+   * 1e-4 relative); any launch with a nearest / label image stays exact.              */
+  int32_t precision;
 } tio_resample_geom;
 
 /* One image tensor resampled with the shared geometry

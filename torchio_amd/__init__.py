@@ -22,6 +22,8 @@ from .data import LabelMap
 from .data import ScalarImage
 from .data import Subject
 from .data import SubjectsBatch
+from .ops import get_resample_precision
+from .ops import set_resample_precision
 from .transforms import Affine
 from .transforms import Anisotropy
 from .transforms import AppliedTransform
@@ -52,5 +54,5 @@ __all__ = [
     "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Flip",
     "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise", "OneOf",
     "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
-    "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "set_noise_rng",
+    "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "set_noise_rng", "set_resample_precision",
 ]

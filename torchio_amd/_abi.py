@@ -19,6 +19,8 @@ UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing
 F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
 # tio_interp
 NEAREST, LINEAR, LABEL_PV = 0, 1, 2
+# tio_precision
+PRECISION_EXACT, PRECISION_FAST = 0, 1
 
 
 class ResampleGeom(C.Structure):
@@ -39,6 +41,7 @@ class ResampleGeom(C.Structure):
         ("in_spacing", C.c_float * 3),
         ("out_spacing", C.c_float * 3),
         ("norm_shape", C.c_int32 * 3),
+        ("precision", C.c_int32),
     ]
 
 

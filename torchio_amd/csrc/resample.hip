@@ -596,6 +596,26 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
       TIO_TILE_LAUNCH(false, 0, TI, TJ, TK, OCC)                                        \
     }                                                                               \
   }
+    // fast intensity path: float32 trilinear images only (nearest / label images need the exact coordinates)
+    const bool fast = geom->precision == TIO_PRECISION_FAST && dtmode == 0 && !a.any_nearest && variant == 0 &&
+                      getenv("TIO_RESAMPLE_EXACT") == nullptr;
+    if (fast) {
+      a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
+      a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;
+      a.magic_j = a.tiles_j > 1 ? 0xFFFFFFFFu / a.tiles_j + 1u : 0u;
+      a.magic_i = a.tiles_i > 1 ? 0xFFFFFFFFu / a.tiles_i + 1u : 0u;
+      const int64_t blocks = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
+      if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+      auto launch_fast = [&](auto kernel) -> int {
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   static_cast<int>(lds)) != hipSuccess)
+          return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
+        return check_launch("tio_resample3d");
+      };
+      if (a.cp != nullptr) return launch_fast(resample_tile_kernel<true, 0, 16, 16, 16, 3, true>);
+      return launch_fast(resample_tile_kernel<false, 0, 16, 16, 16, 3, true>);
+    }
     switch (variant) {
       case 1: TIO_TILE_SHAPE_F32(16, 8, 32, 3) break;
       case 2: TIO_TILE_SHAPE_F32(8, 8, 32, 4) break;

@@ -32,6 +32,30 @@ FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
 INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR, "label": _abi.LABEL_PV}
 
 
+PRECISION_CODES = {"exact": _abi.PRECISION_EXACT, "fast": _abi.PRECISION_FAST}
+_RESAMPLE_PRECISION = "exact"
+
+
+def set_resample_precision(mode: str) -> None:
+    """Process-wide arithmetic of ``tio_resample3d`` for float32 trilinear images.
+
+    ``"exact"`` (default) reproduces the reference's float32 operation sequence bit for bit.
+    ``"fast"`` lets launches made only of float32 trilinear images skip the coordinates'
+    normalise / un-normalise round trip and interpolate with nested fma lerps: the same
+    interpolant, results within ~1e-5 of the exact ones on unit-range data (the contract for
+    intensities is 1e-4 relative), ~25 % less kernel time.  Launches with a nearest-neighbour or
+    ``"label"`` image are always exact, so label maps stay bit-identical.
+    """
+    global _RESAMPLE_PRECISION
+    if mode not in PRECISION_CODES:
+        raise ValueError(f"precision must be one of {sorted(PRECISION_CODES)}, got {mode!r}")
+    _RESAMPLE_PRECISION = mode
+
+
+def get_resample_precision() -> str:
+    return _RESAMPLE_PRECISION
+
+
 def h2d(tensor: Tensor, device) -> Tensor:
     """Upload a (small) host tensor without stalling the device.
 
@@ -129,6 +153,7 @@ class Engine:
         label_tables: Sequence[Tensor | None] | None = None,
         pad_labels: Sequence[float] | None = None,
         norm_shape: Sequence[int] | None = None,
+        precision: str | None = None,
     ) -> list[Tensor]:
         """Resample every ``(B, C, I, J, K)`` tensor in *images* through one coordinate pass.
 
@@ -178,6 +203,7 @@ class Engine:
         geom.out_spacing = (C.c_float * 3)(*[float(s) for s in out_spacing])
         if norm_shape is not None:  # the shape the coordinates are normalised with, when it is not the images' own
             geom.norm_shape = _i32x3(norm_shape)
+        geom.precision = PRECISION_CODES[precision if precision is not None else _RESAMPLE_PRECISION]
         self._check("resample3d", mapping, control_points, cp_skip, passthrough)
 
         outputs: list[Tensor] = []
