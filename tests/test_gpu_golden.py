@@ -15,3 +15,10 @@ CASES = {case["name"]: case for case in load_cases()}
 @pytest.mark.parametrize("name", case_ids())
 def test_golden_case_on_hip(name, hip):
     check_case(CASES[name], "cuda")
+
+
+def test_aten_known_answers_on_hip(hip):
+    """the empirically pinned grid_sample semantics, frozen as known-answer vectors."""
+    import known_answers
+
+    known_answers.check(hip, "cuda")
