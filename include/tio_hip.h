@@ -300,6 +300,24 @@ int tio_axis_gather_lerp(const void* x, void* y, int32_t dtype, int32_t batch, i
 int tio_flip3d(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels,
                const int32_t shape[3], int32_t axes_mask, const uint8_t* flags_dev, void* stream);
 
+typedef enum tio_pad_mode {
+  TIO_PAD_CONSTANT = 0,  /* F.pad(mode="constant", value=fill); also the statistic modes (per-element constants) */
+  TIO_PAD_REFLECT = 1,   /* F.pad(mode="reflect"): mirror without repeating the edge                              */
+  TIO_PAD_REPLICATE = 2, /* F.pad(mode="replicate"): clamp                                                        */
+  TIO_PAD_CIRCULAR = 3   /* F.pad(mode="circular"): wrap                                                          */
+} tio_pad_mode;
+
+/*
+ * pad_tensor (transforms/spatial/_padding.py:62-104; Pad, pad.py:88-108; GridSampler's border
+ * padding, data/sampler.py:127-147): y = F.pad(x, (k0, k1, j0, j1, i0, i1), mode, value) as one
+ * element move.  padding = (i0, i1, j0, j1, k0, k1).  The 'mean' / 'median' / 'minimum' modes of
+ * the reference are constant padding with one value per batch element: fill_per_element_dev
+ * (B values of the image dtype) overrides `fill` then.
+ */
+int tio_pad3d(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels,
+              const int32_t in_shape[3], const int32_t padding[6], int32_t mode, double fill,
+              const void* fill_per_element_dev, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* Feeding side: dense-inference patch aggregation        */
 /* ------------------------------------------------------------------------ */

@@ -887,6 +887,53 @@ int tio_oracle_flip3d(const void* x, void* y, int32_t dtype, int32_t batch, int3
   return TIO_OK;
 }
 
+/* _padding.py:62-104 (F.pad semantics) */
+static int pad_source_index(int q, int n, int mode) {
+  if (mode == TIO_PAD_REPLICATE) return q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+  if (mode == TIO_PAD_CIRCULAR) {
+    q %= n;
+    return q < 0 ? q + n : q;
+  }
+  if (n == 1) return 0;
+  const int period = 2 * (n - 1);
+  q %= period;
+  if (q < 0) q += period;
+  return q < n ? q : period - q;
+}
+
+int tio_oracle_pad3d(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels, const int32_t in_shape[3],
+                     const int32_t padding[6], int32_t mode, double fill, const void* fill_per_element, void* stream) {
+  (void)stream;
+  const size_t es = dtype_size(dtype);
+  if (es == 0) return TIO_ERR_UNSUPPORTED_DTYPE;
+  int32_t out[3];
+  for (int d = 0; d < 3; d++) out[d] = in_shape[d] + padding[2 * d] + padding[2 * d + 1];
+  const int64_t n_in = (int64_t)in_shape[0] * in_shape[1] * in_shape[2], n_out = (int64_t)out[0] * out[1] * out[2];
+  for (int32_t b = 0; b < batch; b++)
+    for (int32_t c = 0; c < channels; c++) {
+      const int64_t bc = (int64_t)b * channels + c;
+      for (int32_t i = 0; i < out[0]; i++)
+        for (int32_t j = 0; j < out[1]; j++)
+          for (int32_t k = 0; k < out[2]; k++) {
+            int32_t si = i - padding[0], sj = j - padding[2], sk = k - padding[4];
+            const int inside = si >= 0 && si < in_shape[0] && sj >= 0 && sj < in_shape[1] && sk >= 0 && sk < in_shape[2];
+            const int64_t o = bc * n_out + ((int64_t)i * out[1] + j) * out[2] + k;
+            if (!inside && mode == TIO_PAD_CONSTANT) {
+              if (fill_per_element) memcpy((char*)y + o * es, (const char*)fill_per_element + (size_t)b * es, es);
+              else store_from_double(y, dtype, o, fill);
+              continue;
+            }
+            if (!inside) {
+              si = pad_source_index(si, in_shape[0], mode);
+              sj = pad_source_index(sj, in_shape[1], mode);
+              sk = pad_source_index(sk, in_shape[2], mode);
+            }
+            memcpy((char*)y + o * es, (const char*)x + (bc * n_in + ((int64_t)si * in_shape[1] + sj) * in_shape[2] + sk) * es, es);
+          }
+    }
+  return TIO_OK;
+}
+
 int tio_oracle_abi_version(void) { return TIO_ABI_VERSION; }
 
 int tio_oracle_num_threads(void) {

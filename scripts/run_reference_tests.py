@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFERENCE_TESTS = "/root/reference/tests"
 DEFAULT_FILES = [
     "test_blur.py", "test_gamma.py", "test_noise.py", "test_bias_field.py", "test_spatial.py", "test_resize.py", "test_anisotropy.py",
-    "test_flip.py", "test_compose.py", "test_one_of.py", "test_some_of.py", "test_inverse.py", "test_parameter_range.py",
+    "test_flip.py", "test_pad.py", "test_crop.py", "test_compose.py", "test_one_of.py", "test_some_of.py", "test_inverse.py", "test_parameter_range.py",
     "test_patches.py", "test_queue.py", "test_affine.py", "test_batch.py",
 ]
 
@@ -62,8 +62,10 @@ def install_alias() -> None:
         setattr(package, key, value)
     sys.modules["torchio.transforms.spatial"] = package
     sys.modules["torchio.transforms.spatial.spatial"] = Shim("torchio.transforms.spatial.spatial")
-    for name in ("anisotropy", "resize", "flip"):  # flat modules here, members of the spatial package there
+    for name in ("anisotropy", "resize", "flip", "pad"):  # flat modules here, members of the spatial package there
         sys.modules[f"torchio.transforms.spatial.{name}"] = importlib.import_module(f"torchio_amd.transforms.{name}")
+    sys.modules["torchio.transforms.spatial.crop"] = sys.modules["torchio.transforms.spatial.pad"]  # Pad and Crop share a module
+    sys.modules["torchio.transforms.spatial._padding"] = sys.modules["torchio.transforms.spatial.pad"]
 
 
 def run_one(name: str) -> int:

@@ -117,6 +117,23 @@ CASES = [
     # images of different shapes resampled onto a named image: the reference samples all of them with the first image's grid
     ("resample_named_target_multires", "Resample", dict(target="t1"), (8, 10, 12), 1, "aniso", "float32", "int16", "multires"),
     ("resample_spacing_multires_batch", "Resample", dict(target=(1.5, 2.0, 1.0)), (8, 10, 12), 2, "identity", "float32", "uint8", "multires"),
+    # Pad / Crop (pad.py:36-122, crop.py:33-112, _padding.py): element moves + an origin shift
+    ("pad_six_constant_fill", "Pad", dict(padding=(2, 3, 1, 0, 4, 2), fill=-1.5), (8, 10, 12), 2, "aniso", "float32", "int16"),
+    ("pad_one_value_oblique", "Pad", dict(padding=3), (6, 5, 4), 1, "oblique", "float64", "uint8"),
+    ("pad_three_reflect", "Pad", dict(padding=(3, 2, 1), padding_mode="reflect"), (8, 10, 12), 2, "identity", "float32", "float32", "many"),
+    ("pad_replicate_f16", "Pad", dict(padding=(0, 4, 2, 2, 5, 0), padding_mode="replicate"), (6, 7, 8), 1, "aniso", "float16", "float32", "many"),
+    ("pad_circular_full_wrap", "Pad", dict(padding=(6, 1, 0, 7, 3, 3), padding_mode="circular"), (6, 7, 8), 2, "identity", "float32", "float32", "many"),
+    ("pad_mean_batch", "Pad", dict(padding=(1, 2, 3), padding_mode="mean"), (10, 9, 8), 3, "identity", "float32", "int16"),
+    ("pad_median_batch", "Pad", dict(padding=(2, 1, 2, 1, 0, 3), padding_mode="median"), (10, 9, 8), 3, "identity", "float32", "int16"),
+    ("pad_minimum_multires", "Pad", dict(padding=2, padding_mode="minimum"), (8, 10, 12), 2, "identity", "float32", "int16", "multires"),
+    ("crop_six", "Crop", dict(cropping=(2, 3, 1, 0, 4, 2)), (12, 10, 14), 2, "oblique", "float32", "int16"),
+    ("crop_three_to_one_voxel_axis", "Crop", dict(cropping=(0, 2, 5)), (6, 7, 11), 1, "aniso", "float16", "int32"),
+    # Flip (flip.py:76-236): per-axis coins, per-element axes, anatomical labels
+    ("flip_axis0", "Flip", dict(axes=0), (8, 10, 12), 1, "identity", "float32", "int16"),
+    ("flip_all_axes_coin_batch", "Flip", dict(axes=(0, 1, 2), flip_probability=0.5), (8, 10, 12), 4, "aniso", "float32", "int16"),
+    ("flip_anatomical_oblique_f16", "Flip", dict(axes=("Left", "A")), (7, 9, 6), 2, "oblique", "float16", "uint8"),
+    ("flip_batch_p_shared", "Flip", dict(axes=(1, 2), flip_probability=0.7, p=0.8, per_instance=False), (6, 6, 6), 3, "identity", "float64", "int64"),
+    ("flip_multires", "Flip", dict(axes=(0, 2)), (8, 10, 12), 2, "identity", "float32", "int16", "multires"),
 ]
 
 COMPOSE = [
@@ -214,7 +231,7 @@ def main():
         transform = getattr(tio, cls)(**kwargs)
         out, result = run(tio, transform, items, seed=2000 + index)
         entry = {"name": name, "cls": cls, "kwargs": kwargs, "seed": 2000 + index, "inputs": items, "expected": result}
-        if cls in ("Affine", "ElasticDeformation", "Spatial", "Resample", "BiasField", "Gamma") and batch <= 2:
+        if cls in ("Affine", "ElasticDeformation", "Spatial", "Resample", "BiasField", "Gamma", "Pad", "Crop", "Flip") and batch <= 2:
             restored = out.apply_inverse_transform()
             outs = [restored] if batch == 1 else restored.unbatch()
             entry["inverse"] = {

@@ -49,6 +49,10 @@ SAMPLER_CASES = [
     ("weighted", dict(shape=(14, 12, 10), patch_size=(4, 6, 4), num_patches=5, seed=12)),
     ("label", dict(shape=(14, 12, 10), patch_size=4, num_patches=5, seed=13, label_probabilities=None)),
     ("label", dict(shape=(14, 12, 10), patch_size=(4, 4, 6), num_patches=5, seed=14, label_probabilities={1: 1.0, 2: 3.0})),
+    # padded before sampling (sampler.py:127-147): overlap // 2 voxels per side through Pad
+    ("grid", dict(shape=(20, 18, 16), patch_size=8, patch_overlap=4, padding_mode="constant", fill=-2.0)),
+    ("grid", dict(shape=(13, 11, 12), patch_size=(8, 6, 10), patch_overlap=(2, 4, 6), padding_mode="reflect")),
+    ("grid", dict(shape=(10, 12, 9), patch_size=6, patch_overlap=(2, 0, 4), padding_mode="mean")),
 ]
 
 

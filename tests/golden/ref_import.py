@@ -3,7 +3,8 @@
 Test/fixture infrastructure only.  The reference needs a few
 non-hot-path third-party modules that are not installed in this image
 (SimpleITK, nibabel, jaxtyping, loguru, humanize, tyro); none of them is used
-by the augmentation hot path, so empty stubs are enough.  Nothing under
+by the augmentation hot path, so empty stubs are enough (one exception: ``Flip`` with anatomical
+labels asks nibabel for the axis codes; the stub restates that published algorithm).  Nothing under
 ``torchio_amd/`` imports this file, and nothing here is available on the GPU
 box (``/root/reference`` does not travel).
 """
@@ -39,6 +40,32 @@ class _Logger:
         return lambda *a, **k: None
 
 
+def _aff2axcodes(affine, labels=(("L", "R"), ("P", "A"), ("I", "S")), tol=None):
+    """nibabel 5.x ``orientations.aff2axcodes`` restated (``io_orientation`` + ``ornt2axcodes``): the closest
+    world axis of every voxel axis after removing the zooms and projecting onto the nearest orthogonal matrix."""
+    import numpy as np  # noqa: PLC0415
+
+    rzs = np.asarray(affine, dtype=np.float64)[:3, :3]
+    zooms = np.sqrt((rzs * rzs).sum(axis=0))
+    zooms[zooms == 0] = 1
+    rs = rzs / zooms
+    p, s, qs = np.linalg.svd(rs, full_matrices=False)
+    if tol is None:
+        tol = s.max() * 3 * np.finfo(s.dtype).eps
+    keep = s > tol
+    r = p[:, keep] @ qs[keep]
+    codes = []
+    for in_ax in range(3):
+        col = r[:, in_ax]
+        if np.allclose(col, 0):
+            codes.append(None)
+            continue
+        out_ax = int(np.argmax(np.abs(col)))
+        codes.append(labels[out_ax][0 if col[out_ax] < 0 else 1])
+        r[out_ax, :] = 0
+    return tuple(codes)
+
+
 def import_reference():
     """Return the reference ``torchio`` module (imported once, cached)."""
     if "torchio" in sys.modules and getattr(sys.modules["torchio"], "_tio_ref", False):
@@ -51,7 +78,7 @@ def import_reference():
     if "nibabel" not in sys.modules:
         nib = _stub("nibabel", Nifti1Image=type("Nifti1Image", (), {}))
         nib.spatialimages = _stub("nibabel.spatialimages", SpatialImage=type("SpatialImage", (), {}))
-        nib.orientations = _stub("nibabel.orientations")
+        nib.orientations = _stub("nibabel.orientations", aff2axcodes=_aff2axcodes)
     if "jaxtyping" not in sys.modules:
         names = ["Float", "Int", "Bool", "Shaped", "Num", "UInt8", "Integer", "Real", "Inexact", "Array"]
         _stub("jaxtyping", **{n: type(n, (_Subscriptable,), {}) for n in names})

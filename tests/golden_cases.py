@@ -29,6 +29,9 @@ BIT_EXACT_FLOAT = {
     "resize_mixed", "resize_down_cube_nearest_image", "resize_f16_to_one_voxel_axis", "resize_f64_many_labels", "anisotropy",
     "anisotropy_batch_p", "anisotropy_batch_nearest_image", "anisotropy_batch_shared", "anisotropy_f16_extreme_factor",
     "resample_named_target_multires", "resample_spacing_multires_batch",
+    "pad_six_constant_fill", "pad_one_value_oblique", "pad_three_reflect", "pad_replicate_f16", "pad_circular_full_wrap",
+    "pad_median_batch", "pad_minimum_multires", "crop_six", "crop_three_to_one_voxel_axis",
+    "flip_axis0", "flip_all_axes_coin_batch", "flip_anatomical_oblique_f16", "flip_batch_p_shared", "flip_multires",
 }
 
 

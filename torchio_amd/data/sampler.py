@@ -48,12 +48,9 @@ class GridSampler(PatchSampler, Dataset):
         if isinstance(patch_overlap, int):
             patch_overlap = (patch_overlap, patch_overlap, patch_overlap)
         self.patch_overlap: tuple[int, int, int] = tuple(patch_overlap)  # type: ignore[assignment]
-        if padding_mode is not None:
-            # the reference pads through its Pad transform (sampler.py:127-147), which is outside this engine
-            raise NotImplementedError("GridSampler(padding_mode=...) needs the Pad transform, which torchio_amd does not provide")
         self.padding_mode = padding_mode
         self.fill = fill
-        self.subject = subject
+        self.subject = self._maybe_pad(subject)
         self.locations = self._compute_locations(self.subject.spatial_shape)
 
     def __len__(self) -> int:
@@ -61,6 +58,16 @@ class GridSampler(PatchSampler, Dataset):
 
     def __getitem__(self, index: int) -> Subject:
         return self._extract_patch(self.subject, self.locations[index])
+
+    def _maybe_pad(self, subject: Subject) -> Subject:
+        """Pad the volume by ``overlap // 2`` on each side before sampling (sampler.py:127-147)."""
+        if self.padding_mode is None:
+            return subject
+        from ..transforms.pad import Pad  # noqa: PLC0415
+
+        border = tuple(v // 2 for v in self.patch_overlap)
+        padding = (border[0], border[0], border[1], border[1], border[2], border[2])
+        return Pad(padding=padding, padding_mode=self.padding_mode, fill=self.fill, copy=False)(subject)
 
     def _compute_locations(self, spatial_shape) -> list[PatchLocation]:
         indices_per_axis: list[list[int]] = []

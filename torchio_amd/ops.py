@@ -489,6 +489,31 @@ class Engine:
                    _i32x3(data.shape[2:]), mask, _ptr(flags), self._stream(data))
         return out
 
+    def pad3d(self, data: Tensor, padding: Sequence[int], mode: str = "constant", fill: float = 0.0,
+              fill_per_element: Tensor | None = None) -> Tensor:
+        """``F.pad`` of the three spatial axes: ``padding = (i0, i1, j0, j1, k0, k1)``, ``mode`` as in ``F.pad``.
+
+        ``fill_per_element``: ``(B,)`` constants (one per batch element, any dtype: cast to the data's).
+        """
+        if data.ndim != 5:
+            raise ValueError(f"expected a (B, C, I, J, K) tensor, got {tuple(data.shape)}")
+        code = {"constant": _abi.PAD_CONSTANT, "reflect": _abi.PAD_REFLECT, "replicate": _abi.PAD_REPLICATE, "circular": _abi.PAD_CIRCULAR}[mode]
+        data = data.contiguous()
+        padding = [int(p) for p in padding]
+        if len(padding) != 6:
+            raise ValueError("padding must have 6 values (i0, i1, j0, j1, k0, k1)")
+        shape = [data.shape[2 + d] + padding[2 * d] + padding[2 * d + 1] for d in range(3)]
+        fills = None
+        if fill_per_element is not None:
+            fills = fill_per_element.to(device=data.device, dtype=data.dtype).contiguous()
+            if fills.numel() != data.shape[0]:
+                raise ValueError("one fill value per batch element")
+        self._check("pad3d", data, fills)
+        out = torch.empty((*data.shape[:2], *shape), dtype=data.dtype, device=data.device)
+        self._call("pad3d", data, _ptr(data), _ptr(out), dtype_code(data.dtype), data.shape[0], data.shape[1], _i32x3(data.shape[2:]),
+                   (C.c_int32 * 6)(*padding), code, float(fill), _ptr(fills), self._stream(data))
+        return out
+
     # -- feeding side -------------------------------------------------------
     def patch_accumulate(
         self,

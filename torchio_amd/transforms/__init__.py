@@ -11,6 +11,8 @@ from .inverse import get_inverse_transform
 from .noise import Noise
 from .noise import get_noise_rng
 from .noise import set_noise_rng
+from .pad import Crop
+from .pad import Pad
 from .parameter_range import Choice
 from .resize import Resize
 from .spatial import Affine
@@ -23,7 +25,7 @@ from .transform import SpatialTransform
 from .transform import Transform
 
 __all__ = [
-    "Affine", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "ElasticDeformation", "Flip", "Gamma",
-    "IntensityTransform", "Noise", "OneOf", "Resample", "Resize", "SomeOf", "Spatial", "SpatialTransform", "Transform",
+    "Affine", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "Crop", "ElasticDeformation", "Flip", "Gamma",
+    "IntensityTransform", "Noise", "OneOf", "Pad", "Resample", "Resize", "SomeOf", "Spatial", "SpatialTransform", "Transform",
     "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "set_noise_rng",
 ]
