@@ -726,7 +726,7 @@ def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pa
     elif default_pad_value == "minimum":
         return engine.channel_min(data)  # stays on the device: no .item() sync
     elif default_pad_value in ("mean", "otsu"):
-        values = [_border_mean(channel, filter_otsu=default_pad_value == "otsu") for channel in data[0]]
+        values = [_compute_channel_pad_value(channel, default_pad_value) for channel in data[0]]
         return ops.h2d(torch.tensor(values, dtype=torch.float32), data.device)
     else:
         raise ValueError(f'Unknown default_pad_value "{default_pad_value}"')
@@ -735,39 +735,54 @@ def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pa
     return ops.h2d(torch.full((channels,), value, dtype=torch.float32), data.device)
 
 
+def _compute_channel_pad_value(channel: Tensor, strategy: str) -> float:
+    """One channel's pad value for ``"minimum"`` / ``"mean"`` / ``"otsu"`` (spatial.py:2089-2101); host-side form."""
+    if strategy == "minimum":
+        return float(channel.min().item())
+    if strategy in ("mean", "otsu"):
+        return _border_mean(channel, filter_otsu=strategy == "otsu")
+    raise ValueError(f'Unknown default_pad_value "{strategy}"')
+
+
 def _border_mean(channel: Tensor, *, filter_otsu: bool) -> float:
     """Mean of the six boundary faces, optionally of the voxels under their Otsu threshold.
 
-    Rare, non-default pad modes (spatial.py:2104-2168): the faces (6 S^2 values)
+    Rare, non-default pad modes (spatial.py:2104-2131): the faces (6 S^2 values)
     are brought to the host and reduced in float32/float64 numpy.
     """
     faces = [channel[0], channel[-1], channel[:, 0], channel[:, -1], channel[:, :, 0], channel[:, :, -1]]
-    borders = torch.cat([f.reshape(-1) for f in faces]).float().cpu().numpy()
+    borders = torch.cat([f.reshape(-1) for f in faces]).float().cpu()
     if not filter_otsu:
-        return float(torch.from_numpy(borders).mean().item())
-    ordered = np.sort(borders)
+        return float(borders.mean().item())
+    below = borders[borders < _otsu_threshold(borders)]
+    if below.numel():
+        return float(below.mean().item())
+    return float(borders.mean().item())
+
+
+def _otsu_threshold(values: Tensor) -> float:
+    """Otsu sweep over the sorted values: maximise ``w_b * w_f * (mean_b - mean_f)^2`` (spatial.py:2133-2168).
+
+    Vectorised; the running sums are float64 like the reference's Python floats, the total is the float32
+    ``Tensor.sum`` it starts from, and the first maximum wins like its strict ``>`` comparison.
+    """
+    ordered = np.sort(values.detach().reshape(-1).float().cpu().numpy())
     count = ordered.size
     if count == 0:
         return 0.0
-    # Otsu sweep over sorted values: maximise w_b * w_f * (mean_b - mean_f)^2 (spatial.py:2133-2168),
-    # vectorised; accumulations run in float64 like the reference's Python floats.
-    values = ordered.astype(np.float64)
+    as_double = ordered.astype(np.float64)
     total = float(torch.from_numpy(ordered).sum().item())
-    background_sum = np.cumsum(values[:-1])
+    background_sum = np.cumsum(as_double[:-1])
     background_count = np.arange(1, count, dtype=np.float64)
     foreground_count = count - background_count
     mean_background = background_sum / background_count
     mean_foreground = (total - background_sum) / foreground_count
     variance = (background_count / count) * (foreground_count / count) * (mean_background - mean_foreground) ** 2
-    threshold = float(values[0])
     if variance.size:
-        best = int(np.argmax(variance))  # first maximum, like the strict `>` sweep
+        best = int(np.argmax(variance))
         if variance[best] > 0.0:
-            threshold = float(values[best])
-    below = borders[borders < threshold]
-    if below.size:
-        return float(torch.from_numpy(below).mean().item())
-    return float(torch.from_numpy(borders).mean().item())
+            return float(as_double[best])
+    return float(as_double[0])
 
 
 def _antialias(engine, data: Tensor, in_affine: AffineMatrix, out_affine: AffineMatrix) -> Tensor:
@@ -1014,30 +1029,52 @@ def _resolve_target_space(target, batch: SubjectsBatch, first_shape, first_affin
             f'Unknown target "{target}". Pass an image name in the subject, an Image, a (shape, affine) pair'
             " or a spacing specification (reading a target image from a file path is not supported here)"
         )
-    if isinstance(target, tuple) and len(target) == 2 and not isinstance(target[0], Number):
-        shape, affine = target
-        if len(shape) != 3:
-            raise ValueError(f"Target shape must have length 3, got {len(shape)}")
-        return tuple(int(s) for s in shape), AffineMatrix(affine)
+    if _is_target_space_tuple(target):
+        return _parse_target_space_tuple(*target)
     if not isinstance(target, (int, float, tuple, list, np.ndarray, Choice, Distribution)):
         raise ValueError(f'Target not understood: "{target}"')
     return _new_shape_affine(first_shape, first_affine, _resolve_target_spacing(target))
 
 
-def _resolve_target_spacing(value) -> tuple[float, float, float]:
-    """Deterministic or random spacing spec → positive 3-tuple (spatial.py:1446-1469)."""
+def _is_target_space_tuple(target) -> bool:
+    """``(shape, affine)``; a 2-tuple of plain numbers is a spacing range instead (spatial.py:1425-1443)."""
+    return isinstance(target, tuple) and len(target) == 2 and not isinstance(target[0], Number)
+
+
+def _parse_target_space_tuple(shape, affine):
+    if len(shape) != 3:
+        raise ValueError(f"Target shape must have length 3, got {len(shape)}")
+    return tuple(int(s) for s in shape), AffineMatrix(affine)
+
+
+def _is_spacing_tuple(value) -> bool:
+    return isinstance(value, tuple) and len(value) == 3
+
+
+def _is_spacing_list(value) -> bool:
+    return isinstance(value, list) and len(value) == 3
+
+
+def _parse_spacing(value) -> tuple[float, float, float]:
+    """A fixed spacing: one number or three (tuple / list / array), strictly positive (spatial.py:1504-1524)."""
     if isinstance(value, np.ndarray):
         spacing = tuple(float(v) for v in value.flat)
-    elif isinstance(value, (int, float)):
+    elif isinstance(value, Number):
         spacing = (float(value),) * 3
     else:
-        spacing = _ParameterRange(tuple(value) if isinstance(value, list) else value).sample()
+        spacing = tuple(float(v) for v in value)
     if len(spacing) != 3:
         raise ValueError(f"Spacing must have 3 values, got {len(spacing)}")
-    spacing = tuple(float(v) for v in spacing)
     if any(v <= 0 for v in spacing):
         raise ValueError(f"Spacing must be strictly positive, got {spacing}")
     return spacing  # type: ignore[return-value]
+
+
+def _resolve_target_spacing(value) -> tuple[float, float, float]:
+    """Deterministic or random spacing spec → positive 3-tuple (spatial.py:1446-1469)."""
+    if isinstance(value, (np.ndarray, int, float)):
+        return _parse_spacing(value)
+    return _parse_spacing(_ParameterRange(tuple(value) if isinstance(value, list) else value).sample())
 
 
 def _new_shape_affine(shape, affine: AffineMatrix, spacing):
