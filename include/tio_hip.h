@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 3
+#define TIO_ABI_VERSION 4
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -360,6 +360,43 @@ int tio_patch_accumulate(void* out, void* weight_sum, int32_t dtype, int32_t cha
                          const int32_t patch_shape[3], const tio_patch_placement* placements_host,
                          int32_t mode, const float* window_i_dev, const float* window_j_dev,
                          const float* window_k_dev, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Motion: k-space compositing                                               */
+/* ------------------------------------------------------------------------ */
+#define TIO_MAX_SEGMENTS 32
+
+/*
+ * _apply_motion_segments (transforms/intensity/motion.py:334-372).  The reference takes
+ * spectrum = fftn(x_0), overwrites the planes [bounds[s], bounds[s+1]) along the FIRST
+ * spatial axis with the same planes of fftn(x_s) for every motion segment s >= 1 (x_s: the
+ * rigidly moved image, tio_resample3d with the matrix of _apply_rigid_transform,
+ * motion.py:393-425) and returns ifftn(spectrum).real.  Only the first axis is masked, so
+ * the transforms along J and K cancel and the composite is the real linear map
+ *
+ *     out[b, c, i, j, k] = sum_s sum_i' W[s][i'][i] * x_s[b, c, i', j, k]
+ *     W[s][i'][i] = (1 / I) * sum_{f = bounds[s]}^{bounds[s+1] - 1} cos(2 pi f (i - i') / I)
+ *
+ * which tio_kspace_segment_mix evaluates as one float32 GEMM per (b, c) on the matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact float32 products and sums, no FFT, no complex volumes).
+ *   segments    host array of n_segments DEVICE pointers, each a float32 (B, C, I, J, K)
+ *               tensor: segments[0] = data.float(), segments[s] = moved image s
+ *   bounds      host, n_segments + 1 plane indices, bounds[0] = 0, bounds[n_segments] = I
+ *               (_segment_bounds, motion.py:375-390)
+ *   mix_dev     device, float32 (n_segments, I, I): the table W above; fill a host buffer
+ *               with tio_kspace_mix_table (float64 arithmetic) and upload it once per shape
+ *   out         device (B, C, I, J, K) of `dtype` (`.to(data.dtype)`); must not alias a segment
+ *   active_dev  device, B bytes or NULL: elements with 0 are skipped, their `out` rows are NOT
+ *               written (the caller restores them from the input, torch.where in the reference)
+ * Parity: float rounding only (the reference's complex64 FFTs and this GEMM are two float32
+ * evaluations of the same sums): <= 1e-5 of the image's magnitude in the tests.
+ */
+int tio_kspace_segment_mix(const void* const* segments, int32_t n_segments, const int32_t* bounds,
+                           const float* mix_dev, void* out, int32_t dtype, int32_t batch,
+                           int32_t channels, const int32_t shape[3], const uint8_t* active_dev,
+                           void* stream);
+/* Host helper: fills table_host (n_segments * length * length floats) with W. */
+int tio_kspace_mix_table(int32_t length, int32_t n_segments, const int32_t* bounds, float* table_host);
 
 /* ------------------------------------------------------------------------ */
 /* Introspection                                                             */

@@ -934,6 +934,98 @@ int tio_oracle_pad3d(const void* x, void* y, int32_t dtype, int32_t batch, int32
   return TIO_OK;
 }
 
+/* ---- Motion: k-space compositing (transforms/intensity/motion.py:334-390) ------------------
+ * The reference's algorithm, literally: 3-D DFT of the still image, planes [bounds[s], bounds[s+1])
+ * along the first spatial axis overwritten with the same planes of the moved image's DFT, inverse
+ * 3-D DFT, real part.  The transforms are plain O(n^2)-per-line DFTs in float64 (test sizes only);
+ * the reference runs complex64 FFTs, so the two agree to float32 rounding, not bit for bit. */
+static void dft_axis(double* re, double* im, const int32_t shape[3], int axis, int inverse) {
+  const int len = shape[axis];
+  if (len == 1) return;
+  const int64_t stride = axis == 0 ? (int64_t)shape[1] * shape[2] : (axis == 1 ? shape[2] : 1);
+  const int64_t total = (int64_t)shape[0] * shape[1] * shape[2];
+  double* cs = (double*)malloc(sizeof(double) * 2 * (size_t)len);
+  for (int t = 0; t < len; t++) {
+    cs[2 * t] = cos(2.0 * M_PI * t / len);
+    cs[2 * t + 1] = (inverse ? 1.0 : -1.0) * sin(2.0 * M_PI * t / len);
+  }
+  double* line = (double*)malloc(sizeof(double) * 2 * (size_t)len);
+  for (int64_t base = 0; base < total; base++) {
+    if ((base / stride) % len != 0) continue; /* first element of every line along `axis` */
+    for (int f = 0; f < len; f++) {
+      double sr = 0.0, si = 0.0;
+      for (int t = 0; t < len; t++) {
+        const int64_t w = ((int64_t)f * t) % len;
+        const double xr = re[base + t * stride], xi = im[base + t * stride];
+        sr += xr * cs[2 * w] - xi * cs[2 * w + 1];
+        si += xr * cs[2 * w + 1] + xi * cs[2 * w];
+      }
+      line[2 * f] = sr;
+      line[2 * f + 1] = si;
+    }
+    for (int f = 0; f < len; f++) {
+      re[base + f * stride] = inverse ? line[2 * f] / len : line[2 * f];
+      im[base + f * stride] = inverse ? line[2 * f + 1] / len : line[2 * f + 1];
+    }
+  }
+  free(line);
+  free(cs);
+}
+
+int tio_oracle_kspace_segment_mix(const void* const* segments, int32_t n_segments, const int32_t* bounds, const float* mix,
+                                  void* out, int32_t dtype, int32_t batch, int32_t channels, const int32_t shape[3],
+                                  const uint8_t* active, void* stream) {
+  (void)stream;
+  (void)mix; /* the table is the HIP library's formulation; the oracle follows the reference's FFT route */
+  if (segments == NULL || bounds == NULL || shape == NULL) return TIO_ERR_INVALID_ARGUMENT;
+  if (n_segments < 1 || n_segments > TIO_MAX_SEGMENTS || bounds[0] != 0 || bounds[n_segments] != shape[0]) return TIO_ERR_INVALID_ARGUMENT;
+  if (dtype_size(dtype) == 0) return TIO_ERR_UNSUPPORTED_DTYPE;
+  const int64_t total = (int64_t)shape[0] * shape[1] * shape[2], plane = (int64_t)shape[1] * shape[2];
+  double* buffers = (double*)malloc(sizeof(double) * 4 * (size_t)total);
+  double *sr = buffers, *si = buffers + total, *mr = buffers + 2 * total, *mi = buffers + 3 * total;
+  for (int64_t bc = 0; bc < (int64_t)batch * channels; bc++) {
+    if (active != NULL && active[bc / channels] == 0) continue;
+    for (int s = 0; s < n_segments; s++) {
+      const float* x = (const float*)segments[s] + bc * total;
+      double *r = s == 0 ? sr : mr, *i = s == 0 ? si : mi;
+      for (int64_t v = 0; v < total; v++) { r[v] = (double)x[v]; i[v] = 0.0; }
+      for (int axis = 0; axis < 3; axis++) dft_axis(r, i, shape, axis, 0);
+      if (s > 0) { /* spectrum[:, :, start:end] = moved_spectrum[:, :, start:end] */
+        memcpy(sr + bounds[s] * plane, mr + bounds[s] * plane, sizeof(double) * (size_t)((bounds[s + 1] - bounds[s]) * plane));
+        memcpy(si + bounds[s] * plane, mi + bounds[s] * plane, sizeof(double) * (size_t)((bounds[s + 1] - bounds[s]) * plane));
+      }
+    }
+    for (int axis = 0; axis < 3; axis++) dft_axis(sr, si, shape, axis, 1);
+    for (int64_t v = 0; v < total; v++) store_from_double(out, dtype, bc * total + v, (double)(float)sr[v]); /* .real (float32) .to(dtype) */
+  }
+  free(buffers);
+  return TIO_OK;
+}
+
+/* The table of the GEMM formulation, restated independently (closed form of the cosine sum:
+ * Dirichlet kernel) so that the tests can hold the HIP library's direct summation against it. */
+int tio_oracle_kspace_mix_table(int32_t length, int32_t n_segments, const int32_t* bounds, float* table) {
+  if (bounds == NULL || table == NULL || length < 1 || n_segments < 1) return TIO_ERR_INVALID_ARGUMENT;
+  if (bounds[0] != 0 || bounds[n_segments] != length) return TIO_ERR_INVALID_ARGUMENT;
+  for (int s = 0; s < n_segments; s++) {
+    const int lo = bounds[s], count = bounds[s + 1] - bounds[s];
+    if (count < 0) return TIO_ERR_INVALID_ARGUMENT;
+    for (int d = 0; d < length; d++) {
+      /* sum_{f=lo}^{lo+count-1} cos(f t) = sin(count t / 2) / sin(t / 2) * cos((2 lo + count - 1) t / 2), t = 2 pi d / I */
+      double value;
+      if (d == 0) {
+        value = (double)count;
+      } else {
+        const double t = 2.0 * M_PI * d / length;
+        value = sin(count * t / 2.0) / sin(t / 2.0) * cos((2.0 * lo + count - 1.0) * t / 2.0);
+      }
+      const float w = (float)(value / length);
+      for (int ip = 0; ip < length; ip++) table[(int64_t)s * length * length + (int64_t)ip * length + (ip + d) % length] = w;
+    }
+  }
+  return TIO_OK;
+}
+
 int tio_oracle_abi_version(void) { return TIO_ABI_VERSION; }
 
 int tio_oracle_num_threads(void) {

@@ -134,6 +134,12 @@ CASES = [
     ("flip_anatomical_oblique_f16", "Flip", dict(axes=("Left", "A")), (7, 9, 6), 2, "oblique", "float16", "uint8"),
     ("flip_batch_p_shared", "Flip", dict(axes=(1, 2), flip_probability=0.7, p=0.8, per_instance=False), (6, 6, 6), 3, "identity", "float64", "int64"),
     ("flip_multires", "Flip", dict(axes=(0, 2)), (8, 10, 12), 2, "identity", "float32", "int16", "multires"),
+    # Motion (motion.py:32-561): rigid copies + k-space slabs; float rounding only (FFT vs GEMM evaluation)
+    ("motion", "Motion", dict(), (16, 14, 12), 1, "identity", "float32", "int16"),
+    ("motion_batch_p_three_events", "Motion", dict(degrees=(5, 25), translation=(-3, 3), num_transforms=3, p=0.6), (13, 10, 12), 4, "aniso", "float32", "int16"),
+    ("motion_2d_shared_one_event", "Motion", dict(num_transforms=1, per_instance=False), (9, 12, 1), 3, "identity", "float32", "uint8"),
+    ("motion_f64_many_events", "Motion", dict(degrees=3.0, translation=1.5, num_transforms=7), (8, 6, 7), 2, "oblique", "float64", "int16"),
+    ("motion_f16", "Motion", dict(), (12, 12, 12), 1, "identity", "float16", "int16"),
 ]
 
 COMPOSE = [

@@ -446,3 +446,83 @@ def test_pad3d_per_element_constants_and_limits(oracle, hip):
     with pytest.raises(EngineError, match="paddings >= 0"):
         hip.pad3d(data.to(DEV), (0, 0, 0, -1, 0, 0))
     assert hip.pad3d(data[:0].to(DEV), (1, 1, 1, 1, 1, 1)).shape == (0, 2, 7, 8, 9)
+
+
+def _segments(shape, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(*shape, generator=g) * 4 - 1) for _ in range(n)]
+
+
+@pytest.mark.parametrize(
+    "shape,bounds",
+    [
+        ((2, 1, 12, 6, 5), [0, 4, 8, 12]),           # unaligned plane, one row tile
+        ((1, 2, 16, 8, 8), [0, 8, 16]),              # float4 path
+        ((1, 1, 150, 7, 9), [0, 37, 74, 111, 150]),  # two row tiles per wave (I > 128), ragged rows and columns
+        ((1, 1, 260, 4, 36), [0, 130, 260]),         # two blocks along the rows (I > 256)
+        ((3, 1, 9, 12, 1), [0, 9]),                  # one segment: the identity map
+        ((1, 1, 33, 20, 20), [0, 0, 11, 33]),        # an empty slab
+    ],
+)
+def test_kspace_segment_mix_matches_the_fft_route(oracle, hip, shape, bounds):
+    segments = _segments(shape, len(bounds) - 1, 201)
+    cpu = oracle.kspace_segment_mix(segments, bounds, torch.float32)
+    gpu = hip.kspace_segment_mix([s.to(DEV) for s in segments], bounds, torch.float32)
+    torch.cuda.synchronize()
+    # two float32 evaluations of the same sums (float64 DFT on the oracle side): <= 1e-5 of the magnitude
+    assert float((cpu - gpu.cpu()).abs().max()) <= 1e-5 * 4
+    spectrum = torch.fft.fftn(segments[0].double(), dim=(-3, -2, -1))
+    for s in range(1, len(segments)):
+        spectrum[:, :, bounds[s] : bounds[s + 1]] = torch.fft.fftn(segments[s].double(), dim=(-3, -2, -1))[:, :, bounds[s] : bounds[s + 1]]
+    expected = torch.fft.ifftn(spectrum, dim=(-3, -2, -1)).real
+    assert float((expected - gpu.cpu().double()).abs().max()) <= 1e-5 * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16, torch.bfloat16, torch.int16, torch.uint8])
+def test_kspace_segment_mix_output_dtypes_and_inactive_rows(oracle, hip, dtype):
+    shape, bounds = (3, 2, 10, 6, 8), [0, 5, 10]
+    segments = [s * 20 + 30 for s in _segments(shape, 2, 203)]  # positive, integer-scale values
+    active = torch.tensor([1, 0, 1], dtype=torch.uint8)
+    cpu = oracle.kspace_segment_mix(segments, bounds, dtype, active=active)
+    gpu = hip.kspace_segment_mix([s.to(DEV) for s in segments], bounds, dtype, active=active.to(DEV))
+    torch.cuda.synchronize()
+    assert gpu.dtype == dtype
+    diff = (cpu[[0, 2]].double() - gpu.cpu()[[0, 2]].double()).abs().max()
+    # float outputs: rounding of the storage type; integer outputs truncate, so a 1e-5 difference may cross an integer
+    bound = {torch.float64: 1e-3, torch.float16: 0.07, torch.bfloat16: 0.6}.get(dtype, 1.0)
+    assert float(diff) <= bound
+    if not dtype.is_floating_point:
+        assert float((cpu[[0, 2]].double() != gpu.cpu()[[0, 2]].double()).double().mean()) < 1e-3
+
+
+def test_kspace_segment_mix_properties_at_full_size(hip):
+    """256^3 (the bench volume): slabs tile k-space, so equal segments give the image back; the map is linear."""
+    g = torch.Generator().manual_seed(205)
+    x = torch.rand(1, 1, 256, 256, 256, generator=g).to(DEV)
+    y = torch.rand(1, 1, 256, 256, 256, generator=g).to(DEV)
+    bounds = [0, 85, 170, 256]
+    same = hip.kspace_segment_mix([x, x, x], bounds, torch.float32)
+    assert float((same - x).abs().max()) <= 1e-5
+    mixed = hip.kspace_segment_mix([x, y, x], bounds, torch.float32)
+    other = hip.kspace_segment_mix([y, x, y], bounds, torch.float32)
+    assert float((mixed + other - (x + y)).abs().max()) <= 2e-5  # W_0 + W_1 + W_2 = identity
+    assert float((mixed - x).abs().max()) > 0.1
+    # the FFT route on the same device, for one (j, k) column block only (a full complex 256^3 is 128 MiB per copy)
+    xs, ys = x[..., :8, :8].contiguous(), y[..., :8, :8].contiguous()
+    spectrum = torch.fft.fft(xs.double(), dim=2)
+    spectrum[:, :, 85:170] = torch.fft.fft(ys.double(), dim=2)[:, :, 85:170]
+    expected = torch.fft.ifft(spectrum, dim=2).real
+    assert float((expected - mixed[..., :8, :8].double()).abs().max()) <= 1e-5
+
+
+def test_kspace_segment_mix_argument_errors(hip):
+    from torchio_amd.ops import EngineError
+
+    x = torch.rand(1, 1, 8, 4, 4, device=DEV)
+    with pytest.raises(EngineError, match="bounds must run from 0"):
+        hip.kspace_segment_mix([x, x], [0, 4, 7], torch.float32)
+    with pytest.raises(ValueError, match="float32 tensors of one shape"):
+        hip.kspace_segment_mix([x, x.double()], [0, 4, 8], torch.float32)
+    with pytest.raises(ValueError, match="at most"):
+        hip.kspace_segment_mix([x] * 40, list(range(41)), torch.float32)
+    assert hip.kspace_segment_mix([x[:0], x[:0]], [0, 4, 8], torch.float32).shape == (0, 1, 8, 4, 4)

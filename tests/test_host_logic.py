@@ -541,3 +541,44 @@ def test_grid_sampler_padding_covers_the_border_with_full_weight():
     aggregator.add_batch(torch.stack([p.t1.data for p in patches]), [p.patch_location for p in patches])
     restored = tio.Crop(cropping=(1, 1, 1, 1, 2, 2))(tio.Subject(out=tio.ScalarImage(aggregator.get_output())))
     assert torch.equal(restored.out.data, volume)
+
+
+# -- Motion --------------------------------------------------------------------------
+def test_motion_parameters_gating_and_errors():
+    with pytest.raises(ValueError, match="num_transforms"):
+        tio.Motion(num_transforms=0)
+    with pytest.raises(ValueError, match="num_transforms"):
+        tio.Motion(num_transforms=1.5)
+    sub = subject(12, 1)
+    torch.manual_seed(3)
+    out = tio.Motion(degrees=15, translation=4, num_transforms=3)(sub)
+    (applied,) = out.applied_transforms
+    assert applied.name == "Motion" and len(applied.params["transforms"]) == 3
+    assert all(set(t) == {"degrees", "translation"} and len(t["degrees"]) == 3 for t in applied.params["transforms"])
+    assert all(abs(v) <= 15 for t in applied.params["transforms"] for v in t["degrees"])
+    assert not torch.equal(out.t1.data, sub.t1.data) and torch.equal(out.seg.data, sub.seg.data)  # label maps untouched
+    assert out.t1.data.dtype == sub.t1.data.dtype and out.t1.shape == sub.t1.shape
+    with pytest.raises(ValueError, match="motion segments"):
+        tio.Motion(num_transforms=12)(sub)  # 13 segments on a 12-plane axis
+
+    # zero motion: every segment is the still image and the slabs tile k-space, so the composite is the image
+    still = tio.Motion(degrees=0, translation=0, num_transforms=4)(sub)
+    torch.testing.assert_close(still.t1.data, sub.t1.data, rtol=0, atol=2e-6)
+
+    b = batch(4, 10, 2)
+    torch.manual_seed(5)
+    out = tio.Motion(p=0.5)(b)
+    lists = out.applied_transforms[-1].params["transforms"]
+    assert len(lists) == 4 and any(len(entry) == 0 for entry in lists) and any(len(entry) == 2 for entry in lists)
+    for index, entry in enumerate(lists):
+        same = torch.equal(out.t1.data[index], b.t1.data[index])
+        assert same == (len(entry) == 0)  # gated-out rows come back bit for bit
+    shared = tio.Motion(per_instance=False)(b)
+    assert isinstance(shared.applied_transforms[-1].params["transforms"][0], dict)
+    from torchio_amd.transforms.motion import _apply_motion_per_instance
+
+    with pytest.raises(ValueError, match="Expected 4 motion parameter lists"):
+        _apply_motion_per_instance(b.t1.data, [[]])
+    one = {"degrees": (1.0, 0.0, 0.0), "translation": (0.0, 0.0, 0.0)}
+    with pytest.raises(ValueError, match="uniform motion transform counts"):
+        _apply_motion_per_instance(b.t1.data, [[one], [one, one], [], [one]])

@@ -37,6 +37,7 @@ from .transforms import ElasticDeformation
 from .transforms import Flip
 from .transforms import Gamma
 from .transforms import IntensityTransform
+from .transforms import Motion
 from .transforms import Noise
 from .transforms import OneOf
 from .transforms import SomeOf
@@ -54,7 +55,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "Crop", "ElasticDeformation", "Flip",
-    "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Noise", "OneOf",
+    "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Motion", "Noise", "OneOf",
     "Pad", "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
     "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "set_noise_rng", "set_resample_precision",
 ]

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_IMAGES = 8
 
 # tio_status
@@ -70,6 +70,7 @@ class PatchPlacement(C.Structure):
 
 
 MAX_PATCHES = 32
+MAX_SEGMENTS = 32  # TIO_MAX_SEGMENTS
 # tio_overlap_mode
 OVERLAP_CROP, OVERLAP_AVERAGE, OVERLAP_HANN = 0, 1, 2
 
@@ -118,6 +119,12 @@ PROTOTYPES = {
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.POINTER(C.c_int32), C.c_int32, C.c_double,
          C.c_void_p, C.c_void_p],
     ),
+    "kspace_segment_mix": (
+        C.c_int,
+        [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+         _I32x3, C.c_void_p, C.c_void_p],
+    ),
+    "kspace_mix_table": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),
     "abi_version": (C.c_int, []),
 }
 

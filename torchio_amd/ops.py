@@ -514,6 +514,51 @@ class Engine:
                    (C.c_int32 * 6)(*padding), code, float(fill), _ptr(fills), self._stream(data))
         return out
 
+    def kspace_segment_mix(self, segments: Sequence[Tensor], bounds: Sequence[int], out_dtype: torch.dtype,
+                           active: Tensor | None = None) -> Tensor:
+        """Motion's k-space composite (motion.py:334-372) of float32 ``(B, C, I, J, K)`` images.
+
+        ``segments[0]`` is the still image, ``segments[s]`` the moved image whose spectrum fills
+        the k-space planes ``[bounds[s], bounds[s + 1])`` along the first spatial axis.  Rows
+        of inactive elements (``active[b] == 0``) are left unwritten.
+        """
+        first = segments[0]
+        if first.ndim != 5:
+            raise ValueError(f"expected (B, C, I, J, K) tensors, got {tuple(first.shape)}")
+        if len(segments) > _abi.MAX_SEGMENTS:
+            raise ValueError(f"at most {_abi.MAX_SEGMENTS - 1} motion transforms are supported, got {len(segments) - 1}")
+        if len(bounds) != len(segments) + 1:
+            raise ValueError("bounds must have one more entry than segments")
+        segments = [s.contiguous() for s in segments]
+        for s in segments:
+            if s.dtype != torch.float32 or s.shape != first.shape:
+                raise ValueError("segments must be float32 tensors of one shape")
+        self._check("kspace_segment_mix", *segments, active)
+        length = int(first.shape[2])
+        table = self._mix_table(length, tuple(int(v) for v in bounds), first.device)
+        flags = None if active is None else active.to(torch.uint8).contiguous()
+        out = torch.empty(first.shape, dtype=out_dtype, device=first.device)
+        pointers = (C.c_void_p * len(segments))(*[s.data_ptr() for s in segments])
+        self._call("kspace_segment_mix", first, pointers, len(segments), (C.c_int32 * len(bounds))(*[int(v) for v in bounds]),
+                   _ptr(table), _ptr(out), dtype_code(out_dtype), first.shape[0], first.shape[1], _i32x3(first.shape[2:]),
+                   _ptr(flags), self._stream(first))
+        return out
+
+    def _mix_table(self, length: int, bounds: tuple, device) -> Tensor:
+        """The ``(n_segments, I, I)`` band-pass table of ``tio_kspace_segment_mix`` on *device* (built once per shape)."""
+        cache = self.__dict__.setdefault("_mix_tables", {})
+        key = (length, bounds, str(device))
+        table = cache.get(key)
+        if table is None:
+            host = torch.empty(len(bounds) - 1, length, length, dtype=torch.float32)
+            status = self._fn["kspace_mix_table"](length, len(bounds) - 1, (C.c_int32 * len(bounds))(*bounds), C.c_void_p(host.data_ptr()))
+            if status != _abi.OK:
+                raise EngineError(f"tio_kspace_mix_table failed with status {status}")
+            if len(cache) >= 8:
+                cache.clear()
+            table = cache[key] = h2d(host, device) if self.device_type == "cuda" else host
+        return table
+
     # -- feeding side -------------------------------------------------------
     def patch_accumulate(
         self,

@@ -8,6 +8,7 @@ from .flip import Flip
 from .gamma import Gamma
 from .inverse import apply_inverse_transform
 from .inverse import get_inverse_transform
+from .motion import Motion
 from .noise import Noise
 from .noise import get_noise_rng
 from .noise import set_noise_rng
@@ -26,6 +27,6 @@ from .transform import Transform
 
 __all__ = [
     "Affine", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "Crop", "ElasticDeformation", "Flip", "Gamma",
-    "IntensityTransform", "Noise", "OneOf", "Pad", "Resample", "Resize", "SomeOf", "Spatial", "SpatialTransform", "Transform",
+    "IntensityTransform", "Motion", "Noise", "OneOf", "Pad", "Resample", "Resize", "SomeOf", "Spatial", "SpatialTransform", "Transform",
     "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "set_noise_rng",
 ]
