@@ -23,7 +23,7 @@ import types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFERENCE_TESTS = "/root/reference/tests"
 DEFAULT_FILES = [
-    "test_blur.py", "test_gamma.py", "test_noise.py", "test_bias_field.py", "test_spatial.py", "test_resize.py", "test_anisotropy.py",
+    "test_blur.py", "test_gamma.py", "test_noise.py", "test_bias_field.py", "test_motion.py", "test_spatial.py", "test_resize.py", "test_anisotropy.py",
     "test_flip.py", "test_pad.py", "test_crop.py", "test_compose.py", "test_one_of.py", "test_some_of.py", "test_inverse.py", "test_parameter_range.py",
     "test_patches.py", "test_queue.py", "test_affine.py", "test_batch.py",
 ]

@@ -553,7 +553,8 @@ class Engine:
             host = torch.empty(len(bounds) - 1, length, length, dtype=torch.float32)
             status = self._fn["kspace_mix_table"](length, len(bounds) - 1, (C.c_int32 * len(bounds))(*bounds), C.c_void_p(host.data_ptr()))
             if status != _abi.OK:
-                raise EngineError(f"tio_kspace_mix_table failed with status {status}")
+                message = (self._fn["last_error"]() or b"").decode(errors="replace") if "last_error" in self._fn else ""
+                raise EngineError(f"tio_kspace_mix_table failed with status {status}: {message}")
             if len(cache) >= 8:
                 cache.clear()
             table = cache[key] = h2d(host, device) if self.device_type == "cuda" else host

@@ -129,11 +129,16 @@ def _apply_motion_segments(data: Tensor, segment_parameters, *, active: Tensor |
     flags = None if active is None else ops.h2d(active.to(torch.uint8), data.device)
     skip = None if active is None else ops.h2d((~active.bool()).to(torch.uint8), data.device)  # inactive rows: plain copies
     images = [still]
-    for degrees, translation in segment_parameters:
-        mapping = ops.h2d(_rigid_voxel_mappings(degrees, translation, shape), data.device)
+    # every event's matrices in one host computation and one upload: (events * B, 3, 4)
+    batch_size = data.shape[0]
+    mappings = ops.h2d(
+        _rigid_voxel_mappings(torch.cat([d for d, _ in segment_parameters]), torch.cat([t for _, t in segment_parameters]), shape),
+        data.device,
+    )
+    for index in range(len(segment_parameters)):
         moved = engine.resample3d(
-            [still], out_shape=shape, mapping=mapping, control_points=None, in_spacing=(1.0, 1.0, 1.0), out_spacing=(1.0, 1.0, 1.0),
-            affine_first=True, interps=["linear"], fills=[None], passthrough=skip,
+            [still], out_shape=shape, mapping=mappings[index * batch_size : (index + 1) * batch_size], control_points=None,
+            in_spacing=(1.0, 1.0, 1.0), out_spacing=(1.0, 1.0, 1.0), affine_first=True, interps=["linear"], fills=[None], passthrough=skip,
         )[0]
         images.append(moved)
     return engine.kspace_segment_mix(images, bounds, data.dtype, active=flags)
@@ -166,23 +171,9 @@ def _rotation_matrices(degrees: Tensor) -> Tensor:
     """``Rz @ Ry @ Rx`` from Euler angles in degrees, float32 like the reference (motion.py:483-561)."""
     radians = torch.deg2rad(degrees)
     cos, sin = torch.cos(radians), torch.sin(radians)
-    batch = degrees.shape[0]
-    r_x = torch.zeros(batch, 3, 3, dtype=degrees.dtype)
-    r_y = torch.zeros(batch, 3, 3, dtype=degrees.dtype)
-    r_z = torch.zeros(batch, 3, 3, dtype=degrees.dtype)
-    r_x[:, 0, 0] = 1
-    r_x[:, 1, 1] = cos[:, 0]
-    r_x[:, 1, 2] = -sin[:, 0]
-    r_x[:, 2, 1] = sin[:, 0]
-    r_x[:, 2, 2] = cos[:, 0]
-    r_y[:, 0, 0] = cos[:, 1]
-    r_y[:, 0, 2] = sin[:, 1]
-    r_y[:, 1, 1] = 1
-    r_y[:, 2, 0] = -sin[:, 1]
-    r_y[:, 2, 2] = cos[:, 1]
-    r_z[:, 0, 0] = cos[:, 2]
-    r_z[:, 0, 1] = -sin[:, 2]
-    r_z[:, 1, 0] = sin[:, 2]
-    r_z[:, 1, 1] = cos[:, 2]
-    r_z[:, 2, 2] = 1
+    (cx, cy, cz), (sx, sy, sz) = cos.unbind(dim=-1), sin.unbind(dim=-1)
+    zero, one = torch.zeros_like(cx), torch.ones_like(cx)
+    r_x = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], dim=1).reshape(-1, 3, 3)
+    r_y = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], dim=1).reshape(-1, 3, 3)
+    r_z = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], dim=1).reshape(-1, 3, 3)
     return r_z @ r_y @ r_x
