@@ -55,6 +55,7 @@ def main():
     parser.add_argument("--batch", type=int, default=4)
     parser.add_argument("--events", type=int, default=2)
     parser.add_argument("--reps", type=int, default=10)
+    parser.add_argument("--profile", action="store_true", help="cProfile of the public Motion call (stderr)")
     args = parser.parse_args()
     engine = ops.engine()
     shape = (args.size,) * 3
@@ -84,6 +85,17 @@ def main():
     subject_batch = tio.SubjectsBatch.from_subjects([tio.Subject(t1=tio.ScalarImage(data[i])) for i in range(args.batch)])
     transform = tio.Motion(num_transforms=args.events, copy=False)
     api_ms = timed(lambda: transform(subject_batch).t1.data, args.reps)
+    if args.profile:
+        import cProfile
+        import pstats
+
+        profiler = cProfile.Profile()
+        profiler.enable()
+        for _ in range(10):
+            transform(subject_batch).t1.data
+        torch.cuda.synchronize()
+        profiler.disable()
+        pstats.Stats(profiler, stream=sys.stderr).sort_stats("tottime").print_stats(14)
     print(json.dumps({
         "workload": f"Motion(num_transforms={args.events}) on {args.batch} x 1 x {args.size}^3 float32",
         "kspace_segment_mix_ms": round(mix_ms, 3), "gemm_tflops": round(flops / mix_ms / 1e9, 1), "f32_mfma_peak_tflops": 157.3,

@@ -15,6 +15,14 @@
 // it runs on the matrix cores: `v_mfma_f32_32x32x2_f32` is exact float32 (a k-ordered fmaf chain)
 // at 157 TFLOP/s; x_s streams through LDS once, the 768 KiB table stays in L2.
 //
+// The slabs tile k-space, so sum_s W_s = 1 and the still image's block never has to be multiplied:
+//
+//     out = x_0 + sum_{s >= 1} W_s (x_s - x_0)
+//
+// which drops 1 / (S + 1) of the GEMM (a third at the default two motion events), makes zero motion
+// return the image exactly, and costs one extra read of x_0 per event (the difference is formed on the
+// way into LDS) plus one as the accumulators' initial value.
+//
 // Block = 4 waves stacked along the rows: (128 * RM) x 128 output tile, wave = (32 * RM) x 128 =
 // RM x 4 accumulators of 32 x 32; K runs in chunks of 8 through double-buffered LDS with the next
 // chunk's global loads in flight during the MFMAs (one barrier per chunk).  LDS is k-major for
@@ -41,6 +49,22 @@ struct MixArgs {
 constexpr int kBN = 128;  // output columns per block
 constexpr int kKC = 8;    // k per LDS chunk
 
+// Epilogue: the accumulators (which started from the still image) converted to the image dtype.  C/D map of the 32x32 MFMA:
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); row0 / col0 carry the lane part.
+template <int RM, int DT>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[RM][4], void* out, int64_t out_base,
+                                           int row0, int col0, int I, int N) {
+#pragma unroll
+  for (int rm = 0; rm < RM; rm++)
+#pragma unroll
+    for (int cn = 0; cn < 4; cn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = row0 + rm * 32 + (r & 3) + 8 * (r >> 2), col = col0 + cn * 32;
+        if (row < I && col < N) Elem<DT>::store(out, out_base + static_cast<int64_t>(row) * N + col, acc[rm][cn][r]);
+      }
+}
+
 template <int RM, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
   constexpr int BM = 128 * RM;
@@ -48,75 +72,113 @@ __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
   __shared__ float As[2][kKC][BM];
   __shared__ float Bs[2][kKC][kBN];
 
+  __shared__ const float* seg_table[TIO_MAX_SEGMENTS];  // dynamic indexing of the by-value argument would go through scratch
+
   const int bc = blockIdx.z;
   if (a.active != nullptr && a.active[bc / a.channels] == 0) return;  // block-uniform
+  if (threadIdx.x < TIO_MAX_SEGMENTS) {
+    const float* p = nullptr;
+#pragma unroll
+    for (int s = 0; s < TIO_MAX_SEGMENTS; s++)
+      if (static_cast<int>(threadIdx.x) == s) p = a.seg[s];
+    seg_table[threadIdx.x] = p;
+  }
+  __syncthreads();
+  const float* const still = a.seg[0];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * kBN, m0 = blockIdx.y * BM;
   const int I = a.I, N = a.N;
-  const int chunks_per_seg = (I + kKC - 1) / kKC, total = a.n_seg * chunks_per_seg;
+  const int chunks_per_seg = (I + kKC - 1) / kKC, total = (a.n_seg - 1) * chunks_per_seg;  // segments 1 .. n_seg-1
 
   // this thread's slots in the two chunk loads
   const int b_k = tid >> 5, b_c = (tid & 31) * 4;
-  float4 ra[A_V4], rb;
+  float4 ra[A_V4], rb, rq;  // W chunk, moved rows, still rows (subtracted on the way into LDS, after the MFMAs)
 
+  // ALIGNED (I and N multiples of 4): every float4 is either fully inside or fully outside, so the loads are
+  // unconditional from a clamped address and the zeroing happens in stash(), after the MFMAs - a branch
+  // around a load makes the compiler drain vmcnt at the join, which serialises the prefetch with the math.
+  unsigned ok = 0;  // bit r: W float4 r is real; bit 8: the image float4 is real
   auto fetch = [&](int chunk) {
-    const int s = chunk / chunks_per_seg, kbase = (chunk - s * chunks_per_seg) * kKC;
+    const int s = 1 + chunk / chunks_per_seg, kbase = (chunk - (s - 1) * chunks_per_seg) * kKC;
     const float* w = a.mix + static_cast<int64_t>(s) * I * I;
+    ok = 0;
 #pragma unroll
     for (int r = 0; r < A_V4; r++) {
       const int f = tid + r * 256, kk = f / (BM / 4), col = (f % (BM / 4)) * 4;
       const int ip = kbase + kk, i = m0 + col;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ip < I) {
-        const float* p = w + static_cast<int64_t>(ip) * I + i;
-        if (ALIGNED && i + 3 < I) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
+      if constexpr (ALIGNED) {
+        ok |= (ip < I && i < I) ? (1u << r) : 0u;
+        ra[r] = *reinterpret_cast<const float4*>(w + static_cast<int64_t>(min(ip, I - 1)) * I + min(i, I - 4));
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ip < I) {
+          const float* p = w + static_cast<int64_t>(ip) * I + i;
           if (i < I) v.x = p[0];
           if (i + 1 < I) v.y = p[1];
           if (i + 2 < I) v.z = p[2];
           if (i + 3 < I) v.w = p[3];
         }
+        ra[r] = v;
+        ok |= 1u << r;
       }
-      ra[r] = v;
     }
     {
       const int ip = kbase + b_k, n = n0 + b_c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ip < I) {
-        const float* p = a.seg[s] + (static_cast<int64_t>(bc) * I + ip) * N + n;
-        if (ALIGNED && n + 3 < N) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (n < N) v.x = p[0];
-          if (n + 1 < N) v.y = p[1];
-          if (n + 2 < N) v.z = p[2];
-          if (n + 3 < N) v.w = p[3];
+      if constexpr (ALIGNED) {
+        ok |= (ip < I && n < N) ? 256u : 0u;
+        const int64_t at = (static_cast<int64_t>(bc) * I + min(ip, I - 1)) * N + min(n, N - 4);
+        rb = *reinterpret_cast<const float4*>(seg_table[s] + at);
+        rq = *reinterpret_cast<const float4*>(still + at);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x0 = v;
+        if (ip < I) {
+          const int64_t at = (static_cast<int64_t>(bc) * I + ip) * N + n;
+          const float *p = seg_table[s] + at, *q = still + at;
+          if (n < N) { v.x = p[0]; x0.x = q[0]; }
+          if (n + 1 < N) { v.y = p[1]; x0.y = q[1]; }
+          if (n + 2 < N) { v.z = p[2]; x0.z = q[2]; }
+          if (n + 3 < N) { v.w = p[3]; x0.w = q[3]; }
         }
+        rb = v;
+        rq = x0;
+        ok |= 256u;
       }
-      rb = v;
     }
   };
   auto stash = [&](int buf) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < A_V4; r++) {
       const int f = tid + r * 256, kk = f / (BM / 4), col = (f % (BM / 4)) * 4;
-      *reinterpret_cast<float4*>(&As[buf][kk][col]) = ra[r];
+      float4 v = ra[r];
+      if (((ok >> r) & 1u) == 0) v = zero;
+      *reinterpret_cast<float4*>(&As[buf][kk][col]) = v;
     }
-    *reinterpret_cast<float4*>(&Bs[buf][b_k][b_c]) = rb;
+    float4 diff = make_float4(rb.x - rq.x, rb.y - rq.y, rb.z - rq.z, rb.w - rq.w);  // moved - still
+    if ((ok & 256u) == 0) diff = zero;
+    *reinterpret_cast<float4*>(&Bs[buf][b_k][b_c]) = diff;
   };
 
+  // the accumulators start from the still image (out = x_0 + ...): 128 unconditional loads from clamped
+  // addresses, in flight together with the first chunk's prefetch; rows / columns outside are never stored
+  const int row0 = m0 + wave * RM * 32 + 4 * (lane >> 5), col0 = n0 + (lane & 31);
+  const int64_t out_base = static_cast<int64_t>(bc) * I * N;
   f32x16 acc[RM][4];
 #pragma unroll
   for (int rm = 0; rm < RM; rm++)
 #pragma unroll
     for (int cn = 0; cn < 4; cn++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[rm][cn][r] = 0.f;
+      for (int r = 0; r < 16; r++) {
+        const int row = row0 + rm * 32 + (r & 3) + 8 * (r >> 2), col = col0 + cn * 32;
+        acc[rm][cn][r] = still[out_base + static_cast<int64_t>(min(row, I - 1)) * N + min(col, N - 1)];
+      }
 
-  fetch(0);
-  stash(0);
+  if (total > 0) {
+    fetch(0);
+    stash(0);
+  }
   __syncthreads();
   const int frag_k = lane >> 5, frag_x = lane & 31;
   for (int chunk = 0; chunk < total; chunk++) {
@@ -139,19 +201,17 @@ __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
     __syncthreads();
   }
 
-  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int64_t out_base = static_cast<int64_t>(bc) * I * N;
-#pragma unroll
-  for (int rm = 0; rm < RM; rm++)
-#pragma unroll
-    for (int cn = 0; cn < 4; cn++) {
-      const int col = n0 + cn * 32 + frag_x;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = m0 + (wave * RM + rm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_k;
-        if (row < I && col < N) store_from_float(a.out, a.dtype, out_base + static_cast<int64_t>(row) * N + col, acc[rm][cn][r]);
-      }
-    }
+  switch (a.dtype) {  // uniform: one specialised copy of the epilogue runs
+    case TIO_F32: store_tile<RM, TIO_F32>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_F64: store_tile<RM, TIO_F64>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_F16: store_tile<RM, TIO_F16>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_BF16: store_tile<RM, TIO_BF16>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_U8: store_tile<RM, TIO_U8>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_I8: store_tile<RM, TIO_I8>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_I16: store_tile<RM, TIO_I16>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_I32: store_tile<RM, TIO_I32>(acc, a.out, out_base, row0, col0, I, N); break;
+    default: store_tile<RM, TIO_I64>(acc, a.out, out_base, row0, col0, I, N); break;
+  }
 }
 
 }  // namespace
