@@ -24,7 +24,7 @@
 // way into LDS) plus one as the accumulators' initial value.
 //
 // Block = 4 waves stacked along the rows: (128 * RM) x 128 output tile, wave = (32 * RM) x 128 =
-// RM x 4 accumulators of 32 x 32; K runs in chunks of 8 through double-buffered LDS with the next
+// RM x 4 accumulators of 32 x 32; K runs in chunks of 16 through double-buffered LDS with the next
 // chunk's global loads in flight during the MFMAs (one barrier per chunk).  LDS is k-major for
 // both operands, so the MFMA fragment reads (lane l: k = l >> 5, row/col = l & 31) are
 // conflict-free 128-byte rows.
@@ -47,22 +47,40 @@ struct MixArgs {
 };
 
 constexpr int kBN = 128;  // output columns per block
-constexpr int kKC = 8;    // k per LDS chunk
+constexpr int kKC = 16;   // k per LDS chunk
 
-// Epilogue: the accumulators (which started from the still image) converted to the image dtype.  C/D map of the 32x32 MFMA:
-// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); row0 / col0 carry the lane part.
-template <int RM, int DT>
-__device__ __forceinline__ void store_tile(const f32x16 (&acc)[RM][4], void* out, int64_t out_base,
-                                           int row0, int col0, int I, int N) {
+// Epilogue: the accumulators (which started from the still image) converted to the image dtype.  C/D map of
+// the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Every store is a
+// block-uniform pointer (scalar registers) plus ONE per-lane 32-bit offset that never changes, so no vector
+// register is rewritten between stores and they all stay in flight (with per-store address registers the
+// compiler reuses them and waits for the previous store each time: 128 serialised round trips per lane).
+template <int RM, int DT, bool ALIGNED>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[RM][4], void* out, int64_t tile_base, int row_base,
+                                           int col_base, int lane, int I, int N) {
+  using T = typename Elem<DT>::type;
+  const int lane_row = 4 * (lane >> 5), lane_col = lane & 31;
+  const unsigned lane_off = static_cast<unsigned>(lane_row) * static_cast<unsigned>(N) + static_cast<unsigned>(lane_col);
 #pragma unroll
   for (int rm = 0; rm < RM; rm++)
 #pragma unroll
-    for (int cn = 0; cn < 4; cn++)
+    for (int cn = 0; cn < 4; cn++) {
+      const bool col_ok = col_base + cn * 32 + lane_col < N;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = row0 + rm * 32 + (r & 3) + 8 * (r >> 2), col = col0 + cn * 32;
-        if (row < I && col < N) Elem<DT>::store(out, out_base + static_cast<int64_t>(row) * N + col, acc[rm][cn][r]);
+      for (int g = 0; g < 4; g++) {  // groups of four consecutive rows: registers 4g .. 4g+3
+        const int row_u = row_base + rm * 32 + 8 * g;  // uniform part of the rows
+        T* base = static_cast<T*>(out) + tile_base + static_cast<int64_t>(rm * 32 + 8 * g) * N + cn * 32;
+        if constexpr (ALIGNED) {  // I % 4 == 0: a group of four rows is inside or outside as a whole
+          if (col_ok && row_u + lane_row < I) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) Elem<DT>::store(base + static_cast<int64_t>(q) * N, lane_off, acc[rm][cn][4 * g + q]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (col_ok && row_u + lane_row + q < I) Elem<DT>::store(base + static_cast<int64_t>(q) * N, lane_off, acc[rm][cn][4 * g + q]);
+        }
       }
+    }
 }
 
 template <int RM, bool ALIGNED>
@@ -93,12 +111,13 @@ __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
 
   // this thread's slots in the two chunk loads
   const int b_k = tid >> 5, b_c = (tid & 31) * 4;
-  float4 ra[A_V4], rb, rq;  // W chunk, moved rows, still rows (subtracted on the way into LDS, after the MFMAs)
+  constexpr int B_V4 = kKC / 8;  // image float4 per thread: 8 rows of 32 float4 per pass
+  float4 ra[A_V4], rb[B_V4], rq[B_V4];  // W chunk, moved rows, still rows (subtracted on the way into LDS, after the MFMAs)
 
   // ALIGNED (I and N multiples of 4): every float4 is either fully inside or fully outside, so the loads are
   // unconditional from a clamped address and the zeroing happens in stash(), after the MFMAs - a branch
   // around a load makes the compiler drain vmcnt at the join, which serialises the prefetch with the math.
-  unsigned ok = 0;  // bit r: W float4 r is real; bit 8: the image float4 is real
+  unsigned ok = 0;  // bit r: W float4 r is real; bit 8 + r: image float4 r is real
   auto fetch = [&](int chunk) {
     const int s = 1 + chunk / chunks_per_seg, kbase = (chunk - (s - 1) * chunks_per_seg) * kKC;
     const float* w = a.mix + static_cast<int64_t>(s) * I * I;
@@ -123,13 +142,14 @@ __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
         ok |= 1u << r;
       }
     }
-    {
-      const int ip = kbase + b_k, n = n0 + b_c;
+#pragma unroll
+    for (int r = 0; r < B_V4; r++) {
+      const int ip = kbase + b_k + 8 * r, n = n0 + b_c;
       if constexpr (ALIGNED) {
-        ok |= (ip < I && n < N) ? 256u : 0u;
+        ok |= (ip < I && n < N) ? (256u << r) : 0u;
         const int64_t at = (static_cast<int64_t>(bc) * I + min(ip, I - 1)) * N + min(n, N - 4);
-        rb = *reinterpret_cast<const float4*>(seg_table[s] + at);
-        rq = *reinterpret_cast<const float4*>(still + at);
+        rb[r] = *reinterpret_cast<const float4*>(seg_table[s] + at);
+        rq[r] = *reinterpret_cast<const float4*>(still + at);
       } else {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x0 = v;
         if (ip < I) {
@@ -140,9 +160,9 @@ __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
           if (n + 2 < N) { v.z = p[2]; x0.z = q[2]; }
           if (n + 3 < N) { v.w = p[3]; x0.w = q[3]; }
         }
-        rb = v;
-        rq = x0;
-        ok |= 256u;
+        rb[r] = v;
+        rq[r] = x0;
+        ok |= 256u << r;
       }
     }
   };
@@ -155,9 +175,12 @@ __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
       if (((ok >> r) & 1u) == 0) v = zero;
       *reinterpret_cast<float4*>(&As[buf][kk][col]) = v;
     }
-    float4 diff = make_float4(rb.x - rq.x, rb.y - rq.y, rb.z - rq.z, rb.w - rq.w);  // moved - still
-    if ((ok & 256u) == 0) diff = zero;
-    *reinterpret_cast<float4*>(&Bs[buf][b_k][b_c]) = diff;
+#pragma unroll
+    for (int r = 0; r < B_V4; r++) {
+      float4 diff = make_float4(rb[r].x - rq[r].x, rb[r].y - rq[r].y, rb[r].z - rq[r].z, rb[r].w - rq[r].w);  // moved - still
+      if ((ok & (256u << r)) == 0) diff = zero;
+      *reinterpret_cast<float4*>(&Bs[buf][b_k + 8 * r][b_c]) = diff;
+    }
   };
 
   // the accumulators start from the still image (out = x_0 + ...): 128 unconditional loads from clamped
@@ -180,37 +203,60 @@ __global__ __launch_bounds__(256, 2) void segment_mix_kernel(MixArgs a) {
     stash(0);
   }
   __syncthreads();
+  // pin the initial values here: with the loads still pending at the loop header the compiler's wait for
+  // them lands INSIDE the loop as vmcnt(0), which also drains every iteration's prefetch before the MFMAs
+#pragma unroll
+  for (int rm = 0; rm < RM; rm++)
+#pragma unroll
+    for (int cn = 0; cn < 4; cn++) asm volatile("" : "+v"(acc[rm][cn]));
   const int frag_k = lane >> 5, frag_x = lane & 31;
   for (int chunk = 0; chunk < total; chunk++) {
     const int buf = chunk & 1;
     if (chunk + 1 < total) fetch(chunk + 1);  // in flight during the MFMAs below
+    // fragments one k-step ahead of the MFMAs that use them: the LDS latency hides under 8 MFMAs
+    float af[RM], bf[4];
+#pragma unroll
+    for (int rm = 0; rm < RM; rm++) af[rm] = As[buf][frag_k][(wave * RM + rm) * 32 + frag_x];
+#pragma unroll
+    for (int cn = 0; cn < 4; cn++) bf[cn] = Bs[buf][frag_k][cn * 32 + frag_x];
 #pragma unroll
     for (int k2 = 0; k2 < kKC; k2 += 2) {
-      float af[RM], bf[4];
+      float an[RM], bn[4];
+      if (k2 + 2 < kKC) {
 #pragma unroll
-      for (int rm = 0; rm < RM; rm++) af[rm] = As[buf][k2 + frag_k][(wave * RM + rm) * 32 + frag_x];
+        for (int rm = 0; rm < RM; rm++) an[rm] = As[buf][k2 + 2 + frag_k][(wave * RM + rm) * 32 + frag_x];
 #pragma unroll
-      for (int cn = 0; cn < 4; cn++) bf[cn] = Bs[buf][k2 + frag_k][cn * 32 + frag_x];
+        for (int cn = 0; cn < 4; cn++) bn[cn] = Bs[buf][k2 + 2 + frag_k][cn * 32 + frag_x];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs
 #pragma unroll
       for (int rm = 0; rm < RM; rm++)
 #pragma unroll
         for (int cn = 0; cn < 4; cn++)
           acc[rm][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rm], bf[cn], acc[rm][cn], 0, 0, 0);
+      if (k2 + 2 < kKC) {
+#pragma unroll
+        for (int rm = 0; rm < RM; rm++) af[rm] = an[rm];
+#pragma unroll
+        for (int cn = 0; cn < 4; cn++) bf[cn] = bn[cn];
+      }
     }
     if (chunk + 1 < total) stash(buf ^ 1);  // the other buffer: its readers passed the previous barrier
     __syncthreads();
   }
 
+  const int row_base = m0 + wave * RM * 32;  // uniform
+  const int64_t tile_base = out_base + static_cast<int64_t>(row_base) * N + n0;
   switch (a.dtype) {  // uniform: one specialised copy of the epilogue runs
-    case TIO_F32: store_tile<RM, TIO_F32>(acc, a.out, out_base, row0, col0, I, N); break;
-    case TIO_F64: store_tile<RM, TIO_F64>(acc, a.out, out_base, row0, col0, I, N); break;
-    case TIO_F16: store_tile<RM, TIO_F16>(acc, a.out, out_base, row0, col0, I, N); break;
-    case TIO_BF16: store_tile<RM, TIO_BF16>(acc, a.out, out_base, row0, col0, I, N); break;
-    case TIO_U8: store_tile<RM, TIO_U8>(acc, a.out, out_base, row0, col0, I, N); break;
-    case TIO_I8: store_tile<RM, TIO_I8>(acc, a.out, out_base, row0, col0, I, N); break;
-    case TIO_I16: store_tile<RM, TIO_I16>(acc, a.out, out_base, row0, col0, I, N); break;
-    case TIO_I32: store_tile<RM, TIO_I32>(acc, a.out, out_base, row0, col0, I, N); break;
-    default: store_tile<RM, TIO_I64>(acc, a.out, out_base, row0, col0, I, N); break;
+    case TIO_F32: store_tile<RM, TIO_F32, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    case TIO_F64: store_tile<RM, TIO_F64, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    case TIO_F16: store_tile<RM, TIO_F16, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    case TIO_BF16: store_tile<RM, TIO_BF16, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    case TIO_U8: store_tile<RM, TIO_U8, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    case TIO_I8: store_tile<RM, TIO_I8, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    case TIO_I16: store_tile<RM, TIO_I16, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    case TIO_I32: store_tile<RM, TIO_I32, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
+    default: store_tile<RM, TIO_I64, ALIGNED>(acc, a.out, tile_base, row_base, n0, lane, I, N); break;
   }
 }
 
