@@ -561,8 +561,11 @@ __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArg
     stage_brick_generic<NT, DTMODE>(s_tile, static_cast<const char*>(g.in) + bc * n_in * es, g.dtype, tid, bx, a.I, a.J, a.K);
   }
   __syncthreads();
-  const float fillv = g.fill != nullptr ? g.fill[c] : 0.0f;
+  // The fill value lives in a scalar register: as a pending vector load its first use (inside the voxel
+  // loop of boundary bricks) makes the compiler wait with vmcnt(0) there, which on every later voxel
+  // also drains the previous voxel's STORE - one store round trip per voxel.
   const bool has_fill = g.fill != nullptr;
+  const float fillv = has_fill ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g.fill[c]))) : 0.0f;
   // Output addresses: block-uniform running pointer (one plane = slab_b bytes) + this
   // thread's byte offset inside the plane.
   const int64_t slab_b = static_cast<int64_t>(slab) * es;
