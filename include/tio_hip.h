@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 4
+#define TIO_ABI_VERSION 5
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -360,6 +360,19 @@ int tio_patch_accumulate(void* out, void* weight_sum, int32_t dtype, int32_t cha
                          const int32_t patch_shape[3], const tio_patch_placement* placements_host,
                          int32_t mode, const float* window_i_dev, const float* window_j_dev,
                          const float* window_k_dev, void* stream);
+
+/*
+ * torch.unique(data) of an 8- or 16-bit integer label map: the sorted value set that sizes the
+ * one-hot encoding of the partial-volume label mode (spatial.py:1360; it becomes labels_dev /
+ * n_labels of a TIO_LABEL_PV image).  A presence bitmap instead of torch.unique's sort.
+ *   x             device, n elements of dtype TIO_U8 / TIO_I8 / TIO_I16, 16-byte aligned
+ *   table_dev     device, room for 65536 doubles (256 for the 8-bit types): the values, ascending
+ *   count_dev     device, one int32: how many
+ *   workspace_dev device, 8 KiB scratch (the bitmap; cleared by the call)
+ * Other dtypes: TIO_ERR_UNSUPPORTED_DTYPE, nothing launched (callers keep torch.unique).
+ */
+int tio_unique_labels(const void* x, int32_t dtype, int64_t n, double* table_dev, int32_t* count_dev,
+                      void* workspace_dev, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Motion: k-space compositing                                               */

@@ -1026,6 +1026,20 @@ int tio_oracle_kspace_mix_table(int32_t length, int32_t n_segments, const int32_
   return TIO_OK;
 }
 
+/* torch.unique(data) for the label mode's table (spatial.py:1360): sorted distinct values */
+int tio_oracle_unique_labels(const void* x, int32_t dtype, int64_t n, double* table, int32_t* count, void* workspace, void* stream) {
+  (void)workspace;
+  (void)stream;
+  if (dtype != TIO_U8 && dtype != TIO_I8 && dtype != TIO_I16) return TIO_ERR_UNSUPPORTED_DTYPE;
+  if (table == NULL || count == NULL) return TIO_ERR_INVALID_ARGUMENT;
+  int32_t found = 0;
+  double* values = unique_labels(x, dtype, n, &found);
+  for (int32_t i = 0; i < found; i++) table[i] = values[i];
+  free(values);
+  *count = found;
+  return TIO_OK;
+}
+
 int tio_oracle_abi_version(void) { return TIO_ABI_VERSION; }
 
 int tio_oracle_num_threads(void) {

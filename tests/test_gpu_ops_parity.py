@@ -526,3 +526,30 @@ def test_kspace_segment_mix_argument_errors(hip):
     with pytest.raises(ValueError, match="at most"):
         hip.kspace_segment_mix([x] * 40, list(range(41)), torch.float32)
     assert hip.kspace_segment_mix([x[:0], x[:0]], [0, 4, 8], torch.float32).shape == (0, 1, 8, 4, 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int8, torch.int16])
+def test_unique_labels_equals_torch_unique(oracle, hip, dtype):
+    g = torch.Generator().manual_seed(301)
+    info = torch.iinfo(dtype)
+    cases = [
+        torch.randint(0, 5, (2, 1, 17, 19, 23), generator=g).to(dtype),                                  # a few labels, odd size
+        torch.randint(info.min, info.max + 1, (1, 1, 40, 40, 40), generator=g, dtype=torch.int64).to(dtype),  # the whole range
+        torch.full((1, 1, 8, 8, 8), info.min, dtype=dtype),                                               # one label, the smallest value
+        torch.tensor([info.max, info.min, 0, info.max], dtype=dtype).reshape(1, 1, 1, 1, 4),             # shorter than one vector
+        torch.zeros(0, 1, 4, 4, 4, dtype=dtype),                                                         # empty
+    ]
+    for data in cases:
+        expected = torch.unique(data).double()
+        assert torch.equal(oracle.unique_labels(data), expected)
+        got = hip.unique_labels(data.to(DEV))
+        assert got.dtype == torch.float64 and torch.equal(got.cpu(), expected)
+    view = cases[1].to(DEV).reshape(-1)[3:]  # not 16-byte aligned: the engine re-aligns
+    assert torch.equal(hip.unique_labels(view).cpu(), torch.unique(cases[1].reshape(-1)[3:]).double())
+
+
+def test_unique_labels_wide_dtypes_keep_the_aten_path_and_full_size(hip):
+    data = torch.tensor([5, -7, 5, 100000], dtype=torch.int32, device=DEV)
+    assert hip.unique_labels(data).tolist() == [-7.0, 5.0, 100000.0]
+    labels = torch.randint(0, 40, (1, 1, 512, 512, 512), dtype=torch.int16, device=DEV)  # the config-5 label map size
+    assert torch.equal(hip.unique_labels(labels), torch.unique(labels).double())

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_IMAGES = 8
 
 # tio_status
@@ -119,6 +119,7 @@ PROTOTYPES = {
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.POINTER(C.c_int32), C.c_int32, C.c_double,
          C.c_void_p, C.c_void_p],
     ),
+    "unique_labels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kspace_segment_mix": (
         C.c_int,
         [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

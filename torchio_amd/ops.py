@@ -514,6 +514,25 @@ class Engine:
                    (C.c_int32 * 6)(*padding), code, float(fill), _ptr(fills), self._stream(data))
         return out
 
+    def unique_labels(self, data: Tensor) -> Tensor:
+        """``torch.unique(data).double()`` (sorted) of a label map; a bitmap pass for 8- / 16-bit integers.
+
+        One 4-byte read-back of the count, like ``torch.unique`` itself (the table's length is a host quantity).
+        """
+        if data.dtype not in (torch.uint8, torch.int8, torch.int16):
+            return torch.unique(data).to(torch.float64)  # wide / floating label maps: ATen's sort
+        data = data.contiguous()
+        if data.data_ptr() % 16 != 0:
+            data = data.clone()
+        self._check("unique_labels", data)
+        capacity = 256 if data.dtype != torch.int16 else 65536
+        table = torch.empty(capacity, dtype=torch.float64, device=data.device)
+        count = torch.empty(1, dtype=torch.int32, device=data.device)
+        workspace = torch.empty(2048, dtype=torch.int32, device=data.device)
+        self._call("unique_labels", data, _ptr(data), dtype_code(data.dtype), data.numel(), _ptr(table), _ptr(count), _ptr(workspace),
+                   self._stream(data))
+        return table[: int(count.item())]
+
     def kspace_segment_mix(self, segments: Sequence[Tensor], bounds: Sequence[int], out_dtype: torch.dtype,
                            active: Tensor | None = None) -> Tensor:
         """Motion's k-space composite (motion.py:334-372) of float32 ``(B, C, I, J, K)`` images.

@@ -609,7 +609,7 @@ def _apply_spatial_to_batch(
                 continue
             else:
                 fill = None
-                table = torch.unique(data).to(torch.float64)  # sorted; sizes the reference's one-hot (spatial.py:1360)
+                table = engine.unique_labels(data)  # torch.unique(data), sorted; sizes the reference's one-hot (spatial.py:1360)
                 pad = float(default_pad_label)
         elif _ORDERS[interpolation] > 1:
             raise NotImplementedError(
@@ -680,7 +680,7 @@ def _label_partial_volume_composite(
     Needed when the channels are smoothed before sampling (``antialias=True``) or sampled
     with ``"nearest"``; the plain linear case is fused inside ``tio_resample3d`` instead.
     """
-    labels = torch.unique(data)
+    labels = engine.unique_labels(data).to(data.dtype)  # torch.unique(data)
     one_hot = (data[:, :1] == labels.view(1, -1, 1, 1, 1)).float()
     if antialias:
         one_hot = _antialias(engine, one_hot, in_affine, out_affine)
