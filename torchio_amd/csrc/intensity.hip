@@ -254,6 +254,13 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   const_float_ptr tc = (const_float_ptr)(t);
   const_float_ptr tk = (const_float_ptr)(a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride);
   (void)s_taps; (void)tk; (void)s_krow;
+  float noise_mu = a.noise_mean, noise_sd = a.noise_std;  // scalar loads, once (see conv_march_kernel)
+  if constexpr (POST_NOISE) {
+    if (a.noise_batched) {
+      noise_mu = ((const_float_ptr)a.noise_mean_b)[b];
+      noise_sd = ((const_float_ptr)a.noise_std_b)[b];
+    }
+  }
   constexpr int RW = kConvStep / (kBlock / 64);  // rows per wave per step (4)
   // PRE_BIAS (I pass of tio_blur_fused): every row is multiplied by exp(trilinear(coarse)) on its
   // way into the ring — the arithmetic of bias_kernel (K- and J-lerps of a coarse plane are
@@ -387,8 +394,7 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
               const int64_t e0 = line + static_cast<int64_t>(p0 + o) * stride;  // element index of acc.x in the tensor
               float z[4];
               philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
-              const float mu = a.noise_batched ? a.noise_mean_b[b] : a.noise_mean;
-              const float sd = a.noise_batched ? a.noise_std_b[b] : a.noise_std;
+              const float mu = noise_mu, sd = noise_sd;
               acc.x = __fadd_rn(acc.x, __fadd_rn(mu, __fmul_rn(sd, z[0])));
               acc.y = __fadd_rn(acc.y, __fadd_rn(mu, __fmul_rn(sd, z[1])));
               acc.z = __fadd_rn(acc.z, __fadd_rn(mu, __fmul_rn(sd, z[2])));
@@ -487,6 +493,16 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
   float tw[W];  // scalar registers
 #pragma unroll
   for (int t = 0; t < W; t++) tw[t] = tc[t];
+  // noise parameters of this strip's element, once, through the scalar cache: as plain global loads inside
+  // the marching loop they sit behind a branch, and the compiler's wait at the join is vmcnt(0) - it
+  // drained the two prefetched rows (and the previous store) on every row
+  float noise_mu = a.noise_mean, noise_sd = a.noise_std;
+  if constexpr (POST_NOISE) {
+    if (a.noise_batched) {
+      noise_mu = ((const_float_ptr)a.noise_mean_b)[b];
+      noise_sd = ((const_float_ptr)a.noise_std_b)[b];
+    }
+  }
 
   // PRE_BIAS: the arithmetic of bias_kernel, coarse planes cached while the row stays in a cell
   Lerp1D b_lk[4];
@@ -605,8 +621,7 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
           const int64_t e0 = line + static_cast<int64_t>(p) * stride;
           float z[4];
           philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
-          const float mu = a.noise_batched ? a.noise_mean_b[b] : a.noise_mean;
-          const float sd = a.noise_batched ? a.noise_std_b[b] : a.noise_std;
+          const float mu = noise_mu, sd = noise_sd;
           acc.x = __fadd_rn(acc.x, __fadd_rn(mu, __fmul_rn(sd, z[0])));
           acc.y = __fadd_rn(acc.y, __fadd_rn(mu, __fmul_rn(sd, z[1])));
           acc.z = __fadd_rn(acc.z, __fadd_rn(mu, __fmul_rn(sd, z[2])));
