@@ -582,3 +582,12 @@ def test_motion_parameters_gating_and_errors():
     one = {"degrees": (1.0, 0.0, 0.0), "translation": (0.0, 0.0, 0.0)}
     with pytest.raises(ValueError, match="uniform motion transform counts"):
         _apply_motion_per_instance(b.t1.data, [[one], [one, one], [], [one]])
+
+
+def test_unique_labels_on_the_oracle_engine(oracle):
+    """The label table of the partial-volume mode: sorted distinct values as float64 (spatial.py:1360)."""
+    g = torch.Generator().manual_seed(11)
+    for dtype in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.float32):
+        data = torch.randint(-3 if dtype != torch.uint8 else 0, 9, (2, 1, 5, 6, 7), generator=g).to(dtype)
+        table = oracle.unique_labels(data)
+        assert table.dtype == torch.float64 and torch.equal(table, torch.unique(data).double())
