@@ -852,16 +852,30 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
         // NaN / Inf control values reach the lerped planes (NaN * 0 = NaN): flag the brick
 #pragma unroll
         for (int e = 0; e < 9; e++) cp_bad |= !(fabsf(P[e]) <= 1e30f);
+        // The two control planes a voxel lerps between change once or twice per brick (at a cell
+        // boundary), so they live in named registers that a SCALAR branch refreshes when the plane pair
+        // moves on; indexing P[] with the (uniform) plane number on every voxel costs an
+        // s_set_gpr_idx_on / v_mov / off sequence per access, six times per voxel.
+        float pa_i = 0.f, pa_j = 0.f, pa_k = 0.f, pb_i = 0.f, pb_j = 0.f, pb_k = 0.f;
+        int cur0 = -1, cur1 = -1;
+#define TIO_PLANE_PICK(E, DI, DJ, DK)                                   \
+  {                                                                     \
+    DI = (E) == 0 ? P[0] : ((E) == 3 ? P[3] : P[6]);                    \
+    DJ = (E) == 0 ? P[1] : ((E) == 3 ? P[4] : P[7]);                    \
+    DK = (E) == 0 ? P[2] : ((E) == 3 ? P[5] : P[8]);                    \
+  }
 #define TIO_PLANE_LOOP(NORM)                                                                                      \
   _Pragma("unroll") for (int t = 0; t < TI; t++) {                                                                \
     const float ci = fminf(ci0 + static_cast<float>(t), ci_last);                                                 \
-    const int e0 = 3 * (__builtin_amdgcn_readlane(li_lane.i0, t) - ia); /* scalars: uniform register index */     \
+    const int e0 = 3 * (__builtin_amdgcn_readlane(li_lane.i0, t) - ia); /* scalars */                             \
     const int e1 = 3 * (__builtin_amdgcn_readlane(li_lane.i1, t) - ia);                                           \
     const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l0), t));                    \
     const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l1), t));                    \
-    const float di = lerp2(P[e0], l0, P[e1], l1);                                                                 \
-    const float dj = lerp2(P[e0 + 1], l0, P[e1 + 1], l1);                                                         \
-    const float dk = lerp2(P[e0 + 2], l0, P[e1 + 2], l1);                                                         \
+    if (e0 != cur0) { TIO_PLANE_PICK(e0, pa_i, pa_j, pa_k) cur0 = e0; }                                           \
+    if (e1 != cur1) { TIO_PLANE_PICK(e1, pb_i, pb_j, pb_k) cur1 = e1; }                                           \
+    const float di = lerp2(pa_i, l0, pb_i, l1);                                                                   \
+    const float dj = lerp2(pa_j, l0, pb_j, l1);                                                                   \
+    const float dk = lerp2(pa_k, l0, pb_k, l1);                                                                   \
     TIO_FINISH_COORD(t, di, dj, dk, true, NORM)                                                                   \
     TIO_TRACK_ALL(t)                                                                                              \
     if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -873,6 +887,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
           TIO_PLANE_LOOP(TIO_NORM_FULL)
         }
 #undef TIO_PLANE_LOOP
+#undef TIO_PLANE_PICK
       } else {
 #pragma unroll
         for (int t = 0; t < TI; t++) {
