@@ -751,6 +751,8 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
   // c*1 + 0 + 0 + 0 returns its argument bit for bit (c >= 0, so no -0 subtlety), skip it.
   const bool ident = (m00 == 1.0f) & (m01 == 0.0f) & (m02 == 0.0f) & (m03 == 0.0f) & (m10 == 0.0f) & (m11 == 1.0f) &
                      (m12 == 0.0f) & (m13 == 0.0f) & (m20 == 0.0f) & (m21 == 0.0f) & (m22 == 1.0f) & (m23 == 0.0f);
+  // the three block-uniform modes of TIO_FINISH_COORD; the hot elastic loop shadows them with literals
+  const bool m_unit = a.unit_spacing != 0, m_ident = ident, m_affine_first = a.affine_first != 0;
 #define TIO_AFFINE_ROW(M0, M1, M2, M3, A, B, C) \
   __builtin_fmaf(1.0f, M3, __builtin_fmaf(C, M2, __builtin_fmaf(B, M1, __fmul_rn(A, M0))))
 #define TIO_FINISH_COORD(T, DI, DJ, DK, HAS_D, NORM)                                                \
@@ -759,16 +761,16 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
     if (HAS_D) {                                                                                \
       float q_i = DI, q_j = DJ, q_k = DK;                                                       \
       (void)q_i; (void)q_j; (void)q_k;                                                          \
-      if (!a.unit_spacing) {                                                                    \
+      if (!m_unit) {                                                                            \
         q_i = exact_div(q_i, a.sp[0], a.rsp[0]);                                                \
         q_j = exact_div(q_j, a.sp[1], a.rsp[1]);                                                \
         q_k = exact_div(q_k, a.sp[2], a.rsp[2]);                                                \
       }                                                                                         \
-      if (ident) { /* c + d either way round */                                                 \
+      if (m_ident) { /* c + d either way round */                                               \
         vi = __fadd_rn(ci, q_i);                                                                \
         vj = __fadd_rn(cj, q_j);                                                                \
         vk = __fadd_rn(ck, q_k);                                                                \
-      } else if (a.affine_first) {                                                              \
+      } else if (m_affine_first) {                                                              \
         vi = __fadd_rn(TIO_AFFINE_ROW(m00, m01, m02, m03, ci, cj, ck), q_i);                    \
         vj = __fadd_rn(TIO_AFFINE_ROW(m10, m11, m12, m13, ci, cj, ck), q_j);                    \
         vk = __fadd_rn(TIO_AFFINE_ROW(m20, m21, m22, m23, ci, cj, ck), q_k);                    \
@@ -864,8 +866,10 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
     DJ = (E) == 0 ? P[1] : ((E) == 3 ? P[4] : P[7]);                    \
     DK = (E) == 0 ? P[2] : ((E) == 3 ? P[5] : P[8]);                    \
   }
-#define TIO_PLANE_LOOP(NORM)                                                                                      \
+#define TIO_PLANE_LOOP(NORM, UNIT, IDENT, AFFINE_FIRST)                                                           \
   _Pragma("unroll") for (int t = 0; t < TI; t++) {                                                                \
+    const bool m_unit = UNIT, m_ident = IDENT, m_affine_first = AFFINE_FIRST; /* literals fold the branches away */ \
+    (void)m_unit; (void)m_ident; (void)m_affine_first;                                                            \
     const float ci = fminf(ci0 + static_cast<float>(t), ci_last);                                                 \
     const int e0 = 3 * (__builtin_amdgcn_readlane(li_lane.i0, t) - ia); /* scalars */                             \
     const int e1 = 3 * (__builtin_amdgcn_readlane(li_lane.i1, t) - ia);                                           \
@@ -881,11 +885,26 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
     if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                                          \
   }
         // one block-uniform branch instead of a select per division
+        // one block-uniform branch instead of a select per division, and - for unit spacing, the usual
+        // 1 mm volumes - one copy of the loop per composition order, so that the 16 unrolled planes carry
+        // no scalar branches at all (they cost a wave more than the arithmetic they skip)
+        const bool outer_unit = a.unit_spacing != 0, outer_ident = ident, outer_af = a.affine_first != 0;
+#define TIO_PLANE_LOOPS(NORM)                                                         \
+  if (outer_unit && outer_ident) {                                                    \
+    TIO_PLANE_LOOP(NORM, true, true, true)                                            \
+  } else if (outer_unit && outer_af) {                                                \
+    TIO_PLANE_LOOP(NORM, true, false, true)                                           \
+  } else if (outer_unit) {                                                            \
+    TIO_PLANE_LOOP(NORM, true, false, false)                                          \
+  } else {                                                                            \
+    TIO_PLANE_LOOP(NORM, outer_unit, outer_ident, outer_af)                           \
+  }
         if (FAST || short_div) {
-          TIO_PLANE_LOOP(TIO_NORM_SHORT)
+          TIO_PLANE_LOOPS(TIO_NORM_SHORT)
         } else {
-          TIO_PLANE_LOOP(TIO_NORM_FULL)
+          TIO_PLANE_LOOPS(TIO_NORM_FULL)
         }
+#undef TIO_PLANE_LOOPS
 #undef TIO_PLANE_LOOP
 #undef TIO_PLANE_PICK
       } else {
