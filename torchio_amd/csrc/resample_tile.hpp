@@ -564,8 +564,11 @@ __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArg
   // The fill value lives in a scalar register: as a pending vector load its first use (inside the voxel
   // loop of boundary bricks) makes the compiler wait with vmcnt(0) there, which on every later voxel
   // also drains the previous voxel's STORE - one store round trip per voxel.
+  // (Through the scalar cache - the fill array is read-only for the launch: a vector load + readfirstlane
+  // here costs every brick, interior ones included, a memory round trip right after the barrier.)
   const bool has_fill = g.fill != nullptr;
-  const float fillv = has_fill ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g.fill[c]))) : 0.0f;
+  typedef __attribute__((address_space(4))) const float* const_float_ptr;
+  const float fillv = has_fill ? ((const_float_ptr)g.fill)[c] : 0.0f;
   // Output addresses: block-uniform running pointer (one plane = slab_b bytes) + this
   // thread's byte offset inside the plane.
   const int64_t slab_b = static_cast<int64_t>(slab) * es;
