@@ -192,3 +192,29 @@ def test_queue_with_distributed_sampler_splits_the_subjects():
     assert seen == [[0, 2, 4], [1, 3, 5]]
     with pytest.raises(ValueError, match="shuffle_subjects must be False"):
         tio.Queue(subjects, tio.UniformSampler(subjects[0], 4), subject_sampler=DistributedSampler(subjects, num_replicas=2, rank=0))
+
+
+# -- SubjectsLoader ----------------------------------------------------------------------
+def test_subjects_loader_runs_the_documented_dense_inference_loop():
+    """sampler.py:84-96: GridSampler -> SubjectsLoader -> model -> aggregator.add_batch(outputs, locations)."""
+    from torchio_amd.loader import ImagesLoader
+    from torchio_amd.loader import SubjectsLoader
+
+    volume = torch.rand(1, 20, 18, 16)
+    subject = tio.Subject(t1=tio.ScalarImage(volume), note="kept")
+    sampler = tio.GridSampler(subject, patch_size=8, patch_overlap=4)
+    aggregator = tio.PatchAggregator(subject.spatial_shape, overlap_mode="crop", patch_overlap=4)
+    seen = 0
+    for batch in SubjectsLoader(sampler, batch_size=5):
+        assert isinstance(batch, tio.SubjectsBatch) and batch.t1.data.shape[1:] == (1, 8, 8, 8)
+        locations = batch.metadata["patch_location"]  # per-sample metadata lists (data/batch.py:124-160)
+        assert len(locations) == batch.batch_size and batch.metadata["note"] == ["kept"] * batch.batch_size
+        aggregator.add_batch(batch.t1.data * 2, locations)  # "model": doubles the intensities
+        seen += batch.batch_size
+    assert seen == len(sampler)
+    assert torch.equal(aggregator.get_output(), volume * 2)
+    with pytest.raises(ValueError, match="sets collate_fn automatically"):
+        SubjectsLoader(sampler, collate_fn=lambda b: b)
+    images = [tio.ScalarImage(torch.rand(1, 4, 4, 4)) for _ in range(3)]
+    (image_batch,) = list(ImagesLoader(images, batch_size=3))
+    assert isinstance(image_batch, tio.ImagesBatch) and image_batch.data.shape == (3, 1, 4, 4, 4)

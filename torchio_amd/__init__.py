@@ -30,6 +30,8 @@ from .transforms import AppliedTransform
 from .transforms import BiasField
 from .transforms import Blur
 from .transforms import Choice
+from .loader import ImagesLoader
+from .loader import SubjectsLoader
 from .transforms import Compose
 from .transforms import Crop
 from .transforms import Pad
@@ -55,7 +57,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "Crop", "ElasticDeformation", "Flip",
-    "Gamma", "GridSampler", "Image", "ImagesBatch", "IntensityTransform", "LabelMap", "LabelSampler", "Motion", "Noise", "OneOf",
+    "Gamma", "GridSampler", "Image", "ImagesBatch", "ImagesLoader", "IntensityTransform", "LabelMap", "LabelSampler", "Motion", "Noise", "OneOf",
     "Pad", "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
-    "SubjectsBatch", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "set_noise_rng", "set_resample_precision",
+    "SubjectsBatch", "SubjectsLoader", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "set_noise_rng", "set_resample_precision",
 ]
