@@ -137,6 +137,29 @@ def aten_baseline(size: int, batch: int, device, steps: int = 3) -> dict:
     }
 
 
+def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int) -> dict:
+    """A few steps of the same Compose in another (noise rng, resample precision) mode: volumes/s on this GPU."""
+    previous = (tio.get_noise_rng(), tio.get_resample_precision())
+    tio.set_noise_rng(noise_rng)
+    tio.set_resample_precision(precision)
+    try:
+        torch.manual_seed(seed)
+        for _ in range(2):
+            transform(batch)
+        torch.cuda.synchronize()
+        start = time.perf_counter()
+        for _ in range(steps):
+            out = transform(batch)
+        del out
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - start
+    finally:
+        tio.set_noise_rng(previous[0])
+        tio.set_resample_precision(previous[1])
+    n = steps * batch.batch_size
+    return {"volumes_per_s": n / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps}
+
+
 def load_traffic() -> float | None:
     """Per-launch HBM bytes of the dominant kernel from the committed PMC summary, if any."""
     path = os.path.join(ROOT, "profiles", "resample_traffic.json")
@@ -159,7 +182,8 @@ def main() -> None:
                         help="exact = the reference's float32 operation sequence bit for bit (default); fast = opt-in fma path, within 1e-4")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-volumes", type=int, default=8)
-    parser.add_argument("--aten-baseline", action="store_true", help="also time the stock-ATen restatement of the pipeline")
+    parser.add_argument("--no-aten-baseline", action="store_true", help="skip the stock-ATen restatement of the pipeline (the honest 'before')")
+    parser.add_argument("--no-mode-matrix", action="store_true", help="skip the extra noise-rng / resample-precision legs (rank 0, N=1 only)")
     args = parser.parse_args()
 
     info = tdist.init_process_group()
@@ -250,7 +274,23 @@ def main() -> None:
                 "launches_timed": len(timer.pairs),
             },
         }
-        if args.gpus == 1 and args.aten_baseline:
+        if args.gpus == 1 and not args.no_mode_matrix:
+            # The headline value above is the mode named in config.  The other modes of the same pipeline, so
+            # that nobody has to guess what a different switch would have measured:
+            #   noise_rng "reference" = the reference's own stream (seeded CPU mt19937 draws + 64 MiB H2D per
+            #   volume: reference-identical, host bound); "philox" = in-kernel draws, NOT reference-identical;
+            #   resample_precision "exact" = bit-identical coordinates / interpolation; "fast" = within 1e-4.
+            out = None
+            modes = {}
+            for rng_mode, prec, steps in (("philox", "exact", 10), ("philox", "fast", 10), ("reference", "exact", 3)):
+                modes[f"noise={rng_mode},resample={prec}"] = time_mode(transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77)
+            line["mode_matrix"] = modes
+            line["noise_modes"] = {
+                "philox": modes["noise=philox,resample=exact"]["volumes_per_s"],
+                "reference": modes["noise=reference,resample=exact"]["volumes_per_s"],
+                "note": "reference = bit-identical noise stream (host mt19937 draws, host bound); philox = in-kernel draws, a different stream",
+            }
+        if args.gpus == 1 and not args.no_aten_baseline:
             out = None
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats()

@@ -10,7 +10,7 @@ mkdir -p "$HERE/_build"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 "$HERE/resample_bench.cpp" -o "$HERE/_build/resample_bench" \
   -L"$ROOT/torchio_amd/csrc" -ltio_hip -L"$ROOT/oracle" -ltio_oracle \
   -Wl,-rpath,'$ORIGIN/../../../torchio_amd/csrc' -Wl,-rpath,'$ORIGIN/../../../oracle'
-for tool in valu_rates dpp_check; do
+for tool in valu_rates dpp_check lds_rates; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 "$HERE/$tool.cpp" -o "$HERE/_build/$tool"
 done
 echo "built $HERE/_build/resample_bench"

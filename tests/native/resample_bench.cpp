@@ -164,10 +164,13 @@ static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
   }
 }
 
-struct Paths { const char* name; const char* path; const char* variant; };
+struct Paths { const char* name; const char* path; const char* variant; int fast; const char* shape; const char* stream; };
 static const Paths kPaths[] = {
-    {"gather", "gather", "0"}, {"tile16x16x16", "tile", "0"}, {"tile16x8x32", "tile", "1"}, {"tile8x8x32", "tile", "2"},
-    {"tile8x16x32w8", "tile", "3"}, {"tile8x16x16", "tile", "4"}};
+    {"gather", "gather", "0", 0, "0", nullptr}, {"tile16x16x16", "tile", "0", 0, "0", nullptr}, {"tile16x8x32", "tile", "1", 0, "0", nullptr},
+    {"tile8x8x32", "tile", "2", 0, "0", nullptr}, {"tile8x16x32w8", "tile", "3", 0, "0", nullptr}, {"tile8x16x16", "tile", "4", 0, "0", nullptr},
+    // TIO_PRECISION_FAST (float32 trilinear launches only; compared within 1e-4 relative, not bit for bit):
+    // the brick kernel's FAST instantiation (the product path) and the experimental streaming kernel
+    {"fast", "tile", "0", 1, "0", nullptr}, {"fast-stream4w", "tile", "0", 1, "0", "1"}, {"fast-stream8w", "tile", "0", 1, "2", "1"}};
 
 static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
   if (!g_case_filter.empty() && cs.name.find(g_case_filter) == std::string::npos) return 0;
@@ -262,6 +265,12 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     if (p != 0 && !g_path_filter.empty() && std::string(kPaths[p].name).find(g_path_filter) == std::string::npos) continue;
     setenv("TIO_RESAMPLE_PATH", kPaths[p].path, 1);
     setenv("TIO_TILE_VARIANT", kPaths[p].variant, 1);
+    setenv("TIO_STREAM_SHAPE", kPaths[p].shape, 1);
+    if (kPaths[p].stream) setenv("TIO_FAST_STREAM", "1", 1); else unsetenv("TIO_FAST_STREAM");
+    geom.precision = kPaths[p].fast ? TIO_PRECISION_FAST : TIO_PRECISION_EXACT;
+    bool all_f32_linear = true;
+    for (const Image& im : cs.images) all_f32_linear &= im.dtype == TIO_F32 && im.interp == TIO_LINEAR;
+    const bool tolerant = kPaths[p].fast && all_f32_linear;  // other launches stay on the exact kernels
     for (Image& im : cs.images) HIP_CHECK(hipMemset(im.d_out, 0xCD, static_cast<size_t>(B) * im.channels * n_out * dtype_bytes(im.dtype)));
     int st = tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
     if (st != 0) { fprintf(stderr, "%s/%s: tio_resample3d failed %d: %s\n", cs.name.c_str(), kPaths[p].name, st, tio_last_error()); return 1; }
@@ -277,12 +286,29 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
       ms /= reps;
     }
     size_t diff_first = 0, diff_oracle = 0;
+    double max_rel = 0.0;
     for (size_t i = 0; i < cs.images.size(); i++) {
       Image& im = cs.images[i];
       const size_t es = dtype_bytes(im.dtype);
       std::vector<uint8_t> got(static_cast<size_t>(B) * im.channels * n_out * es);
       HIP_CHECK(hipMemcpy(got.data(), im.d_out, got.size(), hipMemcpyDeviceToHost));
       if (p == 0) first[i] = got;
+      if (tolerant) {  // |fast - exact| <= 1e-4 max(1, |exact|); a flipped fill decision (mask within rounding of 0.5) counts apart
+        const float* gf = reinterpret_cast<const float*>(got.data());
+        const float* ff = reinterpret_cast<const float*>(first[i].data());
+        size_t flips = 0;
+        for (size_t e = 0; e < got.size() / 4; e++) {
+          const double ref = ff[e], val = gf[e];
+          const double rel = fabs(val - ref) / fmax(1.0, fabs(ref));
+          if (!(rel <= 1e-4)) {
+            const bool fill_flip = im.with_fill && (ff[e] == im.fill[(e / n_out) % im.channels] || gf[e] == im.fill[(e / n_out) % im.channels]);
+            if (fill_flip) flips++; else diff_first++;
+          } else if (rel > max_rel) max_rel = rel;
+        }
+        if (flips > 64) diff_first += flips;
+        if (flips) printf("  [%zu fill flips]", flips);
+        continue;
+      }
       for (size_t e = 0; e < got.size() / es; e++) {
         if (memcmp(&got[e * es], &first[i][e * es], es) != 0) diff_first++;
         if (check_oracle && memcmp(&got[e * es], &expect[i][e * es], es) != 0) diff_oracle++;
@@ -291,6 +317,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     printf("%-34s %-13s", cs.name.c_str(), kPaths[p].name);
     if (time_it) printf(" %8.3f ms  %8.1f GB/s algorithmic (%5.1f%% of 8 TB/s)", ms, algorithmic / (ms * 1e6), algorithmic / (ms * 1e6) / 80.0);
     printf("  mismatch vs gather: %zu", diff_first);
+    if (tolerant) printf("  (max rel %.2e)", max_rel);
     if (check_oracle) printf("  vs oracle: %zu", diff_oracle);
     printf("\n");
     fflush(stdout);

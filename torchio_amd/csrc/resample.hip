@@ -422,6 +422,7 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 }  // namespace tio
 
 #include "resample_tile.hpp"
+#include "resample_fast.hpp"
 
 extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
                               const tio_resample_image* images, void* stream) {
@@ -600,6 +601,63 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     const bool fast = geom->precision == TIO_PRECISION_FAST && dtmode == 0 && !a.any_nearest && variant == 0 &&
                       getenv("TIO_RESAMPLE_EXACT") == nullptr;
     if (fast) {
+      // The streaming kernel (resample_fast.hpp) needs 16-byte rows for its LDS-DMA, a control grid
+      // that fits its LDS slots and whose cells are at least a tile wide, and columns long enough
+      // for its look-ahead; everything else runs the exact kernel's FAST instantiation.
+      // EXPERIMENTAL, opt-in (TIO_FAST_STREAM=1): measured no faster than the brick kernel's FAST instantiation
+      // (profiles/r02_resample_sq.md has the counters and ablations), kept for the A/B.
+      bool stream = getenv("TIO_FAST_STREAM") != nullptr && (a.K & 3) == 0 && a.Io <= 8 * kStreamMaxSlabs;
+      for (int i = 0; i < a.n_images; i++) stream = stream && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
+      if (a.cp != nullptr) {
+        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
+        for (int d = 0; d < 3; d++)
+          if (n_ctl[d] > 2 && (n_vox[d] - 1) < (d == 0 ? 8 : 32) * (n_ctl[d] - 1)) stream = false;
+        if (n_cp > 2048) stream = false;
+      }
+      if (stream) {
+        int bpc_s = 2, shape = 0;
+        if (const char* env = getenv("TIO_STREAM_BPC")) bpc_s = atoi(env);
+        if (const char* env = getenv("TIO_STREAM_SHAPE")) shape = atoi(env);
+        if (bpc_s < 1 || bpc_s > 4) bpc_s = 2;
+        static int n_cu = 0;
+        if (n_cu == 0) {
+          int dev = 0, v = 0;
+          if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+          n_cu = v;
+        }
+        const int tj = 16, tk = 16, nb_s = 2;
+        a.tiles_k = (a.Ko + tk - 1) / tk; a.tiles_j = (a.Jo + tj - 1) / tj; a.tiles_i = 1;
+        int nch = 0;
+        for (int i = 0; i < a.n_images; i++) nch += a.img[i].channels;
+        const int64_t items = static_cast<int64_t>(a.B) * nch * a.tiles_j * a.tiles_k;
+        if (items >= (1LL << 30)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+        a.cp_lds = n_cp > 0 ? ((n_cp + 3) & ~3) : 0;
+        const int fixed_floats = kStreamMaxSlabs * kTableInts + 16 + a.cp_lds;
+        const int total_floats = (kLdsFloatsPerCU - 256) / bpc_s - 64;  // leave the hardware's allocation granule some slack
+        int cap_s = (total_floats - fixed_floats) / nb_s;
+        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0 && v < cap_s) cap_s = v; }
+        cap_s &= ~3;
+        if (cap_s < 1024) return fail(TIO_ERR_LAUNCH, "tio_resample3d: no LDS left for the slab buffers");
+        a.tile_cap = cap_s;
+        const size_t lds_s = static_cast<size_t>(fixed_floats + nb_s * cap_s) * sizeof(float);
+        int blocks_s = n_cu * bpc_s;
+        if (blocks_s > items) blocks_s = static_cast<int>((items + 7) / 8 * 8);
+        auto launch_stream = [&](auto kernel, int threads) -> int {
+          if (lds_s > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      static_cast<int>(lds_s)) != hipSuccess)
+            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_s);
+          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks_s)), dim3(threads), lds_s, s, a, static_cast<int>(items));
+          return check_launch("tio_resample3d");
+        };
+#define TIO_STREAM_LAUNCH(TJ, TK, NPW, NB) \
+  return a.cp != nullptr ? launch_stream(resample_stream_kernel<true, TJ, TK, NPW, NB>, TJ * TK * NPW) : launch_stream(resample_stream_kernel<false, TJ, TK, NPW, NB>, TJ * TK * NPW)
+        switch (shape) {
+          case 2: TIO_STREAM_LAUNCH(16, 16, 2, 2);
+          default: TIO_STREAM_LAUNCH(16, 16, 1, 2);
+        }
+#undef TIO_STREAM_LAUNCH
+      }
       a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
       a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;
       a.magic_j = a.tiles_j > 1 ? 0xFFFFFFFFu / a.tiles_j + 1u : 0u;

@@ -792,8 +792,11 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
     Y[T] = NORM(vj, a.dh[1], a.rdh[1], a.half_h[1]);                                            \
     Z[T] = NORM(vk, a.dh[2], a.rdh[2], a.half_h[2]);                                            \
   }
-#define TIO_NORM_RT(V, D, R, H) (FAST ? (V) : normalise_roundtrip_folded(V, D, R, H, short_div))
-#define TIO_NORM_SHORT(V, D, R, H) (FAST ? (V) : normalise_roundtrip_folded<true>(V, D, R, H))
+// FAST keeps the net scaling of the round trip, (S_own - 1) / max(S_norm - 1, 1) = half_h / dh: 1 for the usual
+// case, 0 on a one-voxel axis (2-D images: the coordinate collapses to 0 like in the exact path), the
+// resolution ratio for Resample(target) on a multi-resolution subject.
+#define TIO_NORM_RT(V, D, R, H) (FAST ? __fmul_rn(V, __fmul_rn(H, R)) : normalise_roundtrip_folded(V, D, R, H, short_div))
+#define TIO_NORM_SHORT(V, D, R, H) (FAST ? __fmul_rn(V, __fmul_rn(H, R)) : normalise_roundtrip_folded<true>(V, D, R, H))
 #define TIO_NORM_FULL(V, D, R, H) normalise_roundtrip_folded<false>(V, D, R, H)
 #define TIO_TRACK_ALL(T)                                                     \
   {                                                                          \
