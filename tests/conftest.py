@@ -24,6 +24,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: test imports the reference from /root/reference (build container only)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain ``pytest tests`` on a CPU-only box skips the gpu-marked tests instead of erroring in them."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (run with -m gpu on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle engine (test infrastructure)."""
@@ -39,5 +51,6 @@ def hip():
 
     from torchio_amd import ops
 
-    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    if not torch.cuda.is_available():
+        pytest.skip("needs a real MI355X (run with -m gpu on the GPU box)")
     return ops.engine()

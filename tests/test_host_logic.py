@@ -591,3 +591,45 @@ def test_unique_labels_on_the_oracle_engine(oracle):
         data = torch.randint(-3 if dtype != torch.uint8 else 0, 9, (2, 1, 5, 6, 7), generator=g).to(dtype)
         table = oracle.unique_labels(data)
         assert table.dtype == torch.float64 and torch.equal(table, torch.unique(data).double())
+
+
+# -- round-1 advisor findings ---------------------------------------------------------------
+def test_crop_result_never_aliases_the_input_batch(oracle):
+    """a transform that returns a VIEW of the borrowed tensor must still be cloned on the way out."""
+    data = torch.arange(2 * 1 * 6 * 6 * 6, dtype=torch.float32).reshape(2, 1, 6, 6, 6)
+    batch = tio.SubjectsBatch({"t1": tio.ImagesBatch(data.clone(), [tio.AffineMatrix() for _ in range(2)], image_class=tio.ScalarImage)})
+    before = batch.t1.data.clone()
+    with use_engine(oracle):
+        out = tio.Crop(cropping=1)(batch)
+    assert out.t1.data.untyped_storage().data_ptr() != batch.t1.data.untyped_storage().data_ptr()
+    out.t1.data.add_(1)
+    assert torch.equal(batch.t1.data, before)
+
+
+def test_lazy_params_survive_plain_dict_copies():
+    """dict(params) / {**params} / update() must see the materialised lists, not the placeholders."""
+    from torchio_amd.transforms._lazy_params import LazyParams
+
+    params = LazyParams(a=1)
+    params.set_lazy("control_points", torch.ones(2, 2))
+    assert dict(params)["control_points"] == [[1.0, 1.0], [1.0, 1.0]]
+    params.set_lazy("affine_matrix", torch.eye(2))
+    assert {**params}["affine_matrix"] == [[1.0, 0.0], [0.0, 1.0]]
+    other = {}
+    params.set_lazy("again", torch.zeros(1))
+    other.update(params)
+    assert other["again"] == [0.0] and list(other) == ["a", "control_points", "affine_matrix", "again"]
+
+
+def test_scalar_draw_plan_follows_reassigned_ranges(oracle):
+    """the draw-plan cache is keyed on the ranges' values, not on object ids."""
+    transform = tio.Affine(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5))
+    subject = tio.Subject(t1=tio.ScalarImage(torch.rand(1, 8, 8, 8)))
+    with use_engine(oracle):
+        transform(subject)
+        transform.degrees = type(transform.degrees)(0)  # a new range object: no rotation at all
+        torch.manual_seed(0)
+        out = transform(subject)
+    matrix = torch.as_tensor(out.applied_transforms[-1].params["affine_matrix"], dtype=torch.float64)
+    off_diagonal = matrix[:3, :3] - torch.diag(torch.diagonal(matrix[:3, :3]))
+    assert float(off_diagonal.abs().max()) < 1e-12, "the stale plan still rotated"

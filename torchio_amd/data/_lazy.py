@@ -17,6 +17,13 @@ import threading
 _state = threading.local()
 
 
+def _shares_storage(a, b) -> bool:
+    try:
+        return a is not None and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    except (AttributeError, RuntimeError):
+        return False
+
+
 def active_scope() -> "LazyCopyScope | None":
     return getattr(_state, "scope", None)
 
@@ -43,6 +50,11 @@ class LazyCopyScope:
         for holder, tensor in self._borrowed:
             if getattr(holder, "_pending", None) is not None:
                 holder._flush()  # deferred stages replace the tensor: no clone needed afterwards
-            if holder._data is tensor:
+            current = holder._data
+            if current is tensor:
                 holder._data = tensor.clone()
+            elif _shares_storage(current, tensor):
+                # a transform handed back a VIEW of the borrowed tensor (Crop slices, a user transform that
+                # writes ``img.data[...]`` in place and re-assigns it): still the caller's memory
+                holder._data = current.clone()
         self._borrowed.clear()

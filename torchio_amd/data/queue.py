@@ -1,21 +1,27 @@
-"""Patch queue for patch-based training (mirror of reference ``src/torchio/data/queue.py``).
+"""``Queue``: a shuffling buffer of patches between the subjects and the training loop.
 
-Same constructor, iteration order, shuffling (Python's ``random`` module, like the reference)
-and properties.  Subjects that live on the GPU are transformed there (the transform runs the
-HIP engine, re-entrant from the worker threads: the C ABI keeps no global mutable state and
-its error text is thread-local) and the sampler hands out views of the transformed tensors,
-so the buffer holds device-resident patches and nothing crosses PCIe on the way to the model.
+Contract = the reference's ``src/torchio/data/queue.py`` (constructor arguments, epoch semantics, use of
+Python's ``random`` for both shuffles, ``subject_sampler`` for the multi-GPU split, the size properties).
+The implementation is a small pipeline of generators:
+
+    subject order  ->  prepared subjects (load + transform, optionally on a thread pool, order kept)
+                   ->  patches (``patches_per_volume`` from each)  ->  buffer of ``max_length``  ->  consumer
+
+A subject that lives on the GPU is transformed there — the HIP engine is re-entrant from worker threads: no
+global mutable state in the C ABI, thread-local error text — and the samplers hand out views of the
+transformed tensors, so the buffer holds device-resident patches and nothing crosses PCIe on its way to the
+model.
 """
 from __future__ import annotations
 
-import random as _random
+import itertools
+import random
 from collections import deque
+from collections.abc import Iterable
 from collections.abc import Iterator
 from collections.abc import Sequence
 from collections.abc import Sized
-from concurrent.futures import Future
 from concurrent.futures import ThreadPoolExecutor
-from itertools import islice
 from typing import Any
 
 from torch.utils.data import IterableDataset
@@ -24,22 +30,35 @@ from torch.utils.data import Sampler
 from .sampler import PatchSampler
 from .subject import Subject
 
+_UNITS = ("Bytes", "KiB", "MiB", "GiB", "TiB")
+
+
+def _in_order(pool: ThreadPoolExecutor, work, items: Iterable) -> Iterator:
+    """``map(work, items)`` on *pool*, results in submission order, at most one item submitted ahead of demand
+    per idle result (the consumer decides how fast the subject list is walked)."""
+    waiting: deque = deque()
+    for item in items:
+        waiting.append(pool.submit(work, item))
+        while waiting and waiting[0].done():
+            yield waiting.popleft().result()
+    while waiting:
+        yield waiting.popleft().result()
+
 
 class Queue(IterableDataset):
-    """Buffer of patches for stochastic patch-based training (queue.py:23-92).
+    """Buffer of patches for stochastic patch-based training.
 
     Args:
         subjects: subjects to sample patches from.
-        patch_sampler: sampler called as ``patch_sampler(subject)``.
-        max_length: patches held in the buffer before it is (shuffled and) drained.
-        patches_per_volume: patches taken from each subject.
-        num_workers: background threads that load / transform subjects (0 = synchronous).
-        shuffle_subjects: shuffle the subject order at the start of each epoch.
-        shuffle_patches: shuffle the buffer before it is drained.
-        transform: applied to each subject before patch extraction.
-        subject_sampler: a ``torch.utils.data.Sampler`` of subject indices (e.g.
-            ``DistributedSampler``: the multi-GPU split of the feeding side); requires
-            ``shuffle_subjects=False``.
+        patch_sampler: called as ``patch_sampler(subject)``; ``patches_per_volume`` patches are taken from it.
+        max_length: patches collected before the buffer is (shuffled and) handed out.
+        patches_per_volume: patches per subject.
+        num_workers: threads that load / transform subjects ahead of the consumer (0 = inline).
+        shuffle_subjects: new random subject order every epoch.
+        shuffle_patches: shuffle each buffer before handing it out.
+        transform: applied to every subject before its patches are cut.
+        subject_sampler: a ``torch.utils.data.Sampler`` of subject indices (``DistributedSampler`` = the multi-GPU
+            split of the feeding side, reference queue.py:48-50); excludes ``shuffle_subjects``.
     """
 
     def __init__(
@@ -66,83 +85,67 @@ class Queue(IterableDataset):
         self.transform = transform
         self.subject_sampler = subject_sampler
 
-    # -- iteration -------------------------------------------------------------------
-    def __iter__(self) -> Iterator[Subject]:
-        buffer: list[Subject] = []
-        order = self._epoch_order()
-        if self.num_workers > 0:
-            yield from self._iterate_with_workers(order, buffer)
-        else:
-            for subject in order:
-                buffer.extend(self._sample_patches(self._prepare(subject)))
-                if len(buffer) >= self.max_length:
-                    yield from self._drain(buffer)
-            yield from self._drain(buffer)
+    # ---- the pipeline ----------------------------------------------------------------------
+    def _subject_order(self) -> list[Subject]:
+        if self.subject_sampler is not None:
+            return [self.subjects[index] for index in self.subject_sampler]
+        order = list(self.subjects)
+        if self.shuffle_subjects:
+            random.shuffle(order)
+        return order
 
-    def _iterate_with_workers(self, order: Iterator[Subject], buffer: list[Subject]) -> Iterator[Subject]:
-        """Subjects are prepared by a thread pool; finished ones are consumed in submission order (queue.py:114-145)."""
-        with ThreadPoolExecutor(max_workers=self.num_workers) as pool:
-            pending: deque[Future] = deque()
-            for subject in order:
-                pending.append(pool.submit(self._prepare, subject))
-                while pending and pending[0].done():
-                    buffer.extend(self._sample_patches(pending.popleft().result()))
-                if len(buffer) >= self.max_length:
-                    yield from self._drain(buffer)
-            for future in pending:
-                buffer.extend(self._sample_patches(future.result()))
-        yield from self._drain(buffer)
+    def _ready(self, subject: Subject) -> Subject:
+        subject.load()
+        return subject if self.transform is None else self.transform(subject)
 
-    def _drain(self, buffer: list[Subject]) -> Iterator[Subject]:
+    def _patches_of(self, subject: Subject) -> list[Subject]:
+        return list(itertools.islice(self.patch_sampler(subject), self.patches_per_volume))
+
+    def _hand_out(self, buffer: list[Subject]) -> Iterator[Subject]:
         if self.shuffle_patches:
-            _random.shuffle(buffer)
+            random.shuffle(buffer)
         while buffer:
             yield buffer.pop()
 
-    def _prepare(self, subject: Subject) -> Subject:
-        subject.load()
-        if self.transform is not None:
-            subject = self.transform(subject)
-        return subject
+    def _stream(self, prepared: Iterable[Subject]) -> Iterator[Subject]:
+        buffer: list[Subject] = []
+        for subject in prepared:
+            buffer += self._patches_of(subject)
+            if len(buffer) >= self.max_length:
+                yield from self._hand_out(buffer)
+        yield from self._hand_out(buffer)
 
-    def _sample_patches(self, subject: Subject) -> list[Subject]:
-        return list(islice(iter(self.patch_sampler(subject)), self.patches_per_volume))
+    def __iter__(self) -> Iterator[Subject]:
+        order = self._subject_order()
+        if self.num_workers <= 0:
+            yield from self._stream(map(self._ready, order))
+            return
+        with ThreadPoolExecutor(max_workers=self.num_workers) as pool:
+            yield from self._stream(_in_order(pool, self._ready, order))
 
-    def _epoch_order(self) -> Iterator[Subject]:
-        if self.subject_sampler is not None:
-            return (self.subjects[index] for index in list(self.subject_sampler))
-        subjects = list(self.subjects)
-        if self.shuffle_subjects:
-            _random.shuffle(subjects)
-        return iter(subjects)
-
-    # -- bookkeeping -----------------------------------------------------------------
+    # ---- sizes -------------------------------------------------------------------------------
     @property
     def num_subjects(self) -> int:
-        if self.subject_sampler is not None:
-            if not isinstance(self.subject_sampler, Sized):
-                raise TypeError("subject_sampler must have a __len__ method")
-            return len(self.subject_sampler)
-        return len(self.subjects)
+        if self.subject_sampler is None:
+            return len(self.subjects)
+        if not isinstance(self.subject_sampler, Sized):
+            raise TypeError("subject_sampler must have a __len__ method")
+        return len(self.subject_sampler)
 
     @property
     def patches_per_epoch(self) -> int:
-        return self.num_subjects * self.patches_per_volume
+        return self.patches_per_volume * self.num_subjects
 
     @property
     def max_memory(self) -> int:
-        """Upper bound of the buffer's footprint in bytes, float32 patches (queue.py:194-203)."""
+        """Bytes a full buffer of float32 patches takes (every image of the first subject counted)."""
         channels = sum(image.num_channels for image in self.subjects[0].images.values())
-        voxels = 1
-        for size in self.patch_sampler.patch_size:
-            voxels *= size
-        return 4 * channels * voxels * self.max_length
+        si, sj, sk = self.patch_sampler.patch_size
+        return self.max_length * channels * si * sj * sk * 4
 
     @property
     def max_memory_pretty(self) -> str:
-        value = float(self.max_memory)
-        for unit in ("Bytes", "KiB", "MiB", "GiB", "TiB"):
-            if value < 1024 or unit == "TiB":
-                return f"{value:.0f} {unit}" if unit == "Bytes" else f"{value:.1f} {unit}"
-            value /= 1024
-        return f"{value:.1f} TiB"
+        amount, unit = float(self.max_memory), 0
+        while amount >= 1024 and unit < len(_UNITS) - 1:
+            amount, unit = amount / 1024, unit + 1
+        return f"{amount:.0f} {_UNITS[unit]}" if unit == 0 else f"{amount:.1f} {_UNITS[unit]}"

@@ -1,12 +1,16 @@
-"""``SubjectsLoader`` / ``ImagesLoader`` (mirror of reference ``loader.py``): ``DataLoader`` + batch collation.
+"""Batch loaders: a ``torch.utils.data.DataLoader`` whose batches are the containers the transforms take.
 
-The feeding side of the path: patches from the samplers (views of device-resident volumes) or whole
-subjects are stacked into the ``SubjectsBatch`` / ``ImagesBatch`` the transforms and the model take
-(loader.py:15-95).  Device tensors cannot cross a worker-process boundary cheaply, so device-resident
-datasets are meant to run with ``num_workers=0`` (the ``Queue`` already overlaps loading with threads).
+``SubjectsLoader(dataset, **kw)`` collates ``Subject`` items into a :class:`~torchio_amd.data.batch.SubjectsBatch`
+and ``ImagesLoader`` collates ``Image`` items into an :class:`~torchio_amd.data.batch.ImagesBatch` — the
+reference's ``src/torchio/loader.py`` contract, including the refusal of a user ``collate_fn`` and the
+``StudiesLoader`` / ``collate_studies`` aliases.  Both classes come out of one factory.
+
+Device tensors do not cross a worker-process boundary cheaply: device-resident datasets are meant to run with
+``num_workers=0`` (``Queue`` already overlaps loading with threads).
 """
 from __future__ import annotations
 
+from collections.abc import Callable
 from collections.abc import Sequence
 from typing import Any
 
@@ -18,36 +22,28 @@ from .data.batch import SubjectsBatch
 
 
 def collate_subjects(batch: Sequence[Any]) -> SubjectsBatch:
-    """A list of ``Subject`` instances as one ``SubjectsBatch`` of stacked 5-D tensors (loader.py:15-25)."""
+    """``[Subject, ...]`` -> one ``SubjectsBatch`` (5-D tensors stacked per image name, metadata as lists)."""
     return SubjectsBatch.from_subjects(list(batch))
 
 
 def collate_images(batch: Sequence[Any]) -> ImagesBatch:
-    """A list of ``Image`` instances as one ``ImagesBatch`` (loader.py:28-38)."""
+    """``[Image, ...]`` -> one ``ImagesBatch``."""
     return ImagesBatch.from_images(list(batch))
 
 
-def _refuse_collate_fn(kwargs: dict, name: str) -> None:
-    if "collate_fn" in kwargs:
-        raise ValueError(f"{name} sets collate_fn automatically; pass a plain DataLoader if you need a custom collate_fn")
-
-
-class SubjectsLoader(DataLoader):
-    """``DataLoader`` that yields ``SubjectsBatch`` instances (loader.py:41-65)."""
-
+def _loader_class(name: str, collate: Callable[[Sequence[Any]], Any], yields: str) -> type[DataLoader]:
     def __init__(self, dataset: Dataset, **kwargs: Any) -> None:
-        _refuse_collate_fn(kwargs, "SubjectsLoader")
-        super().__init__(dataset, collate_fn=collate_subjects, **kwargs)
+        if "collate_fn" in kwargs:
+            raise ValueError(f"{name} sets collate_fn automatically; pass a plain DataLoader if you need a custom collate_fn")
+        DataLoader.__init__(self, dataset, collate_fn=collate, **kwargs)
+
+    doc = f"``DataLoader`` that yields ``{yields}`` instances; every other keyword goes to ``DataLoader`` unchanged."
+    return type(name, (DataLoader,), {"__init__": __init__, "__doc__": doc, "__module__": __name__})
 
 
-class ImagesLoader(DataLoader):
-    """``DataLoader`` that yields ``ImagesBatch`` instances (loader.py:68-91)."""
+SubjectsLoader = _loader_class("SubjectsLoader", collate_subjects, "SubjectsBatch")
+ImagesLoader = _loader_class("ImagesLoader", collate_images, "ImagesBatch")
 
-    def __init__(self, dataset: Dataset, **kwargs: Any) -> None:
-        _refuse_collate_fn(kwargs, "ImagesLoader")
-        super().__init__(dataset, collate_fn=collate_images, **kwargs)
-
-
-# aliases for radiology users (loader.py:93-95)
+# names radiology users know
 StudiesLoader = SubjectsLoader
 collate_studies = collate_subjects

@@ -76,6 +76,17 @@ class LazyParams(dict):
         self._materialise(key)
         return dict.setdefault(self, key, default)
 
+    # dict(params), {**params} and other.update(params) take CPython's C fast path for dict subclasses unless
+    # ``__iter__`` / ``keys`` are overridden: with them overridden the generic mapping protocol (keys() +
+    # __getitem__) is used, which materialises — otherwise a copy would carry the ``None`` placeholders.
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
     def items(self):
         self._materialise()
         return dict.items(self)

@@ -61,6 +61,17 @@ class _PerSampleGrids:
     max_displacements: list[tuple[float, float, float] | None]
 
 
+def _range_key(value):
+    """Hashable identity of a parameter range by value (``_ParameterRange._axes``), for the draw-plan cache."""
+    axes = getattr(value, "_axes", None)
+    if axes is None:
+        return ("raw", repr(value))
+    try:
+        return ("axes", tuple(tuple(a) if isinstance(a, (list, tuple)) else a for a in axes))
+    except TypeError:
+        return ("repr", repr(axes))
+
+
 class Spatial(SpatialTransform):
     r"""Resampling, affine motion and elastic deformation in a single resampling pass.
 
@@ -135,7 +146,9 @@ class Spatial(SpatialTransform):
     def _scalar_plan(self):
         """All scalar draws of one element as one small ``uniform_`` call (same values, same RNG state)."""
         draw_displacement = self.control_points is None
-        key = (id(self.scales), id(self.degrees), id(self.translation), id(self.max_displacement), self.isotropic, draw_displacement)
+        # keyed on the ranges' VALUES (a reassigned range object may reuse a freed object's id)
+        key = (_range_key(self.scales), _range_key(self.degrees), _range_key(self.translation), _range_key(self.max_displacement),
+               self.isotropic, draw_displacement)
         cached = self.__dict__.get("_scalar_plan_cache")
         if cached is None or cached[0] != key:
             ranges = [self.scales, self.degrees, self.translation] + ([self.max_displacement] if draw_displacement else [])
