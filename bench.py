@@ -180,6 +180,7 @@ def main() -> None:
     parser.add_argument("--noise-rng", choices=["reference", "philox"], default="philox")
     parser.add_argument("--resample-precision", choices=["exact", "fast"], default="exact",
                         help="exact = the reference's float32 operation sequence bit for bit (default); fast = opt-in fma path, within 1e-4")
+    parser.add_argument("--prewarm", type=int, default=100, help="untimed process pre-warm calls before the W warm-up steps")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-volumes", type=int, default=8)
     parser.add_argument("--no-aten-baseline", action="store_true", help="skip the stock-ATen restatement of the pipeline (the honest 'before')")
@@ -205,7 +206,7 @@ def main() -> None:
     # calls of a fresh process are ~30 % slower on the host side (pinned staging allocator, dispatcher and
     # Python caches still growing).  Same batch and shapes as the timed steps, so a profiler's per-kernel
     # averages over the whole process stay comparable with the live numbers below.
-    for _ in range(100):
+    for _ in range(args.prewarm):
         transform(batch)
     torch.cuda.synchronize()
     torch.manual_seed(4321 + info.rank)
@@ -259,6 +260,12 @@ def main() -> None:
                 "resample_precision": args.resample_precision,
                 "parallelism": f"batch-split x{args.gpus} (no data-path collective)",
             },
+            "distributed": {
+                "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                "world_size": info.world_size,
+                "counters_shape": list(counters.shape),
+                "collective": "one all_gather of [n_volumes, elapsed_s, algorithmic_bytes] per rank at the end; no data-path collective",
+            },
             "pipeline_algorithmic_GBps": total["algorithmic_bytes"] / total["elapsed_s"] / 1e9,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue_s / args.steps,
             "roofline": {
@@ -299,7 +306,7 @@ def main() -> None:
             line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_volumes, 99)
         print(json.dumps(line), flush=True)
     del out
-    if info.world_size > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

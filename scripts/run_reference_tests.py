@@ -29,6 +29,13 @@ DEFAULT_FILES = [
 ]
 
 
+# --bound: the seams' own test files plus the containers / protocol files that exercise them through Compose, history, inverse
+BOUND_FILES = [
+    "test_spatial.py", "test_blur.py", "test_bias_field.py", "test_noise.py", "test_gamma.py", "test_compose.py", "test_inverse.py",
+    "test_per_instance.py", "test_vectorization.py",
+]
+
+
 def install_alias() -> None:
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -87,21 +94,41 @@ def install_alias() -> None:
     sys.modules["torchio.transforms.spatial._padding"] = sys.modules["torchio.transforms.spatial.pad"]
 
 
-def run_one(name: str) -> int:
+def install_binding() -> None:
+    """--bound: the REAL reference package with `torchio_amd.reference_binding` applied, compute on the CPU oracle —
+    the reference's own classes, containers and tests; only the five seams run this repository's code."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import ref_import  # noqa: PLC0415
+    from oracle.oracle import oracle_engine  # noqa: PLC0415
+    from torchio_amd import ops  # noqa: PLC0415
+    from torchio_amd import reference_binding  # noqa: PLC0415
+
+    reference = ref_import.import_reference()
+    ops._ENGINE = oracle_engine()
+    reference_binding.bind(reference)
+
+
+def run_one(name: str, bound: bool = False) -> int:
     import pytest  # noqa: PLC0415
 
-    install_alias()
+    if bound:
+        install_binding()
+    else:
+        install_alias()
     return pytest.main(["-p", "no:cacheprovider", "-q", "--rootdir=/tmp", "-W", "ignore", os.path.join(REFERENCE_TESTS, name)])
 
 
 def main() -> None:
-    if len(sys.argv) == 3 and sys.argv[1] == "--one":
-        sys.exit(run_one(sys.argv[2]))
-    files = sys.argv[1:] or DEFAULT_FILES
+    if len(sys.argv) == 3 and sys.argv[1] in ("--one", "--one-bound"):
+        sys.exit(run_one(sys.argv[2], bound=sys.argv[1] == "--one-bound"))
+    bound = "--bound" in sys.argv[1:]
+    files = [arg for arg in sys.argv[1:] if arg != "--bound"] or (BOUND_FILES if bound else DEFAULT_FILES)
     rows = []
     for name in files:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        result = subprocess.run([sys.executable, __file__, "--one", name], capture_output=True, text=True, env=env, cwd="/tmp")
+        result = subprocess.run([sys.executable, __file__, "--one-bound" if bound else "--one", name], capture_output=True, text=True, env=env, cwd="/tmp")
         tail = result.stdout.strip().splitlines()[-1] if result.stdout.strip() else result.stderr.strip().splitlines()[-1]
         counts = {key: int(value) for value, key in re.findall(r"(\d+) (passed|failed|skipped|errors|error)", tail)}
         failed = [line.split(" - ")[0].replace("FAILED ::", "") for line in result.stdout.splitlines() if line.startswith("FAILED")]

@@ -1,0 +1,140 @@
+"""Build container only: INTEGRATION.md's patch EXECUTED against the real reference.
+
+``torchio_amd.reference_binding.bind(torchio)`` replaces the reference's five seams with this repository's seam
+functions.  Here the compute engine is the CPU oracle (the HIP library needs a GPU; the arithmetic is held to the
+oracle by the ``-m gpu`` tests), so what these tests pin is the BOUNDARY: the reference's own classes, containers,
+parameter dictionaries, history and inverse keep working when the seams are ours, and everything the engine does
+not take falls back to the reference's original code.
+"""
+from __future__ import annotations
+
+import subprocess
+import sys
+import os
+
+import pytest
+import torch
+
+import ref_import
+from parity_harness import use_engine
+
+pytestmark = [
+    pytest.mark.reference,
+    pytest.mark.skipif(not ref_import.reference_available(), reason="/root/reference is only present in the build container"),
+]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def bound():
+    from torchio_amd import reference_binding
+
+    reference = ref_import.import_reference()
+    reference_binding.bind(reference)
+    try:
+        yield reference
+    finally:
+        reference_binding.unbind()
+
+
+def _subject(tio, size=24, seed=0, grad=False):
+    g = torch.Generator().manual_seed(seed)
+    t1 = torch.rand(1, size, size, size, generator=g)
+    seg = (torch.rand(1, size, size, size, generator=g) * 4).to(torch.int16)
+    return tio.Subject(t1=tio.ScalarImage(t1.requires_grad_(grad)), seg=tio.LabelMap(seg))
+
+
+def _pipeline(tio):
+    return tio.Compose([
+        tio.Affine(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-2, 2)), tio.ElasticDeformation(), tio.BiasField(),
+        tio.Blur(std=(0.5, 2)), tio.Noise(), tio.Gamma(log_gamma=(-0.3, 0.3)),
+    ])
+
+
+def test_reference_classes_run_the_engine_and_agree_with_themselves(oracle):
+    from torchio_amd import ops, reference_binding
+
+    tio = ref_import.import_reference()
+    torch.manual_seed(1)
+    expected = _pipeline(tio)(_subject(tio))  # the unmodified reference
+    calls = []
+    original_call = oracle._call
+    oracle._call = lambda name, *args: (calls.append(name), original_call(name, *args))[1]
+    try:
+        reference_binding.bind(tio)
+        with use_engine(oracle):
+            torch.manual_seed(1)
+            actual = _pipeline(tio)(_subject(tio))
+            restored = actual.apply_inverse_transform(warn=False)
+    finally:
+        oracle._call = original_call
+        reference_binding.unbind()
+    assert {"resample3d", "separable_conv3d", "bias_field_apply", "add_noise", "gamma_pow"} <= set(calls), calls
+    assert type(actual) is type(expected) and type(actual["t1"]) is tio.ScalarImage  # the reference's own containers
+    assert torch.equal(expected["seg"].data, actual["seg"].data)
+    rel = ((expected["t1"].data - actual["t1"].data).abs() / expected["t1"].data.abs().clamp_min(1)).max().item()
+    assert rel <= 5e-6, rel
+    assert [t.name for t in actual.applied_transforms] == [t.name for t in expected.applied_transforms]
+    assert [t.params for t in actual.applied_transforms] == [t.params for t in expected.applied_transforms]
+    assert restored["t1"].data.shape == expected["t1"].data.shape and restored.applied_transforms == []
+
+
+def test_cpu_tensors_fall_back_to_the_reference_when_only_the_hip_engine_exists(bound, monkeypatch):
+    """The product engine reads device memory only: a CPU subject — the reference's everyday use — must keep
+    working through the reference's own code, bit for bit."""
+    from torchio_amd import ops, reference_binding
+
+    tio = bound
+
+    class HipOnly:  # stands for the HIP engine on a box without a GPU: every call on CPU data is refused
+        def __getattr__(self, name):
+            def refuse(*args, **kwargs):
+                raise ops.EngineError(f"{name}: tensor on cpu but the hip engine runs on cuda tensors")
+            return refuse
+
+    monkeypatch.setattr(ops, "_ENGINE", HipOnly())
+    torch.manual_seed(3)
+    actual = _pipeline(tio)(_subject(tio))
+    reference_binding.unbind()
+    torch.manual_seed(3)
+    expected = _pipeline(tio)(_subject(tio))
+    for name in ("t1", "seg"):
+        assert torch.equal(expected[name].data, actual[name].data), name
+
+
+def test_tensors_that_require_grad_stay_on_the_reference(bound, oracle):
+    """reference tests/test_noise.py:75-80: the transforms are differentiable; the engine ops are not, so such
+    inputs never reach them."""
+    tio = bound
+    calls = []
+    original_call = oracle._call
+    oracle._call = lambda name, *args: (calls.append(name), original_call(name, *args))[1]
+    try:
+        with use_engine(oracle):
+            subject = tio.Subject(t1=tio.ScalarImage(torch.rand(1, 12, 12, 12).requires_grad_(True)))
+            out = tio.Compose([tio.Affine(degrees=5), tio.Blur(std=1.0), tio.Noise(std=0.1), tio.Gamma(log_gamma=0.2)])(subject)
+            out["t1"].data.sum().backward()
+    finally:
+        oracle._call = original_call
+    assert calls == [] and out["t1"].data.requires_grad
+
+
+def test_the_references_own_test_files_pass_through_the_binding():
+    """`scripts/run_reference_tests.py --bound`: the reference's test files for the five seams (+ Compose, inverse,
+    per-instance, vectorisation) run against the reference's own classes with the binding active.  The seven failures
+    are the same seven the UNMODIFIED reference has in this image (no `interpol`, no `nibabel`)."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_reference_tests.py"), "--bound"],
+                          capture_output=True, text=True, env=env, timeout=900)
+    rows = {}
+    for line in done.stdout.splitlines():
+        if line.startswith("| `test_"):
+            cells = [c.strip() for c in line.strip("|").split("|")]
+            rows[cells[0].strip("`")] = (int(cells[1]), int(cells[2]), cells[3])
+    assert set(rows) >= {"test_spatial.py", "test_blur.py", "test_bias_field.py", "test_noise.py", "test_gamma.py"}, done.stdout[-2000:]
+    for name, (passed, failed, which) in rows.items():
+        if name == "test_spatial.py":
+            assert passed >= 103 and failed <= 7, (name, passed, failed, which)
+            assert all(("HighOrder" in w) or ("higher_order" in w) or ("integer_order" in w) or ("file_path" in w) for w in which.split(", ")), which
+        else:
+            assert failed == 0 and passed > 0, (name, passed, failed, which)

@@ -36,7 +36,10 @@ def rank_info() -> RankInfo:
 def init_process_group(backend: str | None = None) -> RankInfo:
     """Initialise the default group when WORLD_SIZE > 1 (``nccl`` == RCCL on ROCm, ``gloo`` on CPU)."""
     info = rank_info()
-    if info.world_size > 1 and not dist.is_initialized():
+    # under a launcher (torch.distributed.run sets RANK / MASTER_ADDR) the group is created even for one rank, so that
+    # `--nproc-per-node 1` walks the same RCCL path (communicator, barrier, all-gather) as N ranks do
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if (info.world_size > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -105,10 +105,16 @@ class Engine:
                 continue
             if t.device.type != self.device_type:
                 raise EngineError(
-                    f"{what}: tensor on {t.device} but the {self.name} engine runs on {self.device_type} tensors"
+                    f"{what}: tensor on {t.device} but the {self.name} engine runs on {self.device_type} tensors — move the data"
+                    f" to the GPU (`subject.to('cuda')`), or keep using `torchio` itself with"
+                    " `torchio_amd.reference_binding.bind()`: there, host tensors stay on the reference's own code"
                 )
             if t.requires_grad:
-                raise EngineError(f"{what}: tensors that require grad are not supported by the {self.name} engine")
+                raise EngineError(
+                    f"{what}: tensors that require grad are not supported by the {self.name} engine (its ops are not differentiable)"
+                    " — detach them, or use `torchio` with `torchio_amd.reference_binding.bind()`, which leaves autograd inputs"
+                    " to the reference's differentiable path"
+                )
 
     def _stream(self, ref: Tensor):
         if self.device_type == "cuda":

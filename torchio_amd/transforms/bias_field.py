@@ -93,6 +93,8 @@ def _apply_to_images(transform, batch: SubjectsBatch, std, seed, scale: float, *
 
 def _defer_bias(img_batch, std, seed, scale: float, per_element: bool) -> bool:
     """Queue the multiply on the batch (data/_pending.py): a ``Blur`` that follows folds it into its loads."""
+    if not hasattr(img_batch, "_flush"):  # a foreign container (reference_binding): launch right away
+        return False
     data = img_batch.data  # finished values of whatever came before
     if not _pending.eligible(data):
         return False

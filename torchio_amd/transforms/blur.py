@@ -72,6 +72,8 @@ def _defer_blur(img_batch, sigmas) -> bool:
     A ``BiasField`` queued just before and a ``Noise`` arriving just after are then folded into
     the stencil's passes; any other reader of ``img_batch.data`` launches what is queued.
     """
+    if not hasattr(img_batch, "_flush"):  # a foreign container (reference_binding): launch right away
+        return False
     raw = img_batch._data
     if not _pending.eligible(raw):
         return False

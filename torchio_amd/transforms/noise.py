@@ -84,7 +84,7 @@ class Noise(IntensityTransform):
         generator.manual_seed(seed)
         engine = ops.engine()
         for index, img_batch in enumerate(self._get_images(batch).values()):
-            queue = img_batch._pending
+            queue = getattr(img_batch, "_pending", None)  # foreign containers (reference_binding) never defer
             if (
                 queue is not None and queue.blur is not None and _NOISE_RNG != "reference" and not rician and keep is None
                 and _pending.eligible(img_batch._data)

@@ -61,6 +61,13 @@ class _PerSampleGrids:
     max_displacements: list[tuple[float, float, float] | None]
 
 
+def _is_label_batch(img_batch) -> bool:
+    """Label map or intensity image?  By class NAME along the MRO, so that the reference's own containers
+    (``torchio.LabelMap`` under ``reference_binding``) are recognised like this package's."""
+    kind = img_batch._image_class
+    return isinstance(kind, type) and (issubclass(kind, LabelMap) or any(base.__name__ == "LabelMap" for base in kind.__mro__))
+
+
 def _range_key(value):
     """Hashable identity of a parameter range by value (``_ParameterRange._axes``), for the draw-plan cache."""
     axes = getattr(value, "_axes", None)
@@ -593,7 +600,7 @@ def _apply_spatial_to_batch(
     finished: dict[str, Tensor] = {}
     for name in image_names:
         img_batch = batch.images[name]
-        is_label = issubclass(img_batch._image_class, LabelMap)
+        is_label = _is_label_batch(img_batch)
         interpolation = label_interpolation if is_label else image_interpolation
         data = img_batch.data
         table, pad = None, 0.0
@@ -730,7 +737,7 @@ def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pa
     """
     data = img_batch.data
     channels = data.shape[1]
-    if issubclass(img_batch._image_class, LabelMap):
+    if _is_label_batch(img_batch):
         value: Any = float(default_pad_label)
     elif isinstance(default_pad_value, Number):
         value = float(default_pad_value)
