@@ -164,13 +164,14 @@ static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
   }
 }
 
-struct Paths { const char* name; const char* path; const char* variant; int fast; const char* shape; const char* stream; };
+struct Paths { const char* name; const char* path; const char* variant; int fast; const char* kernel; };
 static const Paths kPaths[] = {
-    {"gather", "gather", "0", 0, "0", nullptr}, {"tile16x16x16", "tile", "0", 0, "0", nullptr}, {"tile16x8x32", "tile", "1", 0, "0", nullptr},
-    {"tile8x8x32", "tile", "2", 0, "0", nullptr}, {"tile8x16x32w8", "tile", "3", 0, "0", nullptr}, {"tile8x16x16", "tile", "4", 0, "0", nullptr},
-    // TIO_PRECISION_FAST (float32 trilinear launches only; compared within 1e-4 relative, not bit for bit):
-    // the brick kernel's FAST instantiation (the product path) and the experimental streaming kernel
-    {"fast", "tile", "0", 1, "0", nullptr}, {"fast-stream4w", "tile", "0", 1, "0", "1"}, {"fast-stream8w", "tile", "0", 1, "2", "1"}};
+    {"gather", "gather", "0", 0, nullptr}, {"tile16x16x16", "tile", "0", 0, nullptr}, {"tile16x8x32", "tile", "1", 0, nullptr},
+    {"tile8x8x32", "tile", "2", 0, nullptr}, {"tile8x16x32w8", "tile", "3", 0, nullptr}, {"tile8x16x16", "tile", "4", 0, nullptr},
+    // TIO_PRECISION_FAST (float32 trilinear launches only; compared within 1e-4 relative, not bit for bit): the brick
+    // kernel's FAST instantiation (the product path) and the experimental kernels of resample_fast.hpp
+    {"fast", "tile", "0", 1, nullptr}, {"fast-lean", "tile", "0", 1, "lean"}, {"fast-stream", "tile", "0", 1, "stream"},
+    {"fast-stream8", "tile", "0", 1, "stream8"}};
 
 static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
   if (!g_case_filter.empty() && cs.name.find(g_case_filter) == std::string::npos) return 0;
@@ -265,8 +266,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     if (p != 0 && !g_path_filter.empty() && std::string(kPaths[p].name).find(g_path_filter) == std::string::npos) continue;
     setenv("TIO_RESAMPLE_PATH", kPaths[p].path, 1);
     setenv("TIO_TILE_VARIANT", kPaths[p].variant, 1);
-    setenv("TIO_STREAM_SHAPE", kPaths[p].shape, 1);
-    if (kPaths[p].stream) setenv("TIO_FAST_STREAM", "1", 1); else unsetenv("TIO_FAST_STREAM");
+    if (kPaths[p].kernel) setenv("TIO_FAST_KERNEL", kPaths[p].kernel, 1); else unsetenv("TIO_FAST_KERNEL");
     geom.precision = kPaths[p].fast ? TIO_PRECISION_FAST : TIO_PRECISION_EXACT;
     bool all_f32_linear = true;
     for (const Image& im : cs.images) all_f32_linear &= im.dtype == TIO_F32 && im.interp == TIO_LINEAR;

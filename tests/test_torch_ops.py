@@ -1,0 +1,58 @@
+"""``torch.ops.tio_hip.*`` (csrc/torch_ops.cpp): the PyTorch-ROCm custom-op face of the C ABI.
+
+CPU: the library loads, every op is registered with the documented schema, CPU tensors are refused by the
+dispatcher.  GPU: every op returns exactly what the ``ctypes`` engine returns (same entry points underneath), on
+the current stream, without synchronising.
+"""
+from __future__ import annotations
+
+import pytest
+import torch
+
+OPS = ("resample3d", "separable_conv3d", "bias_field_apply", "add_noise", "gamma_pow", "channel_min")
+
+
+def test_library_loads_and_registers_every_op():
+    import torchio_amd.torch_ops  # noqa: F401
+
+    for name in OPS:
+        schema = str(getattr(torch.ops.tio_hip, name).default._schema)
+        assert schema.startswith(f"tio_hip::{name}("), schema
+    assert "Tensor?[] fill" in str(torch.ops.tio_hip.resample3d.default._schema)
+    with pytest.raises(NotImplementedError, match="CPU"):
+        torch.ops.tio_hip.gamma_pow(torch.rand(1, 1, 2, 2, 2), torch.tensor(2.0))
+
+
+@pytest.mark.gpu
+def test_custom_ops_equal_the_ctypes_engine(hip):
+    import torchio_amd.torch_ops as tops
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(2, 1, 40, 36, 44, generator=g, device="cuda")
+    seg = (torch.rand(2, 1, 40, 36, 44, generator=g, device="cuda") * 5).to(torch.int16)
+    mapping = torch.tensor([[[0.98, 0.05, -0.02, 1.5], [-0.04, 1.03, 0.03, -2.0], [0.02, -0.03, 0.95, 0.7]]], device="cuda").repeat(2, 1, 1)
+    mapping[1, :, 3] += 1.25
+    cp = (torch.rand(2, 5, 5, 5, 3, generator=g, device="cuda") - 0.5) * 4
+    fill = torch.tensor([-1.0], device="cuda")
+    ours = torch.ops.tio_hip.resample3d([x, seg], [1, 0], mapping, cp, [1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [40, 36, 44], True, [fill, None])
+    ref = hip.resample3d([x, seg], interps=["linear", "nearest"], mapping=mapping, control_points=cp, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1),
+                         out_shape=(40, 36, 44), affine_first=True, fills=[fill, None])
+    assert torch.equal(ours[0], ref[0]) and torch.equal(ours[1], ref[1]) and ours[1].dtype == torch.int16
+
+    blurred = tops.gaussian_blur3d(x, [[1.5, 0.0, 0.7], [0.6, 2.0, 0.0]])
+    from torchio_amd.transforms.blur import _gaussian_smooth
+
+    assert torch.equal(blurred, _gaussian_smooth(x, [[1.5, 0.0, 0.7], [0.6, 2.0, 0.0]]))
+
+    coarse = torch.randn(2, 1, 6, 6, 6, generator=g, device="cuda") * 0.3
+    assert torch.equal(torch.ops.tio_hip.bias_field_apply(x, coarse), hip.bias_field_apply(x, coarse))
+    base = torch.randn(x.shape, generator=g, device="cuda")
+    mean, std = torch.tensor([0.1, -0.2], device="cuda"), torch.tensor([0.3, 0.05], device="cuda")
+    assert torch.equal(torch.ops.tio_hip.add_noise(x, mean, std, False, base), hip.add_noise(x, mean, std, base1=base))
+    assert torch.equal(torch.ops.tio_hip.add_noise(x, torch.tensor(0.0), torch.tensor(0.25), False, None, None, 1234),
+                       hip.add_noise(x, 0.0, 0.25, philox_seed=1234))
+    gamma = torch.tensor([0.8, 1.3], device="cuda")
+    assert torch.equal(torch.ops.tio_hip.gamma_pow(x - 0.5, gamma), hip.gamma_pow(x - 0.5, gamma))
+    assert torch.equal(torch.ops.tio_hip.channel_min(x), hip.channel_min(x))
+    with pytest.raises(RuntimeError, match="require grad"):
+        torch.ops.tio_hip.gamma_pow(x.clone().requires_grad_(True), gamma)

@@ -604,9 +604,11 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
       // The streaming kernel (resample_fast.hpp) needs 16-byte rows for its LDS-DMA, a control grid
       // that fits its LDS slots and whose cells are at least a tile wide, and columns long enough
       // for its look-ahead; everything else runs the exact kernel's FAST instantiation.
-      // EXPERIMENTAL, opt-in (TIO_FAST_STREAM=1): measured no faster than the brick kernel's FAST instantiation
-      // (profiles/r02_resample_sq.md has the counters and ablations), kept for the A/B.
-      bool stream = getenv("TIO_FAST_STREAM") != nullptr && (a.K & 3) == 0 && a.Io <= 8 * kStreamMaxSlabs;
+      // EXPERIMENTAL, opt-in (TIO_FAST_KERNEL=stream | stream8): the persistent streaming kernel of resample_fast.hpp,
+      // measured no faster than the brick kernel's FAST instantiation (profiles/r02_resample_sq.md has the counters
+      // and ablations); kept for the A/B.
+      const char* fast_kernel = getenv("TIO_FAST_KERNEL");  // unset = the brick kernel's FAST instantiation (the product path)
+      bool stream = fast_kernel != nullptr && strncmp(fast_kernel, "stream", 6) == 0 && (a.K & 3) == 0 && a.Io <= 8 * kStreamMaxSlabs;
       for (int i = 0; i < a.n_images; i++) stream = stream && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
       if (a.cp != nullptr) {
         const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
@@ -615,9 +617,9 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
         if (n_cp > 2048) stream = false;
       }
       if (stream) {
-        int bpc_s = 2, shape = 0;
+        int bpc_s = 2;
+        const int shape = strcmp(fast_kernel, "stream8") == 0 ? 2 : 0;  // 8 waves per block (planes of a slab split) or 4
         if (const char* env = getenv("TIO_STREAM_BPC")) bpc_s = atoi(env);
-        if (const char* env = getenv("TIO_STREAM_SHAPE")) shape = atoi(env);
         if (bpc_s < 1 || bpc_s > 4) bpc_s = 2;
         static int n_cu = 0;
         if (n_cu == 0) {
@@ -671,6 +673,35 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
         hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
         return check_launch("tio_resample3d");
       };
+      // EXPERIMENTAL, opt-in (TIO_FAST_KERNEL=lean): the lean brick kernel of resample_fast.hpp — same speed as the
+      // product path for affine launches, slower for elastic ones (profiles/r02_resample_sq.md); kept for the A/B.
+      bool lean = fast_kernel != nullptr && strcmp(fast_kernel, "lean") == 0 && (a.K & 3) == 0;
+      for (int i = 0; i < a.n_images; i++) lean = lean && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
+      if (a.cp != nullptr) {
+        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
+        for (int d = 0; d < 3; d++)
+          if (n_ctl[d] > 2 && (n_vox[d] - 1) < 16 * (n_ctl[d] - 1)) lean = false;
+      }
+      if (lean) {
+        int bpc_l = kTileBlocksPerCU;
+        if (const char* env = getenv("TIO_FAST_BPC")) { const int v = atoi(env); if (v >= 1 && v <= 8) bpc_l = v; }
+        int cap_l = kLdsFloatsPerCU / bpc_l - 512 - 16;
+        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_l = v; }
+        if (cap_l < kTileMinCap) cap_l = kTileMinCap;
+        if (cap_l > kLdsFloatsPerCU - 16) cap_l = kLdsFloatsPerCU - 16;
+        a.tile_cap = cap_l;
+        a.cp_lds = 0;
+        const size_t lds_l = static_cast<size_t>(16 + cap_l) * sizeof(float);
+        auto launch_lean = [&](auto kernel) -> int {
+          if (lds_l > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      static_cast<int>(lds_l)) != hipSuccess)
+            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_l);
+          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds_l, s, a);
+          return check_launch("tio_resample3d");
+        };
+        if (a.cp != nullptr) return launch_lean(resample_fastbrick_kernel<true, 16, 16, 16, 3>);
+        return launch_lean(resample_fastbrick_kernel<false, 16, 16, 16, 3>);
+      }
       if (a.cp != nullptr) return launch_fast(resample_tile_kernel<true, 0, 16, 16, 16, 3, true>);
       return launch_fast(resample_tile_kernel<false, 0, 16, 16, 16, 3, true>);
     }

@@ -1,33 +1,37 @@
-// resample_fast.hpp — the TIO_PRECISION_FAST resampler: float32 trilinear images only.
+// resample_fast.hpp — EXPERIMENTAL kernels for TIO_PRECISION_FAST launches (float32 trilinear images only),
+// opt-in through TIO_FAST_KERNEL=lean | stream | stream8.  The product path for FAST launches is the brick kernel's
+// FAST instantiation in resample_tile.hpp; nothing here runs unless the variable is set.
 //
-// Why a second kernel.  The exact brick kernel (resample_tile.hpp) spends ~130 vector
-// instructions per voxel on reproducing the reference's float32 operation sequence bit for
-// bit and saturates the vector ALU (profiles/r02_resample_sq.md).  Intensities only owe the
-// reference 1e-4 relative (BASELINE.json north_star), so launches made only of float32
-// trilinear images may run this kernel; label maps never do.  Same interpolant and fill rule
-// (spatial.py:1504-1648, 1695-1731), ~32 vector instructions per voxel.
+// Why they exist.  The exact brick kernel spends ~114 vector instructions per voxel on reproducing the reference's
+// float32 operation sequence and is ~80 % vector-ALU bound (profiles/r02_resample_sq.md: 239 M VALU wave-instructions
+// per bench launch, 0.39 ms of issue time at the measured gfx950 rates of tests/native/valu_rates.cpp, 0.496 ms
+// measured).  Intensities only owe the reference 1e-4 relative (BASELINE.json north_star), so the question of round 2
+// was how far a launch of float32 trilinear images can go once the arithmetic is cut to the bone:
+//   * coordinates as a LINE in the plane index per control cell, box-relative (x(t) = A + t B, the constant formed in
+//     float64): 3 fma per voxel, no coordinate arrays, error ~2e-6 voxel on top of the reference's own rounding;
+//   * the staged box from the <= 27 VERTICES of (planes x control cells) — the coordinate map is multilinear on each
+//     such sub-box, so its extremes sit on vertices — instead of per-voxel min / max tracking;
+//   * LDS-DMA addressed on the scalar unit (one wave instruction per group of rows of one x-plane, lane constants
+//     cached per row length);
+//   * seven fma lerps, the fill rule's in-bounds weight in its separable form and only in waves that really have a
+//     column leaving the volume (a monotone line is interior when its two end planes are).
+// That is 46 vector instructions per voxel all in (97 M per launch, 0.18 ms of issue time).
 //
-// Why it is a persistent, software-pipelined kernel.  With independent bricks the three phases
-// of a block — box + constants (vector ALU), staging (memory), sampling (LDS + vector ALU) —
-// measured 135 + 124 + 172 us for the bench launch and simply ADD UP (0.45 ms): the resident
-// blocks start together and stay in lock-step, so nothing overlaps.  Here one block owns a
-// column of TJ x TK output columns and walks it along i in slabs of <= SMAX planes:
-//   * wave NWC (the producer) runs ahead: for slab s + NB - 1 it evaluates the input bounding
-//     box from the <= 27 vertices of (slab x control cells) — the coordinate map is
-//     multilinear on each such sub-box, so its extremes sit on vertices; one lane per vertex, a
-//     DPP wave reduction — writes a descriptor to LDS and issues the LDS-DMA of the box into a
-//     ring of NB buffers (addressing on the scalar unit: one wave instruction per group of rows
-//     of one x-plane, lane constants computed once, no per-chunk division);
-//   * waves 0 .. NWC-1 (the consumers) sample slab s meanwhile: coordinates are a line in the
-//     plane index, x(t) = A + t B, in a box-relative frame (|x| < ~40, so one ulp is 4e-6 voxel;
-//     the slab constant is formed in float64 by the producer) — 3 fma per voxel, no coordinate
-//     arrays; 8 taps as four ds_read2_b32, seven fma lerps; the in-bounds weight mask of the
-//     fill rule in its separable form (boundary slabs with a fill value only);
-//   * ONE s_barrier per slab, no vector-memory wait in the consumers (their only VMEM
-//     operations are the output stores), control points served from an LDS copy.
-// Work items (batch element, image channel, tile column) are dealt to the persistent blocks in
-// XCD-contiguous ranges, neighbouring tile columns to CUs of the same XCD at the same time, so
-// the halo they share is served by that XCD's L2.
+// What was measured (8 x 256^3 f32, affine launch; ablations in profiles/r02_resample_sq.md).  Two structures:
+//   1. `resample_stream_kernel` — persistent blocks, one per (batch element, channel, 16 x 16 tile column), walking the
+//      column along i in slabs of 8 planes through a two-buffer LDS ring: every wave issues its share of slab n + 1's
+//      DMA, samples slab n (8 voxels of LDS reads in flight per lane), waits with a COUNTED vmcnt (its stores may stay
+//      in flight), one s_barrier per slab; the slab table of an item (boxes, float64 constants) is computed up front,
+//      one vertex per thread + LDS atomics.  0.49 - 0.50 ms: set-up alone 0.09, + DMA 0.25, + sampling 0.39 (alone).
+//      With two blocks of four waves per CU (LDS: 2 x 2 x 28 KB) the sampling runs at two waves per SIMD — 6 cycles
+//      per vector instruction on this chip — and the one-slab look-ahead leaves the ~2 us DMA latency exposed; eight
+//      waves per block (`stream8`) fix the first and expose the second; a third buffer only fits with 4-plane slabs.
+//   2. `resample_fastbrick_kernel` — the brick structure (independent 16^3 bricks, three resident blocks per CU) with
+//      the lean arithmetic: 0.436 ms, the same as the product path (0.437): set-up 0.146 + DMA 0.10 + sampling 0.17,
+//      which ADD UP: with three blocks per CU the throughput is 3 / (latency of one brick), and the latency chain
+//      kernarg -> mapping -> box -> barrier -> DMA -> barrier -> sampling is what is left once the ALU work is gone.
+// Neither beats the product path, so neither is the default; they stay as the reproducible A/B behind those numbers
+// (tests/native/resample_bench --path fast) and as the starting point for the next attempt.
 #pragma once
 
 namespace tio {
@@ -65,19 +69,22 @@ __device__ __forceinline__ void fast_axis(float src, int n, int& i0, int& i1, fl
   l = fminf(fmaxf(src - c, 0.0f), 1.0f);
 }
 
-struct FastFrame {
+template <typename CP>
+struct FastFrameT {
   float m[12];            // voxel mapping (rows scaled by the normalisation ratio of the axis)
   double c[3];            // mapping applied to (0, j_lo, k_lo)
   int j_lo, k_lo;
   bool elastic, affine_first;
-  fast_lds_ptr cp;        // control points of this batch element (LDS copy)
+  CP cp;                  // control points of this batch element (LDS copy in the streaming kernel, global in the brick kernel)
   int ni, nj, nk;
   float sci, scj, sck;    // control-grid lerp scales
   float dsc[3];           // displacement scale: 1 / spacing (times the axis ratio when affine_first)
 };
+typedef FastFrameT<fast_lds_ptr> FastFrame;
 
 // displacement (already in voxels) at the volume position (i, j, k), any of them fractional
-__device__ __forceinline__ void fast_displacement(const FastFrame& f, float pi, float pj, float pk, float (&d)[3]) {
+template <typename CP>
+__device__ __forceinline__ void fast_displacement(const FastFrameT<CP>& f, float pi, float pj, float pk, float (&d)[3]) {
   int i0, i1, j0, j1, k0, k1;
   float li, lj, lk;
   fast_axis(f.sci * pi, f.ni, i0, i1, li);
@@ -86,7 +93,7 @@ __device__ __forceinline__ void fast_displacement(const FastFrame& f, float pi, 
   const int s_i = f.nj * f.nk * 3, s_j = f.nk * 3;
 #pragma unroll
   for (int e = 0; e < 3; e++) {
-    fast_lds_ptr p = f.cp + e;
+    const CP p = f.cp + e;
     const float a00 = p[i0 * s_i + j0 * s_j + k0 * 3], a01 = p[i0 * s_i + j0 * s_j + k1 * 3];
     const float a10 = p[i0 * s_i + j1 * s_j + k0 * 3], a11 = p[i0 * s_i + j1 * s_j + k1 * 3];
     const float b00 = p[i1 * s_i + j0 * s_j + k0 * 3], b01 = p[i1 * s_i + j0 * s_j + k1 * 3];
@@ -99,7 +106,8 @@ __device__ __forceinline__ void fast_displacement(const FastFrame& f, float pi, 
 }
 
 // sampling coordinate (volume frame) of output position (u, j_lo + v, k_lo + w), u / v / w possibly fractional
-__device__ __forceinline__ void fast_coord(const FastFrame& f, float u, float v, float w, float& x, float& y, float& z) {
+template <typename CP>
+__device__ __forceinline__ void fast_coord(const FastFrameT<CP>& f, float u, float v, float w, float& x, float& y, float& z) {
   float d[3] = {0.0f, 0.0f, 0.0f};
   if (f.elastic) fast_displacement(f, u, static_cast<float>(f.j_lo) + v, static_cast<float>(f.k_lo) + w, d);
   float eu = u, ev = v, ew = w, ax = 0.0f, ay = 0.0f, az = 0.0f;
@@ -198,6 +206,96 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
     }
     ax += bxg; ay += byg; az += bzg;
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+
+// ---- the coordinate line of one column through a run of planes inside ONE control cell ---------------------
+// x(run0 + t) = A + t B, box-relative: C3 = mapping of (u_ref, j_lo, k_lo) relative to the box origin (float64 ->
+// float32, block uniform), col3 = the column's own (v, w) offset through the mapping, the elastic part as a linear
+// function of the plane index inside the cell.  Returns the end of the run (the next cell boundary or `limit`).
+struct ColumnPlanes {
+  int cell;        // control cell whose end planes are cached (-2: none)
+  float P0[3], P1[3];
+};
+
+template <typename CP>
+__device__ __forceinline__ int fast_column_line(const FastFrameT<CP>& f, const Lerp1D& lj, const Lerp1D& lk, ColumnPlanes& cache, int run0,
+                                                int limit, int u_ref, const float (&C3)[3], const float (&col3)[3], int lane,
+                                                float (&A3)[3], float (&B3)[3]) {
+  int run1 = limit;
+  const float du = static_cast<float>(run0 - u_ref);
+  if (f.elastic) {
+    const int cmax = f.ni > 1 ? f.ni - 2 : 0;
+    const int cell_l = min(max(static_cast<int>(floorf(f.sci * static_cast<float>(run0 + lane))), 0), cmax);
+    const int cell = __builtin_amdgcn_readlane(cell_l, 0);
+    const unsigned long long later = __builtin_amdgcn_ballot_w64((lane < run1 - run0) & (cell_l > cell));
+    if (later != 0ull) run1 = run0 + __builtin_ctzll(later);
+    if (cell != cache.cell) {  // (j, k)-lerped control planes at the two ends of the cell
+      const int s_i = f.nj * f.nk * 3, s_j = f.nk * 3;
+      const int c1 = min(cell + 1, f.ni - 1);
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        const CP q = f.cp + e;
+        const float a00 = q[cell * s_i + lj.i0 * s_j + lk.i0 * 3], a01 = q[cell * s_i + lj.i0 * s_j + lk.i1 * 3];
+        const float a10 = q[cell * s_i + lj.i1 * s_j + lk.i0 * 3], a11 = q[cell * s_i + lj.i1 * s_j + lk.i1 * 3];
+        const float b00 = q[c1 * s_i + lj.i0 * s_j + lk.i0 * 3], b01 = q[c1 * s_i + lj.i0 * s_j + lk.i1 * 3];
+        const float b10 = q[c1 * s_i + lj.i1 * s_j + lk.i0 * 3], b11 = q[c1 * s_i + lj.i1 * s_j + lk.i1 * 3];
+        const float a0 = __builtin_fmaf(lk.l1, a01 - a00, a00), a1 = __builtin_fmaf(lk.l1, a11 - a10, a10);
+        const float b0 = __builtin_fmaf(lk.l1, b01 - b00, b00), b1 = __builtin_fmaf(lk.l1, b11 - b10, b10);
+        cache.P0[e] = __builtin_fmaf(lj.l1, a1 - a0, a0);
+        cache.P1[e] = __builtin_fmaf(lj.l1, b1 - b0, b0);
+      }
+      cache.cell = cell;
+    }
+    // d(run0 + t) = P0 + (sci (run0 + t) - cell) (P1 - P0)
+    const float l_ref = fminf(fmaxf(__builtin_fmaf(f.sci, static_cast<float>(run0), -static_cast<float>(cell)), 0.0f), 1.0f);
+    float D0[3], D1[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const float dP = cache.P1[e] - cache.P0[e];
+      D0[e] = __builtin_fmaf(l_ref, dP, cache.P0[e]) * f.dsc[e];
+      D1[e] = f.sci * dP * f.dsc[e];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if (f.affine_first) {
+        A3[r] = __builtin_fmaf(f.m[4 * r], du, C3[r] + col3[r]) + D0[r];
+        B3[r] = f.m[4 * r] + D1[r];
+      } else {
+        A3[r] = __builtin_fmaf(f.m[4 * r], du + D0[0], __builtin_fmaf(f.m[4 * r + 1], D0[1], __builtin_fmaf(f.m[4 * r + 2], D0[2], C3[r] + col3[r])));
+        B3[r] = __builtin_fmaf(f.m[4 * r], 1.0f + D1[0], __builtin_fmaf(f.m[4 * r + 1], D1[1], f.m[4 * r + 2] * D1[2]));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++) { A3[r] = __builtin_fmaf(f.m[4 * r], du, C3[r] + col3[r]); B3[r] = f.m[4 * r]; }
+  }
+  return run1;
+}
+
+// Sample one run with the cheapest loop that is correct for it: the fill rule only matters where a tap can leave
+// the volume.  Each coordinate of the line is monotone, so a column whose two END planes keep all first taps in
+// [0, S - 2] is interior for the whole run; the wave takes the masked loop only if one of its columns is not.
+template <int GMAX>
+__device__ __forceinline__ void fast_sample_line(int len, const float (&A3)[3], const float (&B3)[3], const FastAddr& ta, char* o, unsigned urow,
+                                                 int64_t slab_b, bool needs_mask, float ox, float oy, float oz, float hx, float hy, float hz,
+                                                 float fillv) {
+  bool masked = false;
+  if (needs_mask) {
+    const float el = static_cast<float>(len - 1);
+    const float xa = A3[0] + ox, xb = __builtin_fmaf(el, B3[0], A3[0]) + ox;
+    const float ya = A3[1] + oy, yb = __builtin_fmaf(el, B3[1], A3[1]) + oy;
+    const float za = A3[2] + oz, zb = __builtin_fmaf(el, B3[2], A3[2]) + oz;
+    const bool inside = (fminf(xa, xb) >= 0.0f) & (fmaxf(xa, xb) < hx) & (fminf(ya, yb) >= 0.0f) & (fmaxf(ya, yb) < hy) &
+                        (fminf(za, zb) >= 0.0f) & (fmaxf(za, zb) < hz);
+    masked = __builtin_amdgcn_ballot_w64(!inside) != 0ull;
+  }
+  if (!masked) {
+    if (GMAX == 8 && len > 4) fast_sample_run<false, 8>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv);
+    else fast_sample_run<false, 4>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv);
+  } else {  // rare (waves on the volume's surface): four voxels in flight keep the register budget of the common loop
+    fast_sample_run<true, 4>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, ox, oy, oz, hx, hy, hz, fillv);
   }
 }
 
@@ -650,6 +748,231 @@ __global__ __launch_bounds__(TJ* TK* NPW, NPW == 1 ? 2 : 4) void resample_stream
       }
       stream_barrier();
     }
+  }
+}
+
+// =====================================================================================================================
+// The FAST brick kernel: the brick structure of resample_tile.hpp (independent 16^3 bricks, three resident blocks per
+// CU, the DMA in flight while the per-column constants are formed) with this file's lean arithmetic:
+//   * the box of the brick from <= 27 vertices evaluated by ONE wave (a DPP wave reduction, 7 ints through LDS, one
+//     barrier) instead of per-voxel min / max tracking and a block reduction;
+//   * no coordinate arrays: each column's coordinates are a line per control cell, 3 fma per voxel;
+//   * scalar-addressed LDS-DMA (stream_stage), 8 voxels of LDS reads in flight per lane, masked loop only in waves
+//     that really have a column leaving the volume.
+// =====================================================================================================================
+typedef FastFrameT<const float*> FastFrameG;
+
+template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK, int OCC>
+__global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_fastbrick_kernel(const ResampleArgs a) {
+  constexpr int NT = TJ * TK, NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* s_box = reinterpret_cast<int*>(smem);  // 7 raw extremes of the pass (wave 0 -> everybody)
+  float* s_tile = smem + 16;
+
+  const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned t1 = fastdiv(tile, a.magic_k, a.tiles_k);
+  const int kt = tile - t1 * a.tiles_k;
+  const unsigned t2 = fastdiv(t1, a.magic_j, a.tiles_j);
+  const int jt = t1 - t2 * a.tiles_j;
+  const unsigned t3 = fastdiv(t2, a.magic_i, a.tiles_i);
+  const int it = t2 - t3 * a.tiles_i;
+  const int b = t3;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tk = tid % TK, tj = tid / TK;
+  const int i_begin = it * TI, j_lo = jt * TJ, k_lo = kt * TK;
+  const int i_count = min(TI, a.Io - i_begin), nv = min(TJ, a.Jo - j_lo), nw = min(TK, a.Ko - k_lo);
+  const bool col_active = (tj < nv) & (tk < nw);
+  const int jv = min(tj, nv - 1), kw = min(tk, nw - 1);
+  const float fv = static_cast<float>(jv), fw = static_cast<float>(kw);
+  const int64_t n_in = static_cast<int64_t>(a.I) * a.J * a.K;
+  const int64_t n_out = static_cast<int64_t>(a.Io) * a.Jo * a.Ko;
+  const int slab = a.Jo * a.Ko;
+  const int64_t slab_b = static_cast<int64_t>(slab) * 4;
+  const int col_off = (j_lo + jv) * a.Ko + (k_lo + kw);
+  const unsigned urow = static_cast<unsigned>(col_off) * 4u;
+  const float hx = a.size_m1[0], hy = a.size_m1[1], hz = a.size_m1[2];
+
+  if (a.passthrough != nullptr && a.passthrough[b] != 0) {  // gated-out element: bit-exact copy
+    if (col_active) {
+      for (int im = 0; im < a.n_images; im++) {
+        const ImgArgs& g = a.img[im];
+        for (int c = 0; c < g.channels; c++) {
+          const int64_t off = (static_cast<int64_t>(b) * g.channels + c) * n_out + col_off;
+          for (int t = 0; t < i_count; t++)
+            static_cast<float*>(g.out)[off + static_cast<int64_t>(i_begin + t) * slab] = static_cast<const float*>(g.in)[off + static_cast<int64_t>(i_begin + t) * slab];
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- the frame of this brick's tile column ----
+  FastFrameG f;
+  const float ratio[3] = {a.half_h[0] / a.dh[0], a.half_h[1] / a.dh[1], a.half_h[2] / a.dh[2]};  // (S_own - 1) / max(S_norm - 1, 1)
+  bool weird = false;
+  {
+    const float* m = a.mapping + (a.mapping_batched ? b * 12 : 0);
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+      const float mv = m[q];
+      weird |= (__float_as_uint(mv) & 0x7FFFFFFFu) > 0x7149F2CAu;
+      f.m[q] = mv * ratio[q >> 2];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    f.c[r] = static_cast<double>(f.m[4 * r + 1]) * j_lo + static_cast<double>(f.m[4 * r + 2]) * k_lo + static_cast<double>(f.m[4 * r + 3]);
+  f.j_lo = j_lo; f.k_lo = k_lo;
+  f.affine_first = a.affine_first != 0;
+  f.ni = a.ni; f.nj = a.nj; f.nk = a.nk; f.sci = a.scale_i; f.scj = a.scale_j; f.sck = a.scale_k;
+  f.cp = nullptr;
+  f.elastic = false;
+#pragma unroll
+  for (int e = 0; e < 3; e++) f.dsc[e] = a.rsp[e] * (f.affine_first ? ratio[e] : 1.0f);
+  Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
+  if constexpr (ELASTIC_POSSIBLE) {
+    f.elastic = !(a.cp_skip != nullptr && a.cp_skip[b] != 0);
+    if (f.elastic) {
+      f.cp = a.cp + (a.cp_batched ? static_cast<int64_t>(b) * (a.ni * a.nj * a.nk * 3) : 0);
+      lj = lerp_index(j_lo + jv, a.nj, a.Jo, a.scale_j);
+      lk = lerp_index(k_lo + kw, a.nk, a.Ko, a.scale_k);
+    }
+  }
+  float col3[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) col3[r] = __builtin_fmaf(f.m[4 * r + 1], fv, f.m[4 * r + 2] * fw);
+  const int n_vert = f.elastic ? 27 : 8;
+  const unsigned tile_lds_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile));
+  StageLanes sl;
+  sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
+  ColumnPlanes planes;
+  planes.cell = -2;
+#pragma unroll
+  for (int e = 0; e < 3; e++) { planes.P0[e] = 0.0f; planes.P1[e] = 0.0f; }
+
+  // ---- passes over the planes: the largest leading range whose box fits the LDS budget ----
+  int u0 = i_begin;
+  const int u_end = i_begin + i_count;
+  bool first_barrier = true;
+  while (u0 < u_end) {
+    int n = u_end - u0;
+    StreamBox bx{};
+    bool fits = false, wrd = false;
+    for (;;) {
+      if (!first_barrier) __syncthreads();  // s_box (and the brick area) are free again
+      first_barrier = false;
+      if (wave == 0) {  // one vertex of (planes x control cells) per lane, extremes by a DPP wave reduction
+        const int vtx = lane < n_vert ? lane : 0;
+        const int u_lo = u0, u_hi = u0 + n - 1;
+        int du, dv, dw;
+        if (f.elastic) { du = vtx % 3; dv = (vtx / 3) % 3; dw = vtx / 9; } else { du = vtx & 1; dv = (vtx >> 1) & 1; dw = vtx >> 2; }
+        bool dense = false;
+        float u = du == 0 ? static_cast<float>(u_lo) : static_cast<float>(u_hi);
+        float v = dv == 0 ? 0.0f : static_cast<float>(nv - 1);
+        float w = dw == 0 ? 0.0f : static_cast<float>(nw - 1);
+        if (f.elastic) {
+          if (du == 2) u = fast_breakpoint(f.sci, f.ni, u_lo, u_hi, dense);
+          if (dv == 2) v = fast_breakpoint(f.scj, f.nj, j_lo, j_lo + nv - 1, dense) - static_cast<float>(j_lo);
+          if (dw == 2) w = fast_breakpoint(f.sck, f.nk, k_lo, k_lo + nw - 1, dense) - static_cast<float>(k_lo);
+        }
+        float x, y, z;
+        fast_coord(f, u, v, w, x, y, z);
+        constexpr float kMargin = 1.0f / 64.0f;  // the per-voxel lines differ from these vertex values by rounding only
+        const bool bad = !(fabsf(x) <= 1e30f) | !(fabsf(y) <= 1e30f) | !(fabsf(z) <= 1e30f) | dense;
+        const float capx = hx + 1.0f + kTileFar, capy = hy + 1.0f + kTileFar, capz = hz + 1.0f + kTileFar;
+        int r[7];
+        r[0] = -static_cast<int>(fminf(fmaxf(floorf(x - kMargin), -kTileFar), capx));
+        r[1] = static_cast<int>(fminf(fmaxf(floorf(x + kMargin), -kTileFar), capx));
+        r[2] = -static_cast<int>(fminf(fmaxf(floorf(y - kMargin), -kTileFar), capy));
+        r[3] = static_cast<int>(fminf(fmaxf(floorf(y + kMargin), -kTileFar), capy));
+        r[4] = -static_cast<int>(fminf(fmaxf(floorf(z - kMargin), -kTileFar), capz));
+        r[5] = static_cast<int>(fminf(fmaxf(floorf(z + kMargin), -kTileFar), capz));
+        r[6] = bad ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 7; q++) r[q] = wave_max_i32(r[q]);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 7; q++) s_box[q] = r[q];
+        }
+      }
+      __syncthreads();
+      const int xmin = -__builtin_amdgcn_readfirstlane(s_box[0]), xmax = __builtin_amdgcn_readfirstlane(s_box[1]);
+      const int ymin = -__builtin_amdgcn_readfirstlane(s_box[2]), ymax = __builtin_amdgcn_readfirstlane(s_box[3]);
+      const int zmin = -__builtin_amdgcn_readfirstlane(s_box[4]), zmax = __builtin_amdgcn_readfirstlane(s_box[5]);
+      wrd = weird | (__builtin_amdgcn_readfirstlane(s_box[6]) != 0);
+      bx.interior = (xmin >= 0) & (xmax + 1 <= a.I - 1) & (ymin >= 0) & (ymax + 1 <= a.J - 1) & (zmin >= 0) & (zmax + 1 <= a.K - 1) & !wrd;
+      const int outside = ((xmax + 1 < 0) | (xmin > a.I - 1) | (ymax + 1 < 0) | (ymin > a.J - 1) | (zmax + 1 < 0) | (zmin > a.K - 1)) & !wrd;
+      bx.bx0 = xmin; bx.by0 = ymin; bx.za = zmin & ~3;
+      bx.Lx = xmax + 2 - xmin; bx.Ly = ymax + 2 - ymin;
+      const int Lz = ((zmax + 1 + 4) & ~3) - bx.za;
+      bx.cpr = Lz >> 2;
+      fits = !wrd && (Lz <= 256) && (bx.Lx <= 4096) && (bx.Ly <= 4096) && (static_cast<int64_t>(bx.Lx) * bx.Ly * Lz <= static_cast<int64_t>(a.tile_cap));
+      bx.kind = outside ? kSlabOutside : (fits ? kSlabStaged : kSlabGather);
+      if (fits | (outside != 0) | wrd | (n <= 1)) break;
+      n = (n + 1) >> 1;
+    }
+    const int u1 = u0 + n;
+
+    for (int im = 0; im < a.n_images; im++) {
+      const ImgArgs& g = a.img[im];
+      typedef __attribute__((address_space(4))) const float* const_float_ptr;
+      for (int c = 0; c < g.channels; c++) {
+        const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
+        const bool has_fill = g.fill != nullptr;
+        const float fillv = has_fill ? ((const_float_ptr)g.fill)[c] : 0.0f;
+        char* out_chan = static_cast<char*>(g.out) + bc * n_out * 4;
+        const float* in_chan = static_cast<const float*>(g.in) + bc * n_in;
+        if (bx.kind == kSlabOutside) {
+          if (col_active)
+            for (int t = u0; t < u1; t++) *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = fillv;
+          continue;
+        }
+        if (bx.kind == kSlabGather) {  // rare: full per-voxel evaluation, per-tap bounds, global gathers
+          if (col_active) {
+            ImgArgs g1 = g;
+            g1.in = in_chan; g1.out = out_chan; g1.channels = 1; g1.fill = has_fill ? g.fill + c : nullptr;
+            for (int t = u0; t < u1; t++) {
+              float x, y, z;
+              fast_coord(f, static_cast<float>(t), fv, fw, x, y, z);
+              gather_voxel<0>(g1, a, 0, n_in, n_out, t * slab + col_off, x, y, z, false);
+            }
+          }
+          continue;
+        }
+        if (im + c > 0) __syncthreads();  // the previous channel's taps are read
+        if (!(a.ablate & 1)) stream_stage<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+        // while the brick is on its way: the first line of this column
+        float C3[3];
+        {
+          const double org[3] = {static_cast<double>(bx.bx0), static_cast<double>(bx.by0), static_cast<double>(bx.za)};
+#pragma unroll
+          for (int r = 0; r < 3; r++) C3[r] = static_cast<float>(static_cast<double>(f.m[4 * r]) * u0 + f.c[r] - org[r]);
+        }
+        float A3[3], B3[3];
+        int run0 = u0;
+        int run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3);
+        FastAddr ta;
+        ta.sYb = bx.cpr * 16; ta.sXb = bx.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
+        ta.sYf = static_cast<float>(ta.sYb); ta.sXf = static_cast<float>(ta.sXb);
+        ta.base_f = static_cast<float>(tile_lds_addr);
+        const float ox = static_cast<float>(bx.bx0), oy = static_cast<float>(bx.by0), oz = static_cast<float>(bx.za);
+        tile_dma_wait();
+        __syncthreads();
+        if (col_active && !(a.ablate & 2)) {
+          for (;;) {
+            fast_sample_line<4>(run1 - run0, A3, B3, ta, out_chan + static_cast<int64_t>(run0) * slab_b, urow, slab_b, has_fill & !bx.interior, ox, oy,
+                                oz, hx, hy, hz, fillv);
+            run0 = run1;
+            if (run0 >= u1) break;
+            run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3);
+          }
+        }
+      }
+    }
+    u0 = u1;
   }
 }
 
