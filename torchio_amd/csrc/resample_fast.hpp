@@ -30,6 +30,8 @@
 //      the lean arithmetic: 0.436 ms, the same as the product path (0.437): set-up 0.146 + DMA 0.10 + sampling 0.17,
 //      which ADD UP: with three blocks per CU the throughput is 3 / (latency of one brick), and the latency chain
 //      kernarg -> mapping -> box -> barrier -> DMA -> barrier -> sampling is what is left once the ALU work is gone.
+//   3. (removed after measurement) persistent bricks with a helper wave preparing the next pass's descriptor in LDS:
+//      0.47 - 0.54 ms — the helper's ~1.3 us (affine) / ~3.4 us (elastic) of single-wave work per pass became the chain.
 // Neither beats the product path, so neither is the default; they stay as the reproducible A/B behind those numbers
 // (tests/native/resample_bench --path fast) and as the starting point for the next attempt.
 #pragma once
