@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 5
+#define TIO_ABI_VERSION 6
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -72,7 +72,16 @@ typedef enum tio_interp {
    * maximum = smallest label); the voxel is in bounds when the float32 sum over the
    * channels (torch.sum's cascade over the sorted label table) exceeds 0.5, else it
    * receives the pad label.                                                       */
-  TIO_LABEL_PV = 2
+  TIO_LABEL_PV = 2,
+  /* The ADJOINT of TIO_LINEAR — the backward pass of the trilinear resampling with respect to the image
+   * (what autograd derives from grid_sample in the reference, whose transforms are differentiable:
+   * tests/test_noise.py:75-80, docs/concepts/transforms.md:289-299).  For such an image the roles of the two
+   * buffers are swapped: `out` is READ, (B, C, Io, Jo, Ko) float32 = dL/d(output); `in` is ACCUMULATED INTO
+   * (despite the const), (B, C, I, J, K) float32, zero-initialised by the caller: every output voxel adds
+   * g * w_t to its in-bounds taps (hardware float atomics: the order of the additions is not defined).  A
+   * non-NULL fill_dev means the forward pass used a fill value: voxels whose in-bounds weight is <= 0.5 took the
+   * fill and carry no gradient.  Same geometry struct, same coordinate arithmetic as the forward launch.     */
+  TIO_LINEAR_ADJOINT = 3
 } tio_interp;
 
 /* ------------------------------------------------------------------------ */

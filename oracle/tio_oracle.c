@@ -441,6 +441,18 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
               const int64_t base_in = ((int64_t)b * img->channels + c) * n_in;
               const int64_t base_out = ((int64_t)b * img->channels + c) * n_out;
               float val;
+              if (img->interp == TIO_LINEAR_ADJOINT) { /* backward of TIO_LINEAR: d(val)/d(in[tap]) = w[tap] */
+                if (img->fill_dev && !(mask > 0.5f)) continue; /* the fill was taken: no gradient */
+                const float gv = ((const float*)img->out)[base_out + o_idx];
+                float* acc = (float*)img->in + base_in;
+                for (int t = 0; t < 8; t++) {
+                  if (!ok[t]) continue;
+                  const float add = gv * w[t];
+#pragma omp atomic
+                  acc[off[t]] += add;
+                }
+                continue;
+              }
               if (img->interp == TIO_LINEAR) {
                 val = 0.0f;
                 for (int t = 0; t < 8; t++)

@@ -102,21 +102,32 @@ def test_cpu_tensors_fall_back_to_the_reference_when_only_the_hip_engine_exists(
         assert torch.equal(expected[name].data, actual[name].data), name
 
 
-def test_tensors_that_require_grad_stay_on_the_reference(bound, oracle):
-    """reference tests/test_noise.py:75-80: the transforms are differentiable; the engine ops are not, so such
-    inputs never reach them."""
+def test_tensors_that_require_grad_backpropagate_through_the_engine(bound, oracle):
+    """reference tests/test_noise.py:75-80: the transforms are differentiable.  Bound to the engine they still are, and
+    the gradient is the one autograd derives through the unmodified reference."""
+    from torchio_amd import reference_binding
+
     tio = bound
+
+    def run():
+        leaf = (torch.rand(1, 12, 12, 12, generator=torch.Generator().manual_seed(1)) + 0.2).requires_grad_(True)
+        torch.manual_seed(2)
+        out = tio.Compose([tio.Affine(degrees=5), tio.Blur(std=1.0), tio.Noise(std=0.1), tio.Gamma(log_gamma=0.2)])(tio.Subject(t1=tio.ScalarImage(leaf)))
+        (out["t1"].data ** 2).sum().backward()
+        return leaf.grad
+
     calls = []
     original_call = oracle._call
     oracle._call = lambda name, *args: (calls.append(name), original_call(name, *args))[1]
     try:
         with use_engine(oracle):
-            subject = tio.Subject(t1=tio.ScalarImage(torch.rand(1, 12, 12, 12).requires_grad_(True)))
-            out = tio.Compose([tio.Affine(degrees=5), tio.Blur(std=1.0), tio.Noise(std=0.1), tio.Gamma(log_gamma=0.2)])(subject)
-            out["t1"].data.sum().backward()
+            through_engine = run()
     finally:
         oracle._call = original_call
-    assert calls == [] and out["t1"].data.requires_grad
+    assert {"resample3d", "separable_conv3d", "add_noise", "gamma_pow"} <= set(calls)
+    reference_binding.unbind()
+    expected = run()
+    assert (expected - through_engine).abs().max().item() <= 1e-4 * expected.abs().max().item()
 
 
 def test_the_references_own_test_files_pass_through_the_binding():

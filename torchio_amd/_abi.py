@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_IMAGES = 8
 
 # tio_status
@@ -18,7 +18,7 @@ UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing
 # tio_dtype (values fixed by include/tio_hip.h)
 F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
 # tio_interp
-NEAREST, LINEAR, LABEL_PV = 0, 1, 2
+NEAREST, LINEAR, LABEL_PV, LINEAR_ADJOINT = 0, 1, 2, 3
 # tio_pad_mode
 PAD_CONSTANT, PAD_REFLECT, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2, 3
 # tio_precision

@@ -132,6 +132,17 @@ __device__ __forceinline__ void sample_interior(const ImgArgs& g, int b, int64_t
     const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
     const typename Elem<DT>::type* p = static_cast<const typename Elem<DT>::type*>(g.in) + bc * n_in;
     float val;
+    if (g.interp == TIO_LINEAR_ADJOINT) {  // backward of TIO_LINEAR: scatter g * w to the 8 taps (all in bounds here)
+      if constexpr (DT == TIO_F32) {
+        const float gv = static_cast<const float*>(g.out)[bc * n_out + o_idx];
+        float* q = const_cast<float*>(static_cast<const float*>(g.in)) + bc * n_in + base;
+        unsafeAtomicAdd(q, gv * w[0]); unsafeAtomicAdd(q + dJK, gv * w[1]);
+        unsafeAtomicAdd(q + dK, gv * w[2]); unsafeAtomicAdd(q + dJK + dK, gv * w[3]);
+        unsafeAtomicAdd(q + 1, gv * w[4]); unsafeAtomicAdd(q + dJK + 1, gv * w[5]);
+        unsafeAtomicAdd(q + dK + 1, gv * w[6]); unsafeAtomicAdd(q + dJK + dK + 1, gv * w[7]);
+      }
+      continue;
+    }
     if (g.interp == TIO_LINEAR) {
       const typename Elem<DT>::type* q = p + base;
       const float v0 = Elem<DT>::load(q, 0), v1 = Elem<DT>::load(q, dJK);
@@ -163,6 +174,18 @@ __device__ __forceinline__ void sample_boundary(const ImgArgs& g, int b, int64_t
     const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
     const typename Elem<DT>::type* p = static_cast<const typename Elem<DT>::type*>(g.in) + bc * n_in;
     float val;
+    if (g.interp == TIO_LINEAR_ADJOINT) {  // backward of TIO_LINEAR with per-tap bounds; no gradient where the fill was taken
+      if constexpr (DT == TIO_F32) {
+        if (g.fill == nullptr || mask > 0.5f) {
+          const float gv = static_cast<const float*>(g.out)[bc * n_out + o_idx];
+          float* q = const_cast<float*>(static_cast<const float*>(g.in)) + bc * n_in;
+#pragma unroll
+          for (int k = 0; k < 8; k++)
+            if ((okbits >> k) & 1u) unsafeAtomicAdd(q + off[k], gv * w[k]);
+        }
+      }
+      continue;
+    }
     if (g.interp == TIO_LINEAR) {
       val = 0.0f;
 #pragma unroll
@@ -492,13 +515,18 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
   pv.n_images = 0;
   pv.any_linear = 1;
   int dtmode = 0;
+  bool any_adjoint = false;
   for (int i = 0; i < n_images; i++) {
     const tio_resample_image& s = images[i];
     if (s.in == nullptr || s.out == nullptr || s.channels < 1)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d has null data or no channels", i);
     if (dtype_size(s.dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d dtype %d", i, s.dtype);
-    if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR && s.interp != TIO_LABEL_PV)
+    if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR && s.interp != TIO_LABEL_PV && s.interp != TIO_LINEAR_ADJOINT)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d interp %d", i, s.interp);
+    if (s.interp == TIO_LINEAR_ADJOINT) {
+      if (s.dtype != TIO_F32) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d: the adjoint works on float32 gradients", i);
+      any_adjoint = true;
+    }
     if (s.interp == TIO_LABEL_PV) {
       if (s.channels != 1)
         return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d: TIO_LABEL_PV needs channels == 1, got %d", i, s.channels);
@@ -509,7 +537,7 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     }
     a.img[a.n_images++] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp, nullptr, 0, 0.0};
     // the in-bounds weight mask needs the trilinear weights even for nearest data (spatial.py:1722-1727)
-    if (s.interp == TIO_LINEAR || s.fill_dev != nullptr) a.any_linear = 1;
+    if (s.interp == TIO_LINEAR || s.interp == TIO_LINEAR_ADJOINT || s.fill_dev != nullptr) a.any_linear = 1;
     if (s.interp == TIO_NEAREST) a.any_nearest = 1;
     const int need = s.dtype == TIO_F32 ? 0 : ((s.dtype == TIO_I16 || s.dtype == TIO_U8 || s.dtype == TIO_I32) ? 1 : 2);
     dtmode = need > dtmode ? need : dtmode;
@@ -537,11 +565,12 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
   // Path: LDS-staged bricks whenever a trilinear image is present (the 8-tap gather is
   // what the staging removes); pure nearest launches keep the one-load gather kernel.
   // TIO_RESAMPLE_PATH=gather|tile overrides (A/B tests compare the two bit for bit).
-  bool use_tile = a.any_linear != 0;
+  bool use_tile = a.any_linear != 0 && !any_adjoint;  // the adjoint scatters to global memory: gather kernel
   if (const char* env = getenv("TIO_RESAMPLE_PATH")) {
     if (strcmp(env, "gather") == 0) use_tile = false;
     if (strcmp(env, "tile") == 0) use_tile = true;
   }
+  if (any_adjoint) use_tile = false;
   if (static_cast<int64_t>(a.Jo) * a.Ko * 8 >= (1LL << 31)) use_tile = false;  // 32-bit byte offsets inside one output plane
   if (n_in >= (1LL << 30)) use_tile = false;  // 32-bit byte offsets inside one input channel (f32 brick DMA)
   if (use_tile) {

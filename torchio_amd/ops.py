@@ -29,7 +29,7 @@ _DTYPE_CODES = {
     torch.int64: _abi.I64,
 }
 FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
-INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR, "label": _abi.LABEL_PV}
+INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR, "label": _abi.LABEL_PV, "linear_adjoint": _abi.LINEAR_ADJOINT}
 
 
 PRECISION_CODES = {"exact": _abi.PRECISION_EXACT, "fast": _abi.PRECISION_FAST}
@@ -90,8 +90,91 @@ def _i32x3(values) -> C.Array:
     return (C.c_int32 * 3)(*[int(v) for v in values])
 
 
+class _AttachBackward(torch.autograd.Function):
+    """Give an engine result its place in the autograd graph: ``result`` was computed by a kernel from
+    ``source.detach()``; ``backward_fn(grad)`` returns dL/d(source) (another kernel, or tensor algebra)."""
+
+    @staticmethod
+    def forward(ctx, source, result, backward_fn):
+        ctx.backward_fn = backward_fn
+        return result.view_as(result)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ctx.backward_fn(grad.contiguous()), None, None
+
+
+class _PadConstantFn(torch.autograd.Function):
+    """Constant padding (one value, or one per batch element for the statistic modes) with its two gradients: the
+    interior of the incoming gradient for the data, the sum over the border for each element's fill value."""
+
+    @staticmethod
+    def forward(ctx, data, fill_per_element, engine, padding, fill):
+        ctx.padding, ctx.in_shape, ctx.has_fills = padding, data.shape, fill_per_element is not None
+        ctx.fill_dtype = None if fill_per_element is None else fill_per_element.dtype
+        ctx.fill_shape = None if fill_per_element is None else fill_per_element.shape
+        fills = None if fill_per_element is None else fill_per_element.detach()
+        return engine.pad3d(data.detach(), padding, "constant", fill, fills)
+
+    @staticmethod
+    def backward(ctx, grad):
+        p, (_, _, si, sj, sk) = ctx.padding, ctx.in_shape
+        inner = grad[:, :, p[0] : p[0] + si, p[2] : p[2] + sj, p[4] : p[4] + sk]
+        grad_fill = None
+        if ctx.has_fills:
+            border = grad.sum(dim=(1, 2, 3, 4)) - inner.sum(dim=(1, 2, 3, 4))
+            grad_fill = border.to(ctx.fill_dtype).reshape(ctx.fill_shape)
+        return inner.contiguous(), grad_fill, None, None, None
+
+
+def _stencil_adjoint(data: Tensor, taps: Tensor, radius, skip: Tensor | None, grad: Tensor) -> Tensor:
+    """Backward of the replicate-padded separable correlation: autograd through its ATen restatement
+    (``F.pad(mode="replicate")`` + grouped ``conv3d`` per axis, reference blur.py:157-252).  The one backward that is
+    not a kernel of this library: the transpose of a CLAMPED stencil folds the border taps back onto the edge
+    voxels, and nobody trains through a Gaussian blur on the hot path."""
+    import torch.nn.functional as F  # noqa: PLC0415
+
+    batch, channels = data.shape[:2]
+    with torch.enable_grad():
+        leaf = data.float().requires_grad_(True)
+        work = leaf
+        for axis in range(3):
+            r = int(radius[axis])
+            if r <= 0:
+                continue
+            pad = [0, 0, 0, 0, 0, 0]
+            pad[2 * (2 - axis)] = pad[2 * (2 - axis) + 1] = r
+            padded = F.pad(work, pad, mode="replicate")
+            kernel = taps[:, axis, : 2 * r + 1].to(leaf.device, torch.float32)
+            shape = [1, 1, 1]
+            shape[axis] = 2 * r + 1
+            if kernel.shape[0] == 1:
+                weight = kernel.reshape(1, 1, *shape).expand(channels, 1, *shape)
+                work = F.conv3d(padded, weight, groups=channels)
+            else:  # per-element kernels: fold the batch into the channel groups
+                weight = kernel.reshape(batch, 1, 1, *shape).expand(batch, channels, 1, *shape).reshape(batch * channels, 1, *shape)
+                work = F.conv3d(padded.reshape(1, batch * channels, *padded.shape[2:]), weight, groups=batch * channels).reshape(batch, channels, *work.shape[2:])
+        if skip is not None:
+            rows = skip.to(leaf.device).bool().reshape(-1, 1, 1, 1, 1)
+            work = torch.where(rows, leaf, work)
+        (result,) = torch.autograd.grad(work, leaf, grad.float())
+    return result.to(data.dtype)
+
+
+def _wants_grad(tensor: Tensor | None) -> bool:
+    return tensor is not None and torch.is_grad_enabled() and tensor.requires_grad
+
+
 class Engine:
-    """One loaded implementation of the C ABI bound to one device type."""
+    """One loaded implementation of the C ABI bound to one device type.
+
+    Autograd: the reference's transforms are differentiable with respect to the image data (they are compositions
+    of torch ops).  Here every op that has a derivative takes inputs that require grad, runs its kernel on the
+    detached data and attaches a backward: the adjoint scatter kernel for trilinear resampling
+    (``TIO_LINEAR_ADJOINT``), the same multiply for the bias field, the flip for the flip, closed-form tensor algebra
+    for gamma / noise, and — the one exception — the ATen restatement of the padded correlation for the stencil.
+    Parameters (mapping, control points, sigmas ...) are plain numbers in the reference too and get no gradient.
+    """
 
     def __init__(self, functions: dict, device_type: str, name: str):
         self._fn = functions
@@ -111,9 +194,9 @@ class Engine:
                 )
             if t.requires_grad:
                 raise EngineError(
-                    f"{what}: tensors that require grad are not supported by the {self.name} engine (its ops are not differentiable)"
-                    " — detach them, or use `torchio` with `torchio_amd.reference_binding.bind()`, which leaves autograd inputs"
-                    " to the reference's differentiable path"
+                    f"{what}: this {self.name} engine op has no backward (differentiable: trilinear resampling, bias field, blur,"
+                    " noise, gamma, flip) — detach the tensor, or use `torchio` with `torchio_amd.reference_binding.bind()`,"
+                    " which leaves autograd inputs to the reference's own path"
                 )
 
     def _stream(self, ref: Tensor):
@@ -160,6 +243,7 @@ class Engine:
         pad_labels: Sequence[float] | None = None,
         norm_shape: Sequence[int] | None = None,
         precision: str | None = None,
+        _adjoint_of: Sequence[Tensor] | None = None,
     ) -> list[Tensor]:
         """Resample every ``(B, C, I, J, K)`` tensor in *images* through one coordinate pass.
 
@@ -212,6 +296,19 @@ class Engine:
         geom.precision = PRECISION_CODES[precision if precision is not None else _RESAMPLE_PRECISION]
         self._check("resample3d", mapping, control_points, cp_skip, passthrough)
 
+        # images that take part in autograd (float, trilinear): the kernel sees the detached data, the result gets
+        # the adjoint launch as its backward
+        sources = list(images)
+        wants = [
+            _adjoint_of is None and _wants_grad(t) and t.dtype in FLOAT_DTYPES
+            and (INTERP_CODES[interps[n]] if isinstance(interps[n], str) else int(interps[n])) == _abi.LINEAR
+            for n, t in enumerate(images)
+        ]
+        images = [t.detach() if (_adjoint_of is None and t.requires_grad) else t for t in images]
+        for n, t in enumerate(sources):
+            if _adjoint_of is None and _wants_grad(t) and not wants[n]:
+                raise EngineError("resample3d: only floating-point images resampled trilinearly are differentiable")
+
         outputs: list[Tensor] = []
         for start in range(0, len(images), _abi.MAX_IMAGES):
             chunk = range(start, min(start + _abi.MAX_IMAGES, len(images)))
@@ -227,7 +324,12 @@ class Engine:
                     if fill.numel() != data.shape[1]:
                         raise ValueError("fill must have one value per channel")
                 self._check("resample3d", data, fill)
-                out = torch.empty((batch, data.shape[1], *out_shape), dtype=data.dtype, device=data.device)
+                if _adjoint_of is not None:  # `data` is the zeroed accumulator, `out` the incoming gradient (read)
+                    out = _adjoint_of[n].to(torch.float32).contiguous()
+                    if tuple(out.shape) != (batch, data.shape[1], *out_shape):
+                        raise ValueError("gradient shape does not match the forward output")
+                else:
+                    out = torch.empty((batch, data.shape[1], *out_shape), dtype=data.dtype, device=data.device)
                 interp = interps[n]
                 descs[slot].in_ = data.data_ptr()
                 descs[slot].out = out.data_ptr()
@@ -248,10 +350,30 @@ class Engine:
                 outputs.append(out)
             self._call("resample3d", first, C.byref(geom), len(chunk), descs, self._stream(first))
         del keep_alive
+        if _adjoint_of is not None:
+            return [t for t in images]  # the accumulators now hold dL/d(input)
+        if any(wants):
+            shared = dict(
+                out_shape=out_shape, mapping=mapping, control_points=control_points, in_spacing=tuple(in_spacing),
+                out_spacing=tuple(out_spacing), affine_first=affine_first, cp_skip=cp_skip, passthrough=passthrough,
+                norm_shape=norm_shape, precision="exact",
+            )
+            for n, want in enumerate(wants):
+                if not want:
+                    continue
+                source, fill = sources[n], fills[n]
+
+                def backward(grad, source=source, fill=fill):
+                    accumulator = torch.zeros(source.shape, dtype=torch.float32, device=source.device)
+                    self.resample3d([accumulator], interps=["linear_adjoint"], fills=[fill], _adjoint_of=[grad], **shared)
+                    return accumulator.to(source.dtype)
+
+                outputs[n] = _AttachBackward.apply(source, outputs[n], backward)
         return outputs
 
     def channel_min(self, data: Tensor) -> Tensor:
         """Per-channel minimum of the first batch element as a ``(C,)`` float32 device tensor."""
+        data = data.detach()  # a fill VALUE (the reference takes `.item()`): no gradient flows through it
         self._check("channel_min", data)
         first = data[0].contiguous()
         channels = first.shape[0]
@@ -271,6 +393,10 @@ class Engine:
             raise ValueError("expected a (B, C, I, J, K) tensor")
         if data.dtype not in FLOAT_DTYPES:
             raise TypeError(f"separable_conv3d needs a floating dtype, got {data.dtype}")
+        if _wants_grad(data):
+            detached = data.detach()
+            result = self.separable_conv3d(detached, taps, radius, skip=skip)
+            return _AttachBackward.apply(data, result, lambda grad: _stencil_adjoint(detached, taps, radius, skip, grad))
         batch, channels = data.shape[:2]
         data = data.contiguous()
         taps = taps.to(torch.float32).contiguous()
@@ -351,6 +477,9 @@ class Engine:
             raise ValueError("data and coarse must be 5-D with the same (B, C)")
         if data.dtype not in FLOAT_DTYPES:
             raise TypeError(f"bias_field_apply needs a floating dtype, got {data.dtype}")
+        if _wants_grad(data):  # y = x * f (or x / f): the gradient is the same multiply applied to the incoming gradient
+            result = self.bias_field_apply(data.detach(), coarse, divide=divide, skip=skip)
+            return _AttachBackward.apply(data, result, lambda grad: self.bias_field_apply(grad.to(data.dtype), coarse, divide=divide, skip=skip))
         data = data.contiguous()
         coarse = coarse.to(torch.float32).contiguous()
         skip = self._flags(skip, data.shape[0], "skip")
@@ -378,6 +507,26 @@ class Engine:
         """``data + (mean + std * z)``; ``z`` from *base1*/*base2* or in-kernel Philox when ``None``."""
         if data.dtype not in FLOAT_DTYPES:
             raise TypeError(f"add_noise needs a floating dtype, got {data.dtype}")
+        if _wants_grad(data):
+            detached = data.detach()
+            result = self.add_noise(detached, mean, std, rician=rician, base1=base1, base2=base2, philox_seed=philox_seed, keep=keep)
+            if not rician:  # additive: dy/dx = 1 (gated-out rows are copies: 1 as well)
+                return _AttachBackward.apply(data, result, lambda grad: grad)
+
+            def rician_backward(grad):
+                # y = sqrt((x + n1)^2 + n2^2): dy/dx = (x + n1) / y, with n1 the FIRST draw of the forward pass
+                draws = base1 if base1 is not None else self.philox_normal(detached.shape, philox_seed, 0, detached.device)
+                shape = (-1,) + (1,) * (detached.ndim - 1)
+                mean_b = mean.to(detached.device).reshape(shape) if isinstance(mean, Tensor) else mean
+                std_b = std.to(detached.device).reshape(shape) if isinstance(std, Tensor) else std
+                numerator = detached.float() + (mean_b + std_b * draws)
+                slope = torch.where(result != 0, numerator / result.float(), torch.zeros_like(numerator))
+                if keep is not None:  # gated-out rows are exact copies of the input
+                    rows = keep.to(detached.device).bool().reshape(shape)
+                    slope = torch.where(rows, slope, torch.ones_like(slope))
+                return (grad.float() * slope).to(data.dtype)
+
+            return _AttachBackward.apply(data, result, rician_backward)
         data = data.contiguous()
         batch = data.shape[0]
         batched = isinstance(mean, Tensor) or isinstance(std, Tensor)
@@ -416,6 +565,15 @@ class Engine:
         """``sign(data) * |data| ** gamma`` with a scalar or per-element ``(B,)`` exponent."""
         if data.dtype not in FLOAT_DTYPES:
             raise TypeError(f"gamma_pow needs a floating dtype, got {data.dtype}")
+        if _wants_grad(data):  # y = sign(x) |x|^g: dy/dx = g |x|^(g - 1)
+            detached = data.detach()
+            result = self.gamma_pow(detached, gamma)
+
+            def backward(grad):
+                exponent = gamma.to(detached.device, torch.float32).reshape((-1,) + (1,) * (detached.ndim - 1)) if isinstance(gamma, Tensor) else float(gamma)
+                return (grad.float() * exponent * detached.float().abs().pow(exponent - 1)).to(data.dtype)
+
+            return _AttachBackward.apply(data, result, backward)
         data = data.contiguous()
         batch = data.shape[0]
         gamma_t = None
@@ -478,6 +636,9 @@ class Engine:
         """``torch.flip`` along spatial ``axes`` (0..2), or per element with a ``(B, 3)`` flag tensor."""
         if data.ndim != 5:
             raise ValueError(f"expected a (B, C, I, J, K) tensor, got {tuple(data.shape)}")
+        if _wants_grad(data):  # a permutation: its transpose is itself
+            result = self.flip3d(data.detach(), axes, per_element)
+            return _AttachBackward.apply(data, result, lambda grad: self.flip3d(grad, axes, per_element))
         data = data.contiguous()
         mask = 0
         for axis in axes or ():
@@ -504,6 +665,10 @@ class Engine:
         if data.ndim != 5:
             raise ValueError(f"expected a (B, C, I, J, K) tensor, got {tuple(data.shape)}")
         code = {"constant": _abi.PAD_CONSTANT, "reflect": _abi.PAD_REFLECT, "replicate": _abi.PAD_REPLICATE, "circular": _abi.PAD_CIRCULAR}[mode]
+        if _wants_grad(data) or _wants_grad(fill_per_element):
+            if mode != "constant":
+                raise EngineError(f"pad3d: mode {mode!r} has no backward in the {self.name} engine (constant / statistic padding does)")
+            return _PadConstantFn.apply(data, fill_per_element, self, [int(p) for p in padding], float(fill))
         data = data.contiguous()
         padding = [int(p) for p in padding]
         if len(padding) != 6:

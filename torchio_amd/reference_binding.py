@@ -14,9 +14,11 @@ Five seams are replaced:
     S5  Gamma / _GammaInverse .apply_transform                        -> tio_gamma_pow
 
 Every replacement keeps the reference's original as the FALLBACK for what the engine does not take — CPU tensors
-(the engine only reads device memory), tensors that require grad (the engine ops are not differentiable),
-interpolation orders >= 2 (torch-interpol) — so ``tio.Affine()(cpu_subject)``, the reference's normal use, keeps
-working exactly as before.  The replacements are this package's own seam functions called with the REFERENCE's
+(the engine only reads device memory), autograd through an op that has no backward here (nearest-neighbour
+resampling of a tensor that requires grad ...), interpolation orders >= 2 (torch-interpol) — so
+``tio.Affine()(cpu_subject)``, the reference's normal use, keeps working exactly as before.  Inputs that require
+grad run on the engine like any other: trilinear resampling, bias field, blur, noise, gamma and flip have backward
+passes (``ops.Engine``).  The replacements are this package's own seam functions called with the REFERENCE's
 objects: containers, parameter dictionaries and helper methods are name-compatible by construction.
 """
 from __future__ import annotations
@@ -30,19 +32,12 @@ from . import ops
 _ORIGINALS: dict[tuple[Any, str], Any] = {}
 
 
-def _wants_reference(tensors) -> bool:
-    """Inputs the engine must not touch: autograd is live on them."""
-    return any(getattr(t, "requires_grad", False) for t in tensors)
-
-
 def _with_fallback(ours, original, tensors_of):
     @functools.wraps(original)
     def seam(*args, **kwargs):
         try:
-            tensors = list(tensors_of(*args, **kwargs))
+            list(tensors_of(*args, **kwargs))
         except Exception:  # noqa: BLE001 - an unexpected call shape is the reference's business
-            return original(*args, **kwargs)
-        if _wants_reference(tensors):
             return original(*args, **kwargs)
         try:
             return ours(*args, **kwargs)
