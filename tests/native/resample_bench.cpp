@@ -171,7 +171,7 @@ static const Paths kPaths[] = {
     // TIO_PRECISION_FAST (float32 trilinear launches only; compared within 1e-4 relative, not bit for bit): the brick
     // kernel's FAST instantiation (the product path) and the experimental kernels of resample_fast.hpp
     {"fast", "tile", "0", 1, nullptr}, {"fast-lean", "tile", "0", 1, "lean"}, {"fast-stream", "tile", "0", 1, "stream"},
-    {"fast-stream8", "tile", "0", 1, "stream8"}};
+    {"fast-stream8", "tile", "0", 1, "stream8"}, {"fast-pipe", "tile", "0", 1, "pipe"}, {"fast-pipe8", "tile", "0", 1, "pipe8"}, {"fast-pipe16", "tile", "0", 1, "pipe16"}, {"fast-desc4", "tile", "0", 1, "desc4"}, {"fast-desc8", "tile", "0", 1, "desc8"}, {"fast-desc16", "tile", "0", 1, "desc16"}, {"fast-ring4", "tile", "0", 1, "ring4"}, {"fast-ring8", "tile", "0", 1, "ring8"}};
 
 static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
   if (!g_case_filter.empty() && cs.name.find(g_case_filter) == std::string::npos) return 0;
@@ -181,7 +181,9 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
   const int nm = cs.batched ? B : 1;
   std::vector<float> mapping(12 * nm);
   for (int b = 0; b < nm; b++) {
-    if (cs.affine) random_mapping(&mapping[12 * b], cs.in_shape, cs.max_deg, cs.scale_dev, cs.shift);
+    // TIO_BENCH_GEOM_SCALE (experiments): scales the rotation and zoom ranges, 0 = pure translation (no LDS bank conflicts)
+    const double gs = getenv("TIO_BENCH_GEOM_SCALE") ? atof(getenv("TIO_BENCH_GEOM_SCALE")) : 1.0;
+    if (cs.affine) random_mapping(&mapping[12 * b], cs.in_shape, cs.max_deg * gs, cs.scale_dev * gs, cs.shift);
     else identity_mapping(&mapping[12 * b]);
     if (cs.out_shape[0] != cs.in_shape[0])  // resampling case: scale the mapping to the output grid
       for (int r = 0; r < 3; r++)
