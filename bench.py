@@ -137,8 +137,9 @@ def aten_baseline(size: int, batch: int, device, steps: int = 3) -> dict:
     }
 
 
-def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int) -> dict:
-    """A few steps of the same Compose in another (noise rng, resample precision) mode: volumes/s on this GPU."""
+def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int, timer=None, launch_bytes: int = 0) -> dict:
+    """A few steps of the same Compose in another (noise rng, resample precision) mode: volumes/s on this GPU, and the
+    mean duration of the tio_resample3d launches in that mode (live HIP events, as for the headline's roofline)."""
     previous = (tio.get_noise_rng(), tio.get_resample_precision())
     tio.set_noise_rng(noise_rng)
     tio.set_resample_precision(precision)
@@ -147,6 +148,8 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
         for _ in range(2):
             transform(batch)
         torch.cuda.synchronize()
+        if timer is not None:
+            timer.pairs, timer.active = [], True
         start = time.perf_counter()
         for _ in range(steps):
             out = transform(batch)
@@ -154,18 +157,25 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - start
     finally:
+        if timer is not None:
+            timer.active = False
         tio.set_noise_rng(previous[0])
         tio.set_resample_precision(previous[1])
     n = steps * batch.batch_size
-    return {"volumes_per_s": n / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps}
+    result = {"volumes_per_s": n / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps}
+    launch_ms = timer.mean_ms() if timer is not None else None
+    if launch_ms:
+        result["resample_launch_ms"] = launch_ms
+        result["resample_frac_of_hbm_peak"] = launch_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return result
 
 
-def load_traffic() -> float | None:
-    """Per-launch HBM bytes of the dominant kernel from the committed PMC summary, if any."""
+def load_traffic(precision: str) -> float | None:
+    """Per-launch HBM bytes of the dominant kernel (of that precision mode) from the committed PMC summary, if any."""
     path = os.path.join(ROOT, "profiles", "resample_traffic.json")
     try:
         with open(path) as handle:
-            return float(json.load(handle)["hbm_bytes_per_launch"])
+            return float(json.load(handle)[f"hbm_bytes_per_launch_{precision}"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -178,8 +188,10 @@ def main() -> None:
     parser.add_argument("--size", type=int, default=256)
     parser.add_argument("--batch", type=int, default=8, help="volumes per GPU per step")
     parser.add_argument("--noise-rng", choices=["reference", "philox"], default="philox")
-    parser.add_argument("--resample-precision", choices=["exact", "fast"], default="exact",
-                        help="exact = the reference's float32 operation sequence bit for bit (default); fast = opt-in fma path, within 1e-4")
+    parser.add_argument("--resample-precision", choices=["exact", "fast"], default="fast",
+                        help="fast (default here, like --noise-rng philox: the throughput modes) = float intensities within the north-star "
+                             "1e-4 relative, planned bricks; exact = the library default, the reference's float32 operation sequence bit for "
+                             "bit.  The other mode is timed as well (mode_matrix) unless --no-mode-matrix")
     parser.add_argument("--prewarm", type=int, default=100, help="untimed process pre-warm calls before the W warm-up steps")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-volumes", type=int, default=8)
@@ -269,13 +281,17 @@ def main() -> None:
             "pipeline_algorithmic_GBps": total["algorithmic_bytes"] / total["elapsed_s"] / 1e9,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue_s / args.steps,
             "roofline": {
-                "kernel": "tio::resample_tile_kernel (tio_resample3d: Affine and ElasticDeformation launches, mean)",
+                "kernel": (
+                    "tio::resample_planned_kernel (+ tio::plan_bricks_kernel; tio_resample3d: Affine and ElasticDeformation launches, mean)"
+                    if args.resample_precision == "fast"
+                    else "tio::resample_tile_kernel (tio_resample3d: Affine and ElasticDeformation launches, mean)"
+                ),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": load_traffic(),
+                "traffic": load_traffic(args.resample_precision),
                 "launch_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "launches_timed": len(timer.pairs),
@@ -290,7 +306,9 @@ def main() -> None:
             out = None
             modes = {}
             for rng_mode, prec, steps in (("philox", "exact", 10), ("philox", "fast", 10), ("reference", "exact", 3)):
-                modes[f"noise={rng_mode},resample={prec}"] = time_mode(transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77)
+                modes[f"noise={rng_mode},resample={prec}"] = time_mode(
+                    transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77, timer=timer, launch_bytes=launch_bytes
+                )
             line["mode_matrix"] = modes
             line["noise_modes"] = {
                 "philox": modes["noise=philox,resample=exact"]["volumes_per_s"],

@@ -68,15 +68,14 @@ struct ResampleArgs {
   int cp_lds;    // floats of LDS reserved for the control points (0 = read them from global)
   int tile_cap;  // floats of LDS available for one staged input brick (tile kernel)
   int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
-  unsigned long long* trace;  // profiling only (TIO_PIPE_TRACE): shader-clock stamps of the pipelined kernel's phases
 };
-constexpr int kTraceBlocks = 64, kTraceIters = 32, kTraceStamps = 8;
 
 constexpr int kTileI = 8;          // output slabs walked by one block
 constexpr int kRowsPerBlock = 4;   // one wave per output row (jo)
 constexpr int kLanes = 64;         // contiguous ko per wave → coalesced stores
 constexpr int kMaxCpLds = 6144;    // floats of control points staged in LDS (24 KiB)
 constexpr int kLdsFloatsPerCU = 40960;   // 160 KiB
+constexpr int kPlannedMinBricks = 12288;  // below: one kernel with in-kernel boxes (the plan costs a launch)
 constexpr int kTileMinCap = 6144;       // the per-voxel fallback parks 8 planes x 3 coordinates x 256 threads there
 constexpr int kTileBlocksPerCU = 3;       // resident blocks the default LDS budget is sized for
 
@@ -452,15 +451,17 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 #include "resample_tile.hpp"
 #include "resample_fast.hpp"
 
-// Device scratch for the brick plan of a FAST launch (resample_fast.hpp): one buffer per stream, grown on demand and kept —
-// launches on one stream are ordered, so the plan of a launch is consumed before the next one overwrites it.
+// Device scratch for the brick plan of a FAST launch (resample_fast.hpp): one buffer per (device, stream), grown on demand
+// and kept — launches on one stream are ordered, so the plan of a launch is consumed before the next one overwrites it.
 static int* plan_workspace(hipStream_t s, size_t bytes) {
-  struct Slot { hipStream_t stream; int* ptr; size_t cap; };
+  struct Slot { int device; hipStream_t stream; int* ptr; size_t cap; };
   static std::mutex mu;
   static std::vector<Slot> slots;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   for (Slot& sl : slots)
-    if (sl.stream == s) {
+    if (sl.device == device && sl.stream == s) {
       if (sl.cap >= bytes) return sl.ptr;
       (void)hipStreamSynchronize(s);
       (void)hipFree(sl.ptr);
@@ -469,54 +470,12 @@ static int* plan_workspace(hipStream_t s, size_t bytes) {
       sl.cap = bytes;
       return sl.ptr;
     }
-  Slot sl{s, nullptr, 0};
+  Slot sl{device, s, nullptr, 0};
   if (hipMalloc(&sl.ptr, bytes) != hipSuccess) return nullptr;
   sl.cap = bytes;
   slots.push_back(sl);
   return sl.ptr;
 }
-
-// profiling only (TIO_PIPE_TRACE): phase durations of the pipelined kernels from their shader-clock stamps
-static void print_pipe_trace(unsigned long long* trace_dev, hipStream_t s, int ablate) {
-  using namespace tio;
-            std::vector<unsigned long long> h(static_cast<size_t>(kTraceBlocks) * kTraceIters * (kTraceStamps + 16));
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(h.data(), trace_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            double sum[kTraceStamps] = {0}; int cnt = 0; double real_ticks = 0;
-            for (int b = 0; b < kTraceBlocks; b++)
-              for (int it = 4; it < kTraceIters - 1; it++) {
-                const unsigned long long* r = &h[(static_cast<size_t>(b) * kTraceIters + it) * kTraceStamps];
-                const unsigned long long* rn = r + kTraceStamps;
-                if (r[0] == 0 || r[2] == 0 || r[3] == 0 || r[5] == 0 || rn[0] == 0) continue;
-                for (int k = 0; k < 5; k++) sum[k] += static_cast<double>(r[k + 1] - r[k]);
-                sum[5] += static_cast<double>(rn[0] - r[5]); sum[6] += static_cast<double>(rn[0] - r[0]);
-                real_ticks += static_cast<double>(rn[6] - r[6]);
-                cnt++;
-              }
-            if (ablate & 16) {  // the stamped sampling loop: issue / wait / finish per iteration of 4 voxels
-              double part[3] = {0, 0, 0}, gap = 0; int n_it = 0;
-              const unsigned long long* base = h.data() + static_cast<size_t>(kTraceBlocks) * kTraceIters * kTraceStamps;
-              for (int b = 0; b < kTraceBlocks; b++)
-                for (int it = 4; it < kTraceIters - 1; it++) {
-                  const unsigned long long* r = base + (static_cast<size_t>(b) * kTraceIters + it) * 16;
-                  if (r[0] == 0 || r[15] == 0) continue;
-                  for (int k = 0; k < 4; k++) {
-                    part[0] += static_cast<double>(r[4 * k + 1] - r[4 * k]); part[1] += static_cast<double>(r[4 * k + 2] - r[4 * k + 1]);
-                    part[2] += static_cast<double>(r[4 * k + 3] - r[4 * k + 2]);
-                    if (k > 0) gap += static_cast<double>(r[4 * k] - r[4 * k - 1]);
-                    n_it++;
-                  }
-                }
-              if (n_it > 0)
-                fprintf(stderr, "  sampling loop (%d iterations of 4 voxels, shader clocks): issue %.0f  lds-wait %.0f  finish+stores %.0f  between %.0f\n", n_it,
-                        part[0] / n_it, part[1] / n_it, part[2] / n_it, gap / (n_it * 0.75));
-            }
-            if (cnt > 0)
-              fprintf(stderr, "pipe trace (%d iterations, shader clocks): lookahead %.0f  frame %.0f  dma-wait+barrier %.0f  sampling %.0f  handover(barrier+dma issue) %.0f  loop %.0f  | total %.0f = %.2f us (shader clock %.0f MHz)\n",
-                      cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, real_ticks / cnt / 100.0,
-                      real_ticks > 0 ? sum[6] / (real_ticks / 100.0) : 0.0);
-}
-
 
 extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
                               const tio_resample_image* images, void* stream) {
@@ -649,7 +608,6 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     if (const char* env = getenv("TIO_TILE_VARIANT")) variant = atoi(env);
     if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) cap = atoi(env);
     if (const char* env = getenv("TIO_TILE_ABLATE")) a.ablate = atoi(env);
-    if (const char* env = getenv("TIO_DESC_STAGGER")) a.ablate |= atoi(env) << 8;
     a.cp_lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? ((n_cp + 3) & ~3) : 0;
     // default brick budget: whatever lets kTileBlocksPerCU blocks share the CU's 160 KiB
     // (minus 2 KiB: the hardware allocates LDS in granules, an exact third does not fit three times)
@@ -674,7 +632,8 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
                               static_cast<int>(lds)) != hipSuccess)                                      \
         return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds);             \
     }                                                                                                    \
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(TJ* TK), lds, s, a);            \
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(TJ* TK), lds, s, a,             \
+                       (TI == 16 && TJ == 16 && TK == 16) ? plan_exact : static_cast<const int*>(nullptr)); \
   }
 #define TIO_TILE_SHAPE(TI, TJ, TK, OCC)                                                  \
   {                                                                                 \
@@ -702,291 +661,90 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
     const bool fast = geom->precision == TIO_PRECISION_FAST && dtmode == 0 && !a.any_nearest && variant == 0 &&
                       getenv("TIO_RESAMPLE_EXACT") == nullptr;
     if (fast) {
-      // The streaming kernel (resample_fast.hpp) needs 16-byte rows for its LDS-DMA, a control grid
-      // that fits its LDS slots and whose cells are at least a tile wide, and columns long enough
-      // for its look-ahead; everything else runs the exact kernel's FAST instantiation.
-      // EXPERIMENTAL, opt-in (TIO_FAST_KERNEL=stream | stream8): the persistent streaming kernel of resample_fast.hpp,
-      // measured no faster than the brick kernel's FAST instantiation (profiles/r02_resample_sq.md has the counters
-      // and ablations); kept for the A/B.
-      const char* fast_kernel = getenv("TIO_FAST_KERNEL");  // unset = the brick kernel's FAST instantiation (the product path)
-      bool stream = fast_kernel != nullptr && strncmp(fast_kernel, "stream", 6) == 0 && (a.K & 3) == 0 && a.Io <= 8 * kStreamMaxSlabs;
-      for (int i = 0; i < a.n_images; i++) stream = stream && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
-      if (a.cp != nullptr) {
-        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
-        for (int d = 0; d < 3; d++)
-          if (n_ctl[d] > 2 && (n_vox[d] - 1) < (d == 0 ? 8 : 32) * (n_ctl[d] - 1)) stream = false;
-        if (n_cp > 2048) stream = false;
-      }
-      if (stream) {
-        int bpc_s = 2;
-        const int shape = strcmp(fast_kernel, "stream8") == 0 ? 2 : 0;  // 8 waves per block (planes of a slab split) or 4
-        if (const char* env = getenv("TIO_STREAM_BPC")) bpc_s = atoi(env);
-        if (bpc_s < 1 || bpc_s > 4) bpc_s = 2;
-        static int n_cu = 0;
-        if (n_cu == 0) {
-          int dev = 0, v = 0;
-          if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-          n_cu = v;
-        }
-        const int tj = 16, tk = 16, nb_s = 2;
-        a.tiles_k = (a.Ko + tk - 1) / tk; a.tiles_j = (a.Jo + tj - 1) / tj; a.tiles_i = 1;
-        int nch = 0;
-        for (int i = 0; i < a.n_images; i++) nch += a.img[i].channels;
-        const int64_t items = static_cast<int64_t>(a.B) * nch * a.tiles_j * a.tiles_k;
-        if (items >= (1LL << 30)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
-        a.cp_lds = n_cp > 0 ? ((n_cp + 3) & ~3) : 0;
-        const int fixed_floats = kStreamMaxSlabs * kTableInts + 16 + a.cp_lds;
-        const int total_floats = (kLdsFloatsPerCU - 256) / bpc_s - 64;  // leave the hardware's allocation granule some slack
-        int cap_s = (total_floats - fixed_floats) / nb_s;
-        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0 && v < cap_s) cap_s = v; }
-        cap_s &= ~3;
-        if (cap_s < 1024) return fail(TIO_ERR_LAUNCH, "tio_resample3d: no LDS left for the slab buffers");
-        a.tile_cap = cap_s;
-        const size_t lds_s = static_cast<size_t>(fixed_floats + nb_s * cap_s) * sizeof(float);
-        int blocks_s = n_cu * bpc_s;
-        if (blocks_s > items) blocks_s = static_cast<int>((items + 7) / 8 * 8);
-        auto launch_stream = [&](auto kernel, int threads) -> int {
-          if (lds_s > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_s)) != hipSuccess)
-            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_s);
-          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks_s)), dim3(threads), lds_s, s, a, static_cast<int>(items));
-          return check_launch("tio_resample3d");
-        };
-#define TIO_STREAM_LAUNCH(TJ, TK, NPW, NB) \
-  return a.cp != nullptr ? launch_stream(resample_stream_kernel<true, TJ, TK, NPW, NB>, TJ * TK * NPW) : launch_stream(resample_stream_kernel<false, TJ, TK, NPW, NB>, TJ * TK * NPW)
-        switch (shape) {
-          case 2: TIO_STREAM_LAUNCH(16, 16, 2, 2);
-          default: TIO_STREAM_LAUNCH(16, 16, 1, 2);
-        }
-#undef TIO_STREAM_LAUNCH
-      }
       a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
       a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;
       a.magic_j = a.tiles_j > 1 ? 0xFFFFFFFFu / a.tiles_j + 1u : 0u;
       a.magic_i = a.tiles_i > 1 ? 0xFFFFFFFFu / a.tiles_i + 1u : 0u;
       const int64_t blocks = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
       if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+      // Planned bricks (resample_fast.hpp): a one-thread-per-brick planning kernel, then one block per brick that starts
+      // from its 64-byte descriptor.  Needs 16-byte rows for the LDS-DMA and control cells at least a brick wide (the
+      // box comes from <= 27 vertices); everything else — and TIO_FAST_KERNEL=brick, the A/B switch — runs the brick
+      // kernel's FAST instantiation with its in-kernel boxes.
+      const char* fast_kernel = getenv("TIO_FAST_KERNEL");
+      // (small launches keep the single-kernel road: the planning kernel and the gap before the second launch cost
+      // ~10-15 us, more than the planned bricks save below ~12 k bricks; TIO_FAST_KERNEL=planned forces them)
+      const bool force_planned = fast_kernel != nullptr && strcmp(fast_kernel, "planned") == 0;
+      bool planned = !(fast_kernel != nullptr && strcmp(fast_kernel, "brick") == 0) && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned);
+      for (int i = 0; i < a.n_images; i++) planned = planned && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
+      if (planned && a.cp != nullptr) {
+        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
+        for (int d = 0; d < 3; d++)
+          if (n_ctl[d] > 2 && (n_vox[d] - 1) < 16 * (n_ctl[d] - 1)) planned = false;
+      }
+      if (planned) {
+        int cap_p = kLdsFloatsPerCU / kTileBlocksPerCU - 512;
+        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_p = v; }
+        if (cap_p < kTileMinCap) cap_p = kTileMinCap;
+        if (cap_p > kLdsFloatsPerCU) cap_p = kLdsFloatsPerCU;
+        a.tile_cap = cap_p;
+        a.cp_lds = 0;
+        const size_t lds_p = static_cast<size_t>(cap_p) * sizeof(float);
+        const int n_items = static_cast<int>(blocks);
+        int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
+        if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+        const int plan_threads = n_items > a.B ? n_items : a.B;
+        const dim3 plan_grid((plan_threads + 255) / 256);
+        if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+        else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+        auto launch_planned = [&](auto kernel) -> int {
+          if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      static_cast<int>(lds_p)) != hipSuccess)
+            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
+          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(256), lds_p, s, a, static_cast<const int*>(plan));
+          return check_launch("tio_resample3d");
+        };
+        if (a.cp != nullptr) return launch_planned(resample_planned_kernel<true, 16, 16, 16, 3>);
+        return launch_planned(resample_planned_kernel<false, 16, 16, 16, 3>);
+      }
       auto launch_fast = [&](auto kernel) -> int {
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    static_cast<int>(lds)) != hipSuccess)
           return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds);
-        hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a, static_cast<const int*>(nullptr));
         return check_launch("tio_resample3d");
       };
-      // EXPERIMENTAL, opt-in (TIO_FAST_KERNEL=lean): the lean brick kernel of resample_fast.hpp — same speed as the
-      // product path for affine launches, slower for elastic ones (profiles/r02_resample_sq.md); kept for the A/B.
-      bool lean = fast_kernel != nullptr && strcmp(fast_kernel, "lean") == 0 && (a.K & 3) == 0;
-      for (int i = 0; i < a.n_images; i++) lean = lean && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
-      if (a.cp != nullptr) {
-        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
-        for (int d = 0; d < 3; d++)
-          if (n_ctl[d] > 2 && (n_vox[d] - 1) < 16 * (n_ctl[d] - 1)) lean = false;
-      }
-      if (lean) {
-        int bpc_l = kTileBlocksPerCU;
-        if (const char* env = getenv("TIO_FAST_BPC")) { const int v = atoi(env); if (v >= 1 && v <= 8) bpc_l = v; }
-        int cap_l = kLdsFloatsPerCU / bpc_l - 512 - 16;
-        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_l = v; }
-        if (cap_l < kTileMinCap) cap_l = kTileMinCap;
-        if (cap_l > kLdsFloatsPerCU - 16) cap_l = kLdsFloatsPerCU - 16;
-        a.tile_cap = cap_l;
-        a.cp_lds = 0;
-        const size_t lds_l = static_cast<size_t>(16 + cap_l) * sizeof(float);
-        auto launch_lean = [&](auto kernel) -> int {
-          if (lds_l > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_l)) != hipSuccess)
-            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_l);
-          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds_l, s, a);
-          return check_launch("tio_resample3d");
-        };
-        if (a.cp != nullptr) return launch_lean(resample_fastbrick_kernel<true, 16, 16, 16, 3>);
-        return launch_lean(resample_fastbrick_kernel<false, 16, 16, 16, 3>);
-      }
-      // TIO_FAST_KERNEL=pipe: persistent blocks, the next brick's box worked out while the current DMA is in flight
-      bool pipe_ok = fast_kernel != nullptr && strncmp(fast_kernel, "pipe", 4) == 0 && (a.K & 3) == 0 && a.n_images == 1 && a.img[0].channels == 1 &&
-                     (reinterpret_cast<uintptr_t>(a.img[0].in) & 15) == 0;
-      if (pipe_ok && a.cp != nullptr) {
-        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
-        for (int d = 0; d < 3; d++)
-          if (n_ctl[d] > 2 && (n_vox[d] - 1) < 16 * (n_ctl[d] - 1)) pipe_ok = false;
-      }
-      const bool pipe = pipe_ok && strcmp(fast_kernel, "pipe") == 0;
-      // TIO_FAST_KERNEL=desc4 | desc8 | desc16: bricks planned by a tiny kernel of their own (one thread per brick), sampled by
-      // blocks of 4 / 8 / 16 waves that read their 64-byte descriptor with one scalar load
-      bool desc_ok = fast_kernel != nullptr && strncmp(fast_kernel, "desc", 4) == 0 && (a.K & 3) == 0 && a.n_images == 1 && a.img[0].channels == 1 &&
-                     (reinterpret_cast<uintptr_t>(a.img[0].in) & 15) == 0;
-      if (desc_ok && a.cp != nullptr) {
-        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
-        for (int d = 0; d < 3; d++)
-          if (n_ctl[d] > 2 && (n_vox[d] - 1) < 16 * (n_ctl[d] - 1)) desc_ok = false;
-      }
-      // TIO_FAST_KERNEL=ring4 | ring8: the planned bricks through a two-buffer ring in persistent blocks
-      bool ring_ok = fast_kernel != nullptr && strncmp(fast_kernel, "ring", 4) == 0 && (a.K & 3) == 0 && a.n_images == 1 && a.img[0].channels == 1 &&
-                     (reinterpret_cast<uintptr_t>(a.img[0].in) & 15) == 0;
-      if (ring_ok && a.cp != nullptr) {
-        const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
-        for (int d = 0; d < 3; d++)
-          if (n_ctl[d] > 2 && (n_vox[d] - 1) < 16 * (n_ctl[d] - 1)) ring_ok = false;
-      }
-      if (ring_ok) {
-        const int npw = strcmp(fast_kernel, "ring8") == 0 ? 2 : 1;
-        int bpc_r = 2;
-        if (const char* env = getenv("TIO_FAST_BPC")) { const int v = atoi(env); if (v >= 1 && v <= 3) bpc_r = v; }
-        int cap_r = (kLdsFloatsPerCU / bpc_r - 512) / 2;
-        cap_r &= ~3;
-        if (cap_r < kTileMinCap) cap_r = kTileMinCap;
-        a.tile_cap = cap_r;
-        a.cp_lds = 0;
-        const size_t lds_r = static_cast<size_t>(2 * cap_r) * sizeof(float);
-        a.tiles_i = (a.Io + 7) / 8;
-        a.magic_i = a.tiles_i > 1 ? 0xFFFFFFFFu / a.tiles_i + 1u : 0u;
-        const int64_t items64 = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
-        if (items64 >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
-        const int n_items = static_cast<int>(items64);
-        int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
-        if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
-        const int plan_threads = n_items > a.B ? n_items : a.B;
-        const dim3 plan_grid((plan_threads + 255) / 256);
-        if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 8, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-        else hipLaunchKernelGGL((plan_bricks_kernel<false, 8, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-        const int grid_r = n_items < bpc_r * 256 ? n_items : bpc_r * 256;
-        auto launch_ring = [&](auto kernel, int threads) -> int {
-          if (lds_r > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_r)) != hipSuccess)
-            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_r);
-          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid_r)), dim3(threads), lds_r, s, a, static_cast<const int*>(plan), n_items);
-          return check_launch("tio_resample3d");
-        };
-        if (a.cp != nullptr) {
-          if (npw == 2) return launch_ring(resample_ring_kernel<true, 8, 16, 16, 2, 4, 4>, 512);
-          return launch_ring(resample_ring_kernel<true, 8, 16, 16, 1, 3, 4>, 256);
-        }
-        if (npw == 2) return launch_ring(resample_ring_kernel<false, 8, 16, 16, 2, 4, 4>, 512);
-        return launch_ring(resample_ring_kernel<false, 8, 16, 16, 1, 3, 4>, 256);
-      }
-      if (desc_ok) {
-        const int npw = strcmp(fast_kernel, "desc16") == 0 ? 4 : (strcmp(fast_kernel, "desc8") == 0 ? 2 : 1);
-        int ti = 16, gmax = 4;
-        if (const char* env = getenv("TIO_DESC_TI")) { if (atoi(env) == 8 && npw == 1) ti = 8; }
-        if (const char* env = getenv("TIO_DESC_G")) { if (atoi(env) == 8 && npw == 1) gmax = 8; }
-        int bpc_d = npw == 4 ? 2 : (ti == 8 ? 5 : 3);
-        if (const char* env = getenv("TIO_FAST_BPC")) { const int v = atoi(env); if (v >= 1 && v <= bpc_d) bpc_d = v; }
-        int cap_d = kLdsFloatsPerCU / bpc_d - 512;
-        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_d = v; }
-        if (cap_d < kTileMinCap) cap_d = kTileMinCap;
-        if (cap_d > kLdsFloatsPerCU) cap_d = kLdsFloatsPerCU;
-        a.tile_cap = cap_d;
-        a.cp_lds = 0;
-        const size_t lds_d = static_cast<size_t>(cap_d) * sizeof(float);
-        if (ti == 8) {
-          a.tiles_i = (a.Io + 7) / 8;
-          a.magic_i = a.tiles_i > 1 ? 0xFFFFFFFFu / a.tiles_i + 1u : 0u;
-        }
-        const int64_t items64 = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
-        if (items64 >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
-        const int n_items = static_cast<int>(items64);
-        int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
-        if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
-        const int plan_threads = n_items > a.B ? n_items : a.B;
-        const dim3 plan_grid((plan_threads + 255) / 256);
-        if (a.cp != nullptr) {
-          if (ti == 8) hipLaunchKernelGGL((plan_bricks_kernel<true, 8, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-          else hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-        } else {
-          if (ti == 8) hipLaunchKernelGGL((plan_bricks_kernel<false, 8, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-          else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-        }
-        auto launch_desc = [&](auto kernel, int threads) -> int {
-          if (lds_d > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_d)) != hipSuccess)
-            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_d);
-          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(threads), lds_d, s, a, static_cast<const int*>(plan));
-          return check_launch("tio_resample3d");
-        };
-#define TIO_DESC_PICK(EL)                                                                                   \
-  {                                                                                                         \
-    if (npw == 4) return launch_desc(resample_desc_kernel<EL, 16, 16, 16, 4, 8, 4>, 1024);                  \
-    if (npw == 2) return launch_desc(resample_desc_kernel<EL, 16, 16, 16, 2, 6, 4>, 512);                   \
-    if (ti == 8 && gmax == 8) return launch_desc(resample_desc_kernel<EL, 8, 16, 16, 1, 5, 8>, 256);        \
-    if (ti == 8) return launch_desc(resample_desc_kernel<EL, 8, 16, 16, 1, 5, 4>, 256);                     \
-    if (gmax == 8) return launch_desc(resample_desc_kernel<EL, 16, 16, 16, 1, 3, 8>, 256);                  \
-    return launch_desc(resample_desc_kernel<EL, 16, 16, 16, 1, 3, 4>, 256);                                 \
-  }
-        if (a.cp != nullptr) TIO_DESC_PICK(true) else TIO_DESC_PICK(false)
-#undef TIO_DESC_PICK
-      }
-      const bool pipe8 = pipe_ok && fast_kernel != nullptr && strcmp(fast_kernel, "pipe8") == 0;
-      const bool pipe16 = pipe_ok && fast_kernel != nullptr && strcmp(fast_kernel, "pipe16") == 0;
-      if (pipe8 || pipe16) {
-        int bpc_p = pipe8 ? 3 : 2;
-        if (const char* env = getenv("TIO_FAST_BPC")) { const int v = atoi(env); if (v >= 1 && v <= (pipe8 ? 3 : 2)) bpc_p = v; }
-        int cap_p = kLdsFloatsPerCU / bpc_p - 512 - kPipeTile;
-        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_p = v; }
-        if (cap_p < kTileMinCap) cap_p = kTileMinCap;
-        if (cap_p > kLdsFloatsPerCU - kPipeTile) cap_p = kLdsFloatsPerCU - kPipeTile;
-        a.tile_cap = cap_p;
-        a.cp_lds = 0;
-        const size_t lds_p = static_cast<size_t>(kPipeTile + cap_p) * sizeof(float);
-        const int n_items = static_cast<int>(blocks);
-        const int grid_p = n_items < bpc_p * 256 ? n_items : bpc_p * 256;
-        const int threads_p = pipe8 ? 512 : 1024;
-        auto launch_pipew = [&](auto kernel) -> int {
-          if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_p)) != hipSuccess)
-            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
-          static unsigned long long* trace_dev = nullptr;
-          const bool tracing = getenv("TIO_PIPE_TRACE") != nullptr;
-          if (tracing) {
-            const size_t bytes = sizeof(unsigned long long) * kTraceBlocks * kTraceIters * (kTraceStamps + 16);
-            if (trace_dev == nullptr && hipMalloc(&trace_dev, bytes) != hipSuccess) return fail(TIO_ERR_LAUNCH, "trace buffer");
-            (void)hipMemsetAsync(trace_dev, 0, bytes, s);
-            a.trace = trace_dev;
-          }
-          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid_p)), dim3(threads_p), lds_p, s, a, n_items);
-          if (tracing) print_pipe_trace(trace_dev, s, a.ablate);
-          return check_launch("tio_resample3d");
-        };
-        if (pipe8) {
-          if (a.cp != nullptr) return launch_pipew(resample_pipew_kernel<true, 16, 16, 16, 2, 6>);
-          return launch_pipew(resample_pipew_kernel<false, 16, 16, 16, 2, 6>);
-        }
-        if (a.cp != nullptr) return launch_pipew(resample_pipew_kernel<true, 16, 16, 16, 4, 8>);
-        return launch_pipew(resample_pipew_kernel<false, 16, 16, 16, 4, 8>);
-      }
-      if (pipe) {
-        int bpc_p = kTileBlocksPerCU;
-        if (const char* env = getenv("TIO_FAST_BPC")) { const int v = atoi(env); if (v >= 1 && v <= 8) bpc_p = v; }
-        int cap_p = kLdsFloatsPerCU / bpc_p - 512 - 16;
-        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_p = v; }
-        if (cap_p < kTileMinCap) cap_p = kTileMinCap;
-        if (cap_p > kLdsFloatsPerCU - 16) cap_p = kLdsFloatsPerCU - 16;
-        a.tile_cap = cap_p;
-        a.cp_lds = 0;
-        const size_t lds_p = static_cast<size_t>(16 + cap_p) * sizeof(float);
-        const int n_items = static_cast<int>(blocks);
-        const int grid_p = n_items < bpc_p * 256 ? n_items : bpc_p * 256;
-        auto launch_pipe = [&](auto kernel) -> int {
-          if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_p)) != hipSuccess)
-            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
-          static unsigned long long* trace_dev = nullptr;
-          const bool tracing = getenv("TIO_PIPE_TRACE") != nullptr;
-          if (tracing) {
-            const size_t bytes = sizeof(unsigned long long) * kTraceBlocks * kTraceIters * (kTraceStamps + 16);
-            if (trace_dev == nullptr && hipMalloc(&trace_dev, bytes) != hipSuccess) return fail(TIO_ERR_LAUNCH, "trace buffer");
-            (void)hipMemsetAsync(trace_dev, 0, bytes, s);
-            a.trace = trace_dev;
-          }
-          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid_p)), dim3(256), lds_p, s, a, n_items);
-          if (tracing) print_pipe_trace(trace_dev, s, a.ablate);
-          return check_launch("tio_resample3d");
-        };
-        if (a.cp != nullptr) return launch_pipe(resample_pipe_kernel<true, 16, 16, 16, 3>);
-        return launch_pipe(resample_pipe_kernel<false, 16, 16, 16, 3>);
-      }
       if (a.cp != nullptr) return launch_fast(resample_tile_kernel<true, 0, 16, 16, 16, 3, true>);
       return launch_fast(resample_tile_kernel<false, 0, 16, 16, 16, 3, true>);
+    }
+    // Large affine-only exact launches of 16^3 bricks are planned too (resample_tile.hpp: the planned box only decides what
+    // is staged; the corner evaluation and its reductions leave the head of every block); TIO_EXACT_PLAN=0 switches it off,
+    // =2 forces it for small launches (A/B, tests).
+    const int* plan_exact = nullptr;
+    {
+      // Measured (8 x 256^3): affine 0.497 -> 0.478 ms; elastic launches LOSE (0.588 -> 0.610: 27 vertices with their
+      // control-point reads per brick cost the planner more than the brick kernel's own reduction), and so do small ones.
+      const char* env_plan = getenv("TIO_EXACT_PLAN");
+      const bool want = variant == 0 && a.ablate == 0 && a.cp == nullptr && !(env_plan != nullptr && atoi(env_plan) == 0) &&
+                        (static_cast<int64_t>(a.B) * ((a.Io + 15) / 16) * ((a.Jo + 15) / 16) * ((a.Ko + 15) / 16) >= kPlannedMinBricks ||
+                         (env_plan != nullptr && atoi(env_plan) == 2));
+      if (want) {
+        a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
+        a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;
+        a.magic_j = a.tiles_j > 1 ? 0xFFFFFFFFu / a.tiles_j + 1u : 0u;
+        a.magic_i = a.tiles_i > 1 ? 0xFFFFFFFFu / a.tiles_i + 1u : 0u;
+        const int64_t items64 = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
+        if (items64 < (1LL << 31)) {
+          const int n_items = static_cast<int>(items64);
+          int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
+          if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+          const int plan_threads = n_items > a.B ? n_items : a.B;
+          const dim3 plan_grid((plan_threads + 255) / 256);
+          if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+          else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+          plan_exact = plan;
+        }
+      }
     }
     switch (variant) {
       case 1: TIO_TILE_SHAPE_F32(16, 8, 32, 3) break;

@@ -243,6 +243,9 @@ __device__ __forceinline__ void gather_voxel(const ImgArgs& g, const ResampleArg
 }
 
 // ---- the staged box of one pass (block uniform, kept in SGPRs) -------------------------
+// The brick plan written by plan_bricks_kernel (resample_fast.hpp): 16 dwords per brick after 16 floats per batch element
+enum : int { kDescInts = 16, kDescStaged = 0, kDescOutside = 1, kDescSlow = 2, kDescGated = 3 };
+
 struct TileBox {
   int bx0, bx1, by0, by1, zlo, zhi, za;  // inclusive tap range per axis; za = zlo aligned down to 4
   int Lx, Ly, Lz;                        // staged extent (Lz a multiple of 4, rows dense)
@@ -638,7 +641,7 @@ __device__ __forceinline__ void tile_channel(const ResampleArgs& a, const ImgArg
 // themselves, a few ulps away from the round-tripped ones) and the interpolation uses nested fma
 // lerps.  Everything else — boxes, staging, masks — is shared with the exact kernel.
 template <bool ELASTIC_POSSIBLE, int DTMODE, int TI, int TJ, int TK, int OCC, bool FAST = false>
-__global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_kernel(const ResampleArgs a) {
+__global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_kernel(const ResampleArgs a, const int* __restrict__ plan) {
   constexpr int NT = TJ * TK, NW = NT / 64;
   constexpr int NQ = 4, QT = TI / NQ;  // a brick is split (when needed) at quarter granularity
   static_assert(TI % NQ == 0 && QT <= kTileStashPlanes, "unsupported brick depth");
@@ -818,7 +821,26 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
   const float capx = hx + 1.0f, capy = hy + 1.0f, capz = hz + 1.0f;
   TileBox box_full;
   bool have_box = false, prestaged = false;
-  if (!elastic) {
+  // A planned launch (16^3 bricks only): the brick's box was bounded ahead of time from the <= 27 vertices of the
+  // coordinate map, with a margin (1 / 64 voxel) far above what the float32 operation sequence below can differ from
+  // the real-valued map by.  It only decides WHAT is staged — every coordinate and every tap weight is still computed
+  // here, bit for bit — but it is known before phase A, so the brick travels while the coordinates are formed and the
+  // per-voxel tracking, the block reduction and its barrier are not waited for.  Bricks the planner could not bound
+  // (non-finite geometry, several control cells per brick axis, a box beyond the LDS budget) take the in-kernel road.
+  if (plan != nullptr && !weird) {
+    typedef __attribute__((address_space(4))) const int* const_int_ptr;
+    const_int_ptr d = (const_int_ptr)(plan + a.B * 16) + static_cast<size_t>(tile) * kDescInts;
+    const int kw = d[0];
+    if ((kw & 0xFF) == kDescStaged) {
+      box_full.bx0 = d[1]; box_full.by0 = d[2]; box_full.za = d[3];
+      box_full.Lx = d[4]; box_full.Ly = d[5]; box_full.Lz = d[6] * 4;
+      box_full.bx1 = box_full.bx0 + box_full.Lx - 1; box_full.by1 = box_full.by0 + box_full.Ly - 1;
+      box_full.zlo = box_full.za; box_full.zhi = box_full.za + box_full.Lz - 1;
+      box_full.interior = kw >> 8; box_full.outside = 0; box_full.fits = 1;
+      have_box = true;
+    }
+  }
+  if (!elastic && !have_box) {
     int r[6];
     {
       const int j_lo = jt * TJ, j_hi = min(j_lo + TJ, a.Jo) - 1, k_lo = kt * TK, k_hi = min(k_lo + TK, a.Ko) - 1;
@@ -834,6 +856,8 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
     for (int q = 0; q < 6; q++) r[q] = wave_max_i32(r[q]);
     box_full = make_box(r, a, weird);
     have_box = true;
+  }
+  if (have_box) {
     const ImgArgs& g0 = a.img[0];
     prestaged = (a.n_images == 1) & (g0.channels == 1) & (g0.interp == TIO_LINEAR) & (box_full.fits != 0) & (box_full.outside == 0) &
                 (g0.dtype == TIO_F32) & ((a.K & 3) == 0) & ((reinterpret_cast<uintptr_t>(g0.in) & 15) == 0) & (a.ablate == 0);
