@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 6
+#define TIO_ABI_VERSION 7
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -165,6 +165,12 @@ typedef struct tio_resample_image {
   const double* labels_dev;
   int32_t n_labels;
   double pad_label;
+  /* Optional (NULL = not wanted): C floats on the device that receive the per-channel minimum of the FIRST batch
+   * element of `out` — what the NEXT transform's default_pad_value="minimum" will ask for (spatial.py:2054-2060,
+   * 2094-2095: `tensor[0, c].min()` of the data it is handed).  Large TIO_PRECISION_FAST launches fold it into their
+   * stores (no extra pass over the volume); every other launch runs tio_channel_min on `out` before returning.
+   * NaN propagates like torch.min.  Ignored for TIO_LINEAR_ADJOINT. */
+  float* out_min_dev;
 } tio_resample_image;
 
 /* Resample n_images image tensors through ONE coordinate computation. */

@@ -105,3 +105,85 @@ def test_planned_exact_affine_launches_are_bit_identical(hip, monkeypatch, shape
     planned = hip.resample3d([t1, seg], **kwargs)
     torch.cuda.synchronize()
     assert torch.equal(plain[0], planned[0]) and torch.equal(plain[1], planned[1])
+
+
+# -- the folded minimum (tio_resample_image.out_min_dev) ------------------------------------------------------
+@pytest.fixture(autouse=True)
+def _restore_folded_min_switch(monkeypatch):
+    monkeypatch.delenv("TIO_FOLDED_MIN", raising=False)
+    yield
+    import os
+
+    os.environ.pop("TIO_FOLDED_MIN", None)
+
+
+def _large_launch(hip, *, elastic: bool, poison: bool = False, gated: bool = False):
+    """3 x 256^3 = 12 288 bricks: the smallest launch that takes the planned road (and can fold the minimum) by itself."""
+    import os
+
+    from torchio_amd import ops
+
+    os.environ["TIO_FOLDED_MIN"] = "1"  # opt-in (ops.Engine.resample3d); the autouse fixture below restores it
+
+    batch, shape = 3, (256, 256, 256)
+    g = torch.Generator(device="cuda").manual_seed(41)
+    data = torch.rand(batch, 2, *shape, generator=g, device="cuda") - 0.25
+    if poison:
+        data[0, 1, 100, 100, 100] = float("nan")
+    kwargs = dict(
+        out_shape=shape, mapping=_mapping(batch, 43, scale=0.05, shift=3.0).cuda(),
+        control_points=_control_points(batch, (7, 7, 7), 44, amplitude=5.0).cuda() if elastic else None,
+        in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["linear"],
+        fills=[torch.tensor([-0.5, 0.125], device="cuda")], precision="fast",
+        passthrough=torch.tensor([1, 0, 0], dtype=torch.uint8).cuda() if gated else None,
+    )
+    out = hip.resample3d([data], **kwargs)[0]
+    return data, out, ops.folded_channel_min(out)
+
+
+@pytest.mark.parametrize("elastic", [False, True])
+def test_folded_minimum_equals_the_reduction(hip, elastic):
+    _, out, folded = _large_launch(hip, elastic=elastic)
+    assert folded is not None and folded.shape == (2,)
+    assert torch.equal(folded, hip.channel_min(out))
+    assert torch.equal(folded.cpu(), out[0].amin(dim=(1, 2, 3)).cpu())
+    # a second launch on the same stream finds the workspace as the first one left it
+    _, out2, folded2 = _large_launch(hip, elastic=elastic)
+    assert torch.equal(folded2, hip.channel_min(out2)) and torch.equal(out, out2)
+
+
+def test_folded_minimum_propagates_nan_and_sees_gated_elements(hip):
+    _, out, folded = _large_launch(hip, elastic=False, poison=True)
+    assert torch.isnan(folded[1]) and not torch.isnan(folded[0])
+    assert torch.equal(folded[:1], hip.channel_min(out)[:1])
+    data, out, folded = _large_launch(hip, elastic=False, gated=True)  # element 0 is copied bit for bit
+    assert torch.equal(out[0], data[0]) and torch.equal(folded, hip.channel_min(data))
+
+
+def test_folded_minimum_is_dropped_once_the_tensor_is_written(hip):
+    from torchio_amd import ops
+
+    _, out, folded = _large_launch(hip, elastic=False)
+    assert folded is not None
+    out.add_(1.0)
+    assert ops.folded_channel_min(out) is None
+
+
+def test_compose_is_bit_identical_with_and_without_the_folded_minimum(hip, monkeypatch):
+    import torchio_amd as tio
+
+    g = torch.Generator().manual_seed(3)
+    subjects = [tio.Subject(t1=tio.ScalarImage(torch.rand(1, 256, 256, 256, generator=g) + 0.5)) for _ in range(3)]
+    transform = tio.Compose([tio.Affine(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5)), tio.ElasticDeformation()])
+    previous = tio.get_resample_precision()
+    tio.set_resample_precision("fast")
+    try:
+        results = []
+        for on in ("0", "1"):
+            monkeypatch.setenv("TIO_FOLDED_MIN", on)
+            torch.manual_seed(5)
+            results.append(transform(tio.SubjectsBatch.from_subjects(subjects).to("cuda")).t1.data)
+        torch.cuda.synchronize()
+    finally:
+        tio.set_resample_precision(previous)
+    assert torch.equal(results[0], results[1])

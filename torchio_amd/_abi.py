@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_IMAGES = 8
 
 # tio_status
@@ -60,6 +60,7 @@ class ResampleImage(C.Structure):
         ("labels_dev", C.c_void_p),
         ("n_labels", C.c_int32),
         ("pad_label", C.c_double),
+        ("out_min_dev", C.c_void_p),
     ]
 
 

@@ -179,4 +179,21 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
   return start + slot;
 }
 
+
+// Per-channel minimum through ordered-integer keys (intensity.hip: tio_channel_min; resample_fast.hpp: the minimum of a
+// resampler's own output, folded into its stores).  NaN maps to key 0 so it wins, matching torch.min's NaN propagation.
+__device__ __forceinline__ uint32_t float_to_key(float f) {
+  if (f != f) return 0u;
+  const uint32_t bits = __float_as_uint(f);
+  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t key) {
+  if (key == 0u) return __uint_as_float(0x7FC00000u);
+  const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+  return __uint_as_float(bits);
+}
+// `*cap` keys (all ones) followed by `*cap` tickets (zero), *cap >= entries, one pair of arrays per (device, stream): set
+// up once, every user restores what it touched before it ends.  Calls on one stream are ordered.
+uint32_t* min_workspace(hipStream_t s, int entries, int* cap);
+
 }  // namespace tio

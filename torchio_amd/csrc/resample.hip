@@ -39,6 +39,9 @@ struct ImgArgs {
   const double* labels;
   int n_labels;
   double pad_label;
+  // the folded minimum (planned FAST launches): per-channel result, and this image's first key in the workspace
+  float* out_min;
+  uint32_t* min_keys;
 };
 
 struct ResampleArgs {
@@ -477,9 +480,10 @@ static int* plan_workspace(hipStream_t s, size_t bytes) {
   return sl.ptr;
 }
 
-extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
-                              const tio_resample_image* images, void* stream) {
+// `folded` comes back true when the launch itself produced every requested out_min_dev (planned FAST bricks)
+static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, const tio_resample_image* images, void* stream, bool* folded) {
   using namespace tio;
+  *folded = false;
   if (geom == nullptr || images == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: null argument");
   if (n_images < 1 || n_images > TIO_MAX_IMAGES)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: n_images=%d not in [1, %d]", n_images, TIO_MAX_IMAGES);
@@ -562,10 +566,10 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
         return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d: TIO_LABEL_PV needs channels == 1, got %d", i, s.channels);
       if (s.n_labels < 0 || (s.n_labels > 0 && s.labels_dev == nullptr))
         return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d: bad label table", i);
-      pv.img[pv.n_images++] = ImgArgs{s.in, s.out, nullptr, 1, s.dtype, s.interp, s.labels_dev, s.n_labels, s.pad_label};
+      pv.img[pv.n_images++] = ImgArgs{s.in, s.out, nullptr, 1, s.dtype, s.interp, s.labels_dev, s.n_labels, s.pad_label, nullptr, nullptr};
       continue;
     }
-    a.img[a.n_images++] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp, nullptr, 0, 0.0};
+    a.img[a.n_images++] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, s.out_min_dev, nullptr};
     // the in-bounds weight mask needs the trilinear weights even for nearest data (spatial.py:1722-1727)
     if (s.interp == TIO_LINEAR || s.interp == TIO_LINEAR_ADJOINT || s.fill_dev != nullptr) a.any_linear = 1;
     if (s.interp == TIO_NEAREST) a.any_nearest = 1;
@@ -675,7 +679,7 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
       // (small launches keep the single-kernel road: the planning kernel and the gap before the second launch cost
       // ~10-15 us, more than the planned bricks save below ~12 k bricks; TIO_FAST_KERNEL=planned forces them)
       const bool force_planned = fast_kernel != nullptr && strcmp(fast_kernel, "planned") == 0;
-      bool planned = !(fast_kernel != nullptr && strcmp(fast_kernel, "brick") == 0) && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned);
+      bool planned = !(fast_kernel != nullptr && strcmp(fast_kernel, "brick") == 0) && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned) && blocks < (1LL << 26);
       for (int i = 0; i < a.n_images; i++) planned = planned && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
       if (planned && a.cp != nullptr) {
         const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
@@ -693,15 +697,42 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
         const int n_items = static_cast<int>(blocks);
         int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
         if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
-        const int plan_threads = n_items > a.B ? n_items : a.B;
+        const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
+        const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
         const dim3 plan_grid((plan_threads + 255) / 256);
         if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
         else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+        // the folded minimum: kMinSlots keys per channel that asked for it (common.hpp: min_workspace, all ones between
+        // launches), finished by min_finish_kernel behind the sampling kernel
+        uint32_t* min_keys = nullptr;
+        MinOuts min_outs{};
+        int min_channels = 0;
+        {
+          for (int i = 0; i < a.n_images; i++) min_channels += a.img[i].out_min != nullptr ? a.img[i].channels : 0;
+          if (min_channels > 0 && min_channels <= kMinChannels && pv.n_images == 0) {
+            int cap = 0;
+            min_keys = min_workspace(s, min_channels * kMinSlots, &cap);
+            if (min_keys == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the reduction workspace");
+            int slot = 0;
+            for (int i = 0; i < a.n_images; i++)
+              if (a.img[i].out_min != nullptr) {
+                a.img[i].min_keys = min_keys + slot * kMinSlots;
+                for (int c = 0; c < a.img[i].channels; c++) min_outs.p[slot + c] = a.img[i].out_min + c;
+                slot += a.img[i].channels;
+              }
+            *folded = true;
+          } else {
+            min_channels = 0;
+            for (int i = 0; i < a.n_images; i++) a.img[i].out_min = nullptr;
+          }
+        }
         auto launch_planned = [&](auto kernel) -> int {
           if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       static_cast<int>(lds_p)) != hipSuccess)
             return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
           hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(256), lds_p, s, a, static_cast<const int*>(plan));
+          if (min_channels > 0)
+            hipLaunchKernelGGL(min_finish_kernel, dim3(static_cast<unsigned>(min_channels)), dim3(kMinSlots), 0, s, min_keys, min_outs, min_channels);
           return check_launch("tio_resample3d");
         };
         if (a.cp != nullptr) return launch_planned(resample_planned_kernel<true, 16, 16, 16, 3>);
@@ -734,11 +765,12 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
         a.magic_j = a.tiles_j > 1 ? 0xFFFFFFFFu / a.tiles_j + 1u : 0u;
         a.magic_i = a.tiles_i > 1 ? 0xFFFFFFFFu / a.tiles_i + 1u : 0u;
         const int64_t items64 = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
-        if (items64 < (1LL << 31)) {
+        if (items64 < (1LL << 26)) {
           const int n_items = static_cast<int>(items64);
           int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
           if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
-          const int plan_threads = n_items > a.B ? n_items : a.B;
+          const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
+        const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
           const dim3 plan_grid((plan_threads + 255) / 256);
           if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
           else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
@@ -774,4 +806,19 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,
   }
 #undef TIO_LAUNCH
   return check_launch("tio_resample3d");
+}
+
+extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images, const tio_resample_image* images, void* stream) {
+  bool folded = false;
+  const int status = resample3d_impl(geom, n_images, images, stream, &folded);
+  if (status != TIO_OK || folded || geom == nullptr || images == nullptr || geom->batch < 1) return status;
+  // out_min_dev of launches that did not fold it into their stores: the plain reduction over what was just written
+  const int64_t n_out = static_cast<int64_t>(geom->out_shape[0]) * geom->out_shape[1] * geom->out_shape[2];
+  for (int i = 0; i < n_images; i++) {
+    const tio_resample_image& im = images[i];
+    if (im.out_min_dev == nullptr || im.interp == TIO_LINEAR_ADJOINT) continue;
+    const int st = tio_channel_min(im.out, im.dtype, im.channels, n_out, im.out_min_dev, stream);
+    if (st != TIO_OK) return st;
+  }
+  return TIO_OK;
 }

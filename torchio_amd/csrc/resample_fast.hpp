@@ -144,10 +144,11 @@ __device__ __forceinline__ float fast_mask(const FastTaps& ts, float x0, float y
 // n planes of this thread's column: coordinate(t) = (ax, ay, az) + t (bxs, bys, bzs), box-relative.
 // G voxels have their LDS reads in flight before the first interpolation starts.  The output
 // address is a block-uniform running pointer (one plane = slab_b bytes) + this thread's byte offset.
-template <bool MASKED, int G, bool NOSTORE = false>
+// TRACK: the ordered-integer key of the smallest value stored (the folded minimum of the launch's own output)
+template <bool MASKED, int G, bool NOSTORE = false, bool TRACK = false>
 __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float az, float bxs, float bys, float bzs, const FastAddr& ta,
                                                 char* out_generic, unsigned urow, int64_t slab_b, float ox, float oy, float oz, float hx,
-                                                float hy, float hz, float fillv) {
+                                                float hy, float hz, float fillv, uint32_t& kmin) {
   // The running pointer passes through an empty asm (to pin it to scalar registers), which hides its address space
   // from the compiler: it MUST be typed global here, or the stores become flat_store_dword — flat operations count
   // on lgkmcnt as well, so every wait for the LDS taps would also wait for the previous voxels' stores to be
@@ -182,6 +183,7 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
 #pragma unroll
       for (int q = 0; q < G; q++) {
         if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + urow) = vals[q];
+        if constexpr (TRACK) kmin = min(kmin, float_to_key(vals[q]));
         out_t += slab_b;
         asm volatile("" : "+s"(out_t));  // one running pointer (2 scalar adds per plane), not G precomputed ones
       }
@@ -190,6 +192,7 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
       for (int q = 0; q < G; q++) {
         if (tg + q < n) {
           if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + urow) = vals[q];
+          if constexpr (TRACK) kmin = min(kmin, float_to_key(vals[q]));
         }
         out_t += slab_b;
         asm volatile("" : "+s"(out_t));
@@ -268,10 +271,10 @@ __device__ __forceinline__ int fast_column_line(const FastFrameT<CP>& f, const L
 // Sample one run with the cheapest loop that is correct for it: the fill rule only matters where a tap can leave
 // the volume.  Each coordinate of the line is monotone, so a column whose two END planes keep all first taps in
 // [0, S - 2] is interior for the whole run; the wave takes the masked loop only if one of its columns is not.
-template <int GMAX>
+template <int GMAX, bool TRACK = false>
 __device__ __forceinline__ void fast_sample_line(int len, const float (&A3)[3], const float (&B3)[3], const FastAddr& ta, char* o, unsigned urow,
                                                  int64_t slab_b, bool needs_mask, float ox, float oy, float oz, float hx, float hy, float hz,
-                                                 float fillv) {
+                                                 float fillv, uint32_t& kmin) {
   bool masked = false;
   if (needs_mask) {
     const float el = static_cast<float>(len - 1);
@@ -283,10 +286,12 @@ __device__ __forceinline__ void fast_sample_line(int len, const float (&A3)[3], 
     masked = __builtin_amdgcn_ballot_w64(!inside) != 0ull;
   }
   if (!masked) {
-    if (GMAX == 8 && len > 4) fast_sample_run<false, 8>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv);
-    else fast_sample_run<false, 4>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv);
+    if (GMAX == 8 && len > 4)
+      fast_sample_run<false, 8, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv, kmin);
+    else
+      fast_sample_run<false, 4, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv, kmin);
   } else {  // rare (waves on the volume's surface): four voxels in flight keep the register budget of the common loop
-    fast_sample_run<true, 4>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, ox, oy, oz, hx, hy, hz, fillv);
+    fast_sample_run<true, 4, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, ox, oy, oz, hx, hy, hz, fillv, kmin);
   }
 }
 
@@ -440,25 +445,30 @@ __device__ __forceinline__ void pipe_vertex(const ResampleArgs& a, const FastFra
 //           of (i_begin, j_lo, k_lo) relative to the box origin   [10] b [11] i_begin [12] j_lo [13] k_lo [14] elastic
 //   batch:  [0..11] mapping rows scaled by the axis ratios (S_own - 1) / max(S_norm - 1, 1)
 // =====================================================================================================================
+// A group of lanes per brick, one vertex per lane: 32 lanes (27 busy) when the launch has control points — a vertex then
+// reads 24 control values, and one thread walking its 27 vertices one after the other made the planner a chain of 27
+// memory round trips (21.6 us per bench launch; side by side 16.4) — 8 lanes for affine-only launches (5.8 us either
+// way).  The extremes meet through shuffles inside the group; its lane 0 writes the descriptor.
+constexpr int plan_group(bool elastic_possible) { return elastic_possible ? 32 : 8; }
+
 template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK>
 __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, int* __restrict__ plan, int n_items) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int GROUP = plan_group(ELASTIC_POSSIBLE);
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const float ratio[3] = {a.half_h[0] / a.dh[0], a.half_h[1] / a.dh[1], a.half_h[2] / a.dh[2]};
-  if (t < a.B) {
-    const float* m = a.mapping + (a.mapping_batched ? t * 12 : 0);
-    float* fr = reinterpret_cast<float*>(plan) + t * 16;
+  if (gtid < a.B) {
+    const float* m = a.mapping + (a.mapping_batched ? gtid * 12 : 0);
+    float* fr = reinterpret_cast<float*>(plan) + gtid * 16;
     for (int q = 0; q < 12; q++) fr[q] = m[q] * ratio[q >> 2];
     for (int q = 12; q < 16; q++) fr[q] = 0.0f;
   }
-  if (t >= n_items) return;
+  const int t = gtid / GROUP, v = gtid % GROUP;
+  if (t >= n_items) return;  // (whole groups leave together: the shuffles below stay inside a group)
   PipePlan p;
   pipe_decode<TI, TJ, TK>(a, static_cast<unsigned>(t), p);
   int* d = plan + a.B * 16 + t * kDescInts;
-  d[10] = p.b; d[11] = p.i_begin; d[12] = p.j_lo; d[13] = p.k_lo; d[15] = 0;
   if (a.passthrough != nullptr && a.passthrough[p.b] != 0) {
-    d[0] = kDescGated;
-    for (int q = 1; q < 10; q++) d[q] = 0;
-    d[14] = 0;
+    for (int q = v; q < kDescInts; q += GROUP) d[q] = q == 0 ? kDescGated : (q == 10 ? p.b : (q == 11 ? p.i_begin : (q == 12 ? p.j_lo : (q == 13 ? p.k_lo : 0))));
     return;
   }
   FastFrameG f;
@@ -482,18 +492,24 @@ __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, 
     f.cp = f.elastic ? a.cp + (a.cp_batched ? static_cast<int64_t>(p.b) * (a.ni * a.nj * a.nk * 3) : 0) : nullptr;
   }
   pipe_brick_frame(f, p.j_lo, p.k_lo);
-  int ext[6] = {-0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000};
-  bool any_bad = false;
+  int ext[7] = {-0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, 0};
   const int n_vert = f.elastic ? 27 : 8;
-  for (int v = 0; v < n_vert; v++) {
+  if (v < n_vert) {
     int r[6]; bool bad;
     pipe_vertex(a, f, v, p.i_begin, p.i_count, p.nv, p.nw, r, bad);
 #pragma unroll
-    for (int q = 0; q < 6; q++) ext[q] = max(ext[q], r[q]);
-    any_bad |= bad;
+    for (int q = 0; q < 6; q++) ext[q] = r[q];
+    ext[6] = bad ? 1 : 0;
   }
+#pragma unroll
+  for (int s = GROUP / 2; s > 0; s >>= 1) {
+#pragma unroll
+    for (int q = 0; q < 7; q++) ext[q] = max(ext[q], __shfl_xor(ext[q], s));
+  }
+  if (v != 0) return;
+  d[10] = p.b; d[11] = p.i_begin; d[12] = p.j_lo; d[13] = p.k_lo; d[15] = 0;
   const int xmin = -ext[0], xmax = ext[1], ymin = -ext[2], ymax = ext[3], zmin = -ext[4], zmax = ext[5];
-  const bool wrd = weird | any_bad;
+  const bool wrd = weird | (ext[6] != 0);
   const int interior = (xmin >= 0) & (xmax + 1 <= a.I - 1) & (ymin >= 0) & (ymax + 1 <= a.J - 1) & (zmin >= 0) & (zmax + 1 <= a.K - 1) & !wrd;
   const int outside = ((xmax + 1 < 0) | (xmin > a.I - 1) | (ymax + 1 < 0) | (ymin > a.J - 1) | (zmax + 1 < 0) | (zmin > a.K - 1)) & !wrd;
   const int za = zmin & ~3, Lx = xmax + 2 - xmin, Ly = ymax + 2 - ymin, Lz = ((zmax + 1 + 4) & ~3) - za;
@@ -504,6 +520,21 @@ __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, 
 #pragma unroll
   for (int r = 0; r < 3; r++) d[7 + r] = __float_as_int(static_cast<float>(static_cast<double>(f.m[4 * r]) * p.i_begin + f.c[r] - org[r]));
   d[14] = f.elastic ? 1 : 0;
+}
+
+constexpr int kMinSlots = 64;  // keys per channel of the folded minimum
+
+// one 64-lane block per channel: the slots' minimum, decoded; the slots go back to all ones
+constexpr int kMinChannels = 16;  // channels of one launch that can fold their minimum (more: the plain reduction)
+struct MinOuts { float* p[kMinChannels]; };
+
+__global__ __launch_bounds__(kMinSlots) void min_finish_kernel(uint32_t* __restrict__ keys, const MinOuts outs, int n_channels) {
+  const int c = blockIdx.x;
+  if (c >= n_channels) return;
+  uint32_t* slot = keys + c * kMinSlots + threadIdx.x;
+  const uint32_t k = __hip_atomic_exchange(slot, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t m = wave_min_u32(k);
+  if (threadIdx.x == 0) *outs.p[c] = key_to_float(m);
 }
 
 // =====================================================================================================================
@@ -544,18 +575,35 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
   const unsigned urow = static_cast<unsigned>(col_off) * 4u;
   const int u0 = i_begin, u1 = i_begin + i_count;
 
+  // The folded minimum (ImgArgs::out_min): the waves of the FIRST batch element fold the keys of what they store into one
+  // of kMinSlots keys per channel (by brick, so that a few hundred — not sixteen thousand — atomics meet on an address;
+  // returnless: nobody waits for them); min_finish_kernel, launched behind this kernel, folds the slots, decodes the
+  // result into out_min[c] and restores the keys.  It replaces the three launches and the re-read of tio_channel_min
+  // for the next transform's "minimum" fill.  (A first version decoded in the last wave to finish, through a ticket
+  // counter and returning atomics: 0.40 -> 0.43 - 0.45 ms per launch, more than the reduction it saved.)
+  auto publish_min = [&](const ImgArgs& g, int c, uint32_t kmin) {
+    const uint32_t wmin = wave_min_u32(kmin);
+    if (lane == 0 && wmin != 0xFFFFFFFFu)
+      __hip_atomic_fetch_min(g.min_keys + c * kMinSlots + (brick & (kMinSlots - 1)), wmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
   if (kind == kDescGated || kind == kDescOutside) {  // gated-out element: bit-exact copy; nothing of the volume in sight: fill (or 0)
-    if (col_active) {
-      for (int im = 0; im < a.n_images; im++) {
-        const ImgArgs& g = a.img[im];
-        for (int c = 0; c < g.channels; c++) {
-          const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
-          char* out_chan = static_cast<char*>(g.out) + bc * n_out * 4;
-          const float* in_chan = static_cast<const float*>(g.in) + bc * n_in;
-          const float fillv = g.fill != nullptr ? ((const_float_ptr)g.fill)[c] : 0.0f;
-          for (int t = u0; t < u1; t++)
-            *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = kind == kDescGated ? in_chan[static_cast<int64_t>(t) * slab + col_off] : fillv;
+    for (int im = 0; im < a.n_images; im++) {
+      const ImgArgs& g = a.img[im];
+      for (int c = 0; c < g.channels; c++) {
+        const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
+        char* out_chan = static_cast<char*>(g.out) + bc * n_out * 4;
+        const float* in_chan = static_cast<const float*>(g.in) + bc * n_in;
+        const float fillv = g.fill != nullptr ? ((const_float_ptr)g.fill)[c] : 0.0f;
+        uint32_t kmin = 0xFFFFFFFFu;
+        if (col_active) {
+          for (int t = u0; t < u1; t++) {
+            const float val = kind == kDescGated ? in_chan[static_cast<int64_t>(t) * slab + col_off] : fillv;
+            *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
+            kmin = min(kmin, float_to_key(val));
+          }
         }
+        if (g.out_min != nullptr && b == 0) publish_min(g, c, kmin);
       }
     }
     return;
@@ -581,12 +629,23 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
 
   if (kind == kDescSlow) {  // box beyond the LDS budget / non-finite geometry: per-voxel evaluation, global gathers (rare)
     pipe_brick_frame(f, j_lo, k_lo);
-    if (col_active) {
-      for (int im = 0; im < a.n_images; im++) {
+    for (int im = 0; im < a.n_images; im++) {
+      const ImgArgs& g = a.img[im];
+      if (col_active) {
         for (int t = u0; t < u1; t++) {
           float x, y, z;
           fast_coord(f, static_cast<float>(t), static_cast<float>(jv), static_cast<float>(kw), x, y, z);
-          gather_voxel<0>(a.img[im], a, b, n_in, n_out, t * slab + col_off, x, y, z, false);
+          gather_voxel<0>(g, a, b, n_in, n_out, t * slab + col_off, x, y, z, false);
+        }
+      }
+      if (g.out_min != nullptr && b == 0) {  // (this thread reads back what it has just stored)
+        for (int c = 0; c < g.channels; c++) {
+          uint32_t kmin = 0xFFFFFFFFu;
+          if (col_active) {
+            const float* out_chan = static_cast<const float*>(g.out) + (static_cast<int64_t>(b) * g.channels + c) * n_out;
+            for (int t = u0; t < u1; t++) kmin = min(kmin, float_to_key(out_chan[static_cast<int64_t>(t) * slab + col_off]));
+          }
+          publish_min(g, c, kmin);
         }
       }
     }
@@ -637,15 +696,22 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
       int run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3);
       tile_dma_wait();
       __syncthreads();
+      const bool track = g.out_min != nullptr && b == 0;  // block uniform
+      uint32_t kmin = 0xFFFFFFFFu;
       if (col_active && !(a.ablate & 2)) {
         for (;;) {
-          fast_sample_line<4>(run1 - run0, A3, B3, ta, out_chan + static_cast<int64_t>(run0) * slab_b, urow, slab_b, has_fill & !bx.interior, ox, oy, oz, hx,
-                              hy, hz, fillv);
+          if (track)
+            fast_sample_line<4, true>(run1 - run0, A3, B3, ta, out_chan + static_cast<int64_t>(run0) * slab_b, urow, slab_b, has_fill & !bx.interior, ox,
+                                      oy, oz, hx, hy, hz, fillv, kmin);
+          else
+            fast_sample_line<4, false>(run1 - run0, A3, B3, ta, out_chan + static_cast<int64_t>(run0) * slab_b, urow, slab_b, has_fill & !bx.interior, ox,
+                                       oy, oz, hx, hy, hz, fillv, kmin);
           run0 = run1;
           if (run0 >= u1) break;
           run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3);
         }
       }
+      if (track) publish_min(g, c, kmin);
     }
   }
 }

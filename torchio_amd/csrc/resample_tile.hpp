@@ -59,6 +59,12 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return max(max(r0, r1), max(r2, r3));
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  // unsigned order of v = signed order of v ^ 0x80000000; complementing reverses it without overflow: min = ~max(~.)
+  const int flipped = static_cast<int>((~v) ^ 0x80000000u);
+  return ~(static_cast<uint32_t>(wave_max_i32(flipped)) ^ 0x80000000u);
+}
+
 // block-wide max of N <= 8 values; every call uses its own LDS slot, so one barrier per call
 template <int NW, int N>
 __device__ __forceinline__ void block_max6(int (&r)[N], int* s_red, int slot, int wave, int lane) {

@@ -32,8 +32,8 @@ def enabled() -> bool:
 class Pending:
     """What has been promised for a batch's tensor but not launched yet (in application order)."""
 
-    bias_coarse: Tensor | None = None       # (B, C, si, sj, sk) float32 on the device
-    blur: tuple | None = None               # (taps (n, 3, stride) device tensor, radius [3])
+    bias_coarse: Tensor | None = None       # (B, C, si, sj, sk) float32, still on the HOST (flush uploads everything at once)
+    blur: tuple | None = None               # (taps (n, 3, stride) float32 host tensor, radius [3])
     notes: list[str] = field(default_factory=list)
 
     def is_empty(self) -> bool:
@@ -50,6 +50,19 @@ def flush(data: Tensor, pending: Pending, *, noise: tuple | None = None) -> Tens
     from .. import ops  # noqa: PLC0415
 
     engine = ops.engine()
+    # the queued parameter blocks are still on the host: one staging copy for all of them (and the noise vectors)
+    mean = std = None
+    if noise is not None:
+        mean, std = noise[0], noise[1]
+    host_mean = mean if isinstance(mean, Tensor) and mean.device.type == "cpu" else None
+    host_std = std if isinstance(std, Tensor) and std.device.type == "cpu" else None
+    taps_host = pending.blur[0] if pending.blur is not None else None
+    coarse_dev, taps_dev, mean_dev, std_dev = ops.h2d_packed([pending.bias_coarse, taps_host, host_mean, host_std], data.device)
+    pending.bias_coarse = coarse_dev
+    if pending.blur is not None:
+        pending.blur = (taps_dev, pending.blur[1])
+    if noise is not None:
+        noise = (mean_dev if host_mean is not None else mean, std_dev if host_std is not None else std, noise[2])
     if pending.blur is not None:
         taps, radius = pending.blur
         fused = engine.blur_fused(data, taps, radius, bias_coarse=pending.bias_coarse, noise=noise)

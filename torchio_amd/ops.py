@@ -10,6 +10,7 @@ reference transform.py:220-221).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections.abc import Sequence
 
 import torch
@@ -69,6 +70,43 @@ def h2d(tensor: Tensor, device) -> Tensor:
     if device.type != "cuda" or tensor.device.type != "cpu":
         return tensor.to(device)
     return tensor.contiguous().pin_memory().to(device, non_blocking=True)
+
+
+def h2d_packed(tensors: Sequence[Tensor | None], device) -> list[Tensor | None]:
+    """Upload several small float32 host tensors with ONE staging copy; returns device views of the same shapes.
+
+    Each stream-ordered upload is a ~4 us copy kernel plus a ~6 us gap on the GPU's timeline, in front of whatever needs
+    it; a transform (or a fused launch of three) that needs three parameter blocks pays that three times.  Entries that are
+    ``None`` or already on the device pass through.  Segments start on 256-byte boundaries (vector loads in the kernels).
+    """
+    device = torch.device(device)
+    todo = [i for i, t in enumerate(tensors) if t is not None and t.device.type == "cpu"]
+    out: list[Tensor | None] = list(tensors)
+    if device.type != "cuda" or not todo:
+        return [None if t is None else t.to(device) for t in tensors]
+    if len(todo) == 1:
+        out[todo[0]] = h2d(tensors[todo[0]].to(torch.float32), device)
+        return out
+    offsets, total = [], 0
+    for i in todo:
+        offsets.append(total)
+        total += (tensors[i].numel() + 63) // 64 * 64
+    staging = torch.empty(total, dtype=torch.float32).pin_memory()
+    for i, off in zip(todo, offsets, strict=True):
+        staging[off : off + tensors[i].numel()] = tensors[i].reshape(-1).to(torch.float32)
+    block = staging.to(device, non_blocking=True)
+    for i, off in zip(todo, offsets, strict=True):
+        out[i] = block[off : off + tensors[i].numel()].view(tensors[i].shape)
+    return out
+
+
+def folded_channel_min(data: Tensor) -> Tensor | None:
+    """The per-channel minimum of element 0 that the launch which produced *data* left behind, if it did and the
+    tensor has not been written since (``Engine.resample3d``); ``None`` otherwise."""
+    record = getattr(data, "_tio_channel_min", None)
+    if record is None or record[0] != data._version:
+        return None
+    return record[1]
 
 
 class EngineError(RuntimeError):
@@ -309,6 +347,22 @@ class Engine:
             if _adjoint_of is None and _wants_grad(t) and not wants[n]:
                 raise EngineError("resample3d: only floating-point images resampled trilinearly are differentiable")
 
+        # The folded minimum (opt-in, TIO_FOLDED_MIN=1): a large FAST launch can hand back the per-channel minimum of
+        # element 0 of each output (tio_resample_image.out_min_dev), which is what the NEXT spatial transform's
+        # default_pad_value="minimum" will ask of exactly this tensor (`folded_channel_min`).  Measured on the bench step
+        # (DESIGN.md section 7): the tracking costs every planned launch ~17 us, the reduction it saves is ~26 us for the
+        # one consumer that exists — a wash, and a loss for pipelines whose next transform is not spatial — so it is off
+        # by default.  Requested only where the C side folds it (the rule of resample.hip's planned path, mirrored
+        # loosely: a miss costs one tio_channel_min launch, never a wrong value).
+        codes = [INTERP_CODES[i] if isinstance(i, str) else int(i) for i in interps]
+        bricks = batch * -(-out_shape[0] // 16) * -(-out_shape[1] // 16) * -(-out_shape[2] // 16)
+        fold_min = (
+            _adjoint_of is None and geom.precision == _abi.PRECISION_FAST and bricks >= 12288 and not any(wants)
+            and len(images) <= _abi.MAX_IMAGES and all(t.dtype == torch.float32 for t in images) and all(c == _abi.LINEAR for c in codes)
+            and os.environ.get("TIO_FOLDED_MIN", "") not in ("", "0")
+        )
+        folded: list[Tensor | None] = []
+
         outputs: list[Tensor] = []
         for start in range(0, len(images), _abi.MAX_IMAGES):
             chunk = range(start, min(start + _abi.MAX_IMAGES, len(images)))
@@ -346,10 +400,16 @@ class Engine:
                         descs[slot].n_labels = table.numel()
                     descs[slot].pad_label = 0.0 if pad_labels is None else float(pad_labels[n])
                     keep_alive.append(table)
+                minimum = torch.empty(data.shape[1], dtype=torch.float32, device=data.device) if fold_min else None
+                descs[slot].out_min_dev = None if minimum is None else minimum.data_ptr()
+                folded.append(minimum)
                 keep_alive += [data, fill]
                 outputs.append(out)
             self._call("resample3d", first, C.byref(geom), len(chunk), descs, self._stream(first))
         del keep_alive
+        for out, minimum in zip(outputs, folded, strict=True):
+            if minimum is not None:
+                out._tio_channel_min = (out._version, minimum)
         if _adjoint_of is not None:
             return [t for t in images]  # the accumulators now hold dL/d(input)
         if any(wants):

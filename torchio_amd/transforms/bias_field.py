@@ -110,7 +110,7 @@ def _defer_bias(img_batch, std, seed, scale: float, per_element: bool) -> bool:
         coarse = torch.cat(fields, dim=0)
     else:
         coarse = _sample_coarse_field(data.shape, std=std, scale=scale, seed=seed)
-    img_batch._pending = _pending.Pending(bias_coarse=ops.h2d(coarse, data.device))
+    img_batch._pending = _pending.Pending(bias_coarse=coarse)  # host tensor: uploaded by the flush, with its neighbours' blocks
     return True
 
 

@@ -91,7 +91,7 @@ def _defer_blur(img_batch, sigmas) -> bool:
         queue = None
     if queue is None:
         queue = _pending.Pending()
-    queue.blur = (ops.h2d(taps, raw.device), [int(r) for r in radius])
+    queue.blur = (taps, [int(r) for r in radius])  # host tensor: uploaded by the flush, with its neighbours' blocks
     img_batch._pending = queue
     return True
 

@@ -90,11 +90,9 @@ class Noise(IntensityTransform):
                 and _pending.eligible(img_batch._data)
             ):  # a Blur is still queued on this tensor: the noise rides on its stores
                 device = img_batch._data.device
-                if isinstance(mean, list) and isinstance(std, list):  # one staging upload for both vectors
-                    mean_arg, std_arg = ops.h2d(torch.tensor([mean, std], dtype=torch.float32), device)
-                else:
-                    mean_arg = ops.h2d(torch.tensor(mean, dtype=torch.float32), device) if isinstance(mean, list) else mean
-                    std_arg = ops.h2d(torch.tensor(std, dtype=torch.float32), device) if isinstance(std, list) else std
+                # per-element vectors stay on the host: the flush uploads them with the queued bias / blur blocks
+                mean_arg = torch.tensor(mean, dtype=torch.float32) if isinstance(mean, list) else mean
+                std_arg = torch.tensor(std, dtype=torch.float32) if isinstance(std, list) else std
                 img_batch._flush(noise=(mean_arg, std_arg, (index << 32) | int(seed)))
                 continue
             data = img_batch.data

@@ -744,7 +744,8 @@ def _fill_value(engine, img_batch: ImagesBatch, *, default_pad_value, default_pa
     elif not isinstance(default_pad_value, str):
         raise TypeError(f"default_pad_value must be a string or number, got {type(default_pad_value)}")
     elif default_pad_value == "minimum":
-        return engine.channel_min(data)  # stays on the device: no .item() sync
+        folded = ops.folded_channel_min(data)  # the resampler that wrote this tensor may have left it behind
+        return folded if folded is not None else engine.channel_min(data)  # stays on the device: no .item() sync
     elif default_pad_value in ("mean", "otsu"):
         values = [_compute_channel_pad_value(channel, default_pad_value) for channel in data[0]]
         return ops.h2d(torch.tensor(values, dtype=torch.float32), data.device)
