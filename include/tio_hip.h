@@ -81,7 +81,19 @@ typedef enum tio_interp {
    * g * w_t to its in-bounds taps (hardware float atomics: the order of the additions is not defined).  A
    * non-NULL fill_dev means the forward pass used a fill value: voxels whose in-bounds weight is <= 0.5 took the
    * fill and carry no gradient.  Same geometry struct, same coordinate arithmetic as the forward launch.     */
-  TIO_LINEAR_ADJOINT = 3
+  TIO_LINEAR_ADJOINT = 3,
+  /* B-spline interpolation of order 2 / 3 — the reference's orders >= 2 go to torch-interpol (spatial.py:1734-1761:
+   * interpol.grid_pull(data.float(), grid, interpolation=order, bound="dct2", extrapolate=False, prefilter=True)).
+   * Here `in` holds the B-spline COEFFICIENTS of the image (float32, tio_bspline_prefilter), `out` is float32 (the
+   * caller casts back like `.to(data.dtype)`), and each output voxel is the (order + 1)^3-tap sum of the basis weights at
+   * its voxel coordinate — the coordinate the reference hands to grid_pull, i.e. BEFORE grid_sample's normalise /
+   * un-normalise round trip — with half-sample-symmetric ("dct2") index reflection, and zero wherever a coordinate lies
+   * outside (-0.05, S - 1 + 0.05) (grid_pull's extrapolate=False mask); fill_dev is ignored, as the reference ignores
+   * its fill value on this road.  torch-interpol is not vendored by the reference (pyproject.toml:46) and absent from
+   * the build image: the arithmetic follows its published algorithm, pinned against scipy.ndimage (mode="reflect",
+   * the same extension) instead of against the package itself — "parity unpinned" in DESIGN.md.                      */
+  TIO_QUADRATIC = 4,
+  TIO_CUBIC = 5
 } tio_interp;
 
 /* ------------------------------------------------------------------------ */
@@ -281,6 +293,15 @@ int tio_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch,
 /* ------------------------------------------------------------------------ */
 /* F.interpolate users: Resize, Anisotropy                */
 /* ------------------------------------------------------------------------ */
+
+/*
+ * B-spline coefficients of a (B * C) stack of volumes for tio_resample3d's TIO_QUADRATIC / TIO_CUBIC images: the
+ * recursive prefilter of order `order` (2: pole sqrt(8) - 3, 3: pole sqrt(3) - 2) along I, J, K with the
+ * half-sample-symmetric ("dct2") boundary — what grid_pull(prefilter=True, bound="dct2") applies before sampling
+ * (spatial.py:1753-1760).  x has `dtype`, y is float32 of the same shape.
+ */
+int tio_bspline_prefilter(const void* x, float* y, int32_t dtype, int64_t n_batch_channels, const int32_t shape[3],
+                          int32_t order, void* stream);
 
 /*
  * F.interpolate(x.float(), size=out_shape, mode=...).to(x.dtype) on a dense

@@ -5,7 +5,11 @@
  * this file; it is used by tests/, __graft_entry__.smoke() and the
  * `cpu_baseline` leg of bench.py as the checker / baseline.
  *
- * Parity status: PINNED.  Every function below is checked bit-for-bit (integer /
+ * Parity status: PINNED — except the B-spline functions (spline_*, tio_oracle_bspline_prefilter and the TIO_QUADRATIC /
+ * TIO_CUBIC branch of tio_oracle_resample3d): the reference delegates those orders to torch-interpol, which is neither
+ * vendored under /root/reference nor installed here; they restate its published algorithm and are pinned against
+ * scipy.ndimage instead (tests/test_bspline.py).  THEIR PARITY WITH THE REFERENCE IS UNPINNED.
+ * Every other function below is checked bit-for-bit (integer /
  * nearest results) or to 1e-5 (float results) against outputs of the unmodified
  * reference (TorchIO 2.0.0a2 on torch 2.10.0 CPU kernels, run in the build
  * container by tests/golden/make_golden.py); the vectors live in tests/golden/.
@@ -316,6 +320,106 @@ static void label_pv_voxel(const tio_resample_image* img, const double* labels, 
   store_from_double(img->out, img->dtype, out_index, in_bounds ? labels[winner] : img->pad_label);
 }
 
+/* ---- B-spline orders 2 / 3 (torch-interpol's published algorithm; see include/tio_hip.h: TIO_QUADRATIC) ---------
+ * Restated from the package's documented behaviour, NOT from its source (it is not vendored by the reference and not
+ * installed here): basis weights of Unser's B-splines, `dct2` (half-sample symmetric) index reflection, the
+ * extrapolate=False mask with its 0.05-voxel tolerance.  Pinned against scipy.ndimage.map_coordinates /
+ * spline_filter(mode="reflect") in tests/test_bspline.py.  PARITY WITH THE REFERENCE ITSELF IS UNPINNED. */
+static inline int spline_reflect(int i, int n) { /* dct2: ... c b a | a b c ... */
+  const int n2 = 2 * n;
+  if (i < 0) i = -i - 1;
+  i %= n2;
+  return i >= n ? n2 - i - 1 : i;
+}
+
+static inline void spline_weights(float x, int order, int* low, float w[4]) {
+  if (order == 2) {
+    const float c = floorf(x + 0.5f); /* nearest node */
+    const float t = x - c;            /* [-0.5, 0.5] */
+    *low = (int)c - 1;
+    w[0] = 0.5f * (0.5f - t) * (0.5f - t);
+    w[1] = 0.75f - t * t;
+    w[2] = 0.5f * (0.5f + t) * (0.5f + t);
+    w[3] = 0.0f;
+  } else {
+    const float f = floorf(x);
+    const float t = x - f; /* [0, 1) */
+    const float u = 1.0f - t;
+    *low = (int)f - 1;
+    w[0] = u * u * u / 6.0f;
+    w[1] = (t * t * (t - 2.0f) * 3.0f + 4.0f) / 6.0f;
+    w[2] = (u * u * (u - 2.0f) * 3.0f + 4.0f) / 6.0f;
+    w[3] = t * t * t / 6.0f;
+  }
+}
+
+static float spline_sample(const float* coef, int32_t I, int32_t J, int32_t K, float vi, float vj, float vk, int order) {
+  const float tiny = 5e-2f;
+  if (!(vi > -tiny && vi < (float)(I - 1) + tiny && vj > -tiny && vj < (float)(J - 1) + tiny && vk > -tiny && vk < (float)(K - 1) + tiny))
+    return 0.0f; /* extrapolate=False (NaN coordinates land here too) */
+  int li, lj, lk;
+  float wi[4], wj[4], wk[4];
+  spline_weights(vi, order, &li, wi);
+  spline_weights(vj, order, &lj, wj);
+  spline_weights(vk, order, &lk, wk);
+  float val = 0.0f;
+  for (int a = 0; a <= order; a++) {
+    const int64_t ia = spline_reflect(li + a, I);
+    for (int b = 0; b <= order; b++) {
+      const int64_t jb = spline_reflect(lj + b, J);
+      const float wab = wi[a] * wj[b];
+      for (int c = 0; c <= order; c++) {
+        const int64_t kc = spline_reflect(lk + c, K);
+        const float wabc = wab * wk[c];
+        val = val + wabc * coef[(ia * J + jb) * K + kc];
+      }
+    }
+  }
+  return val;
+}
+
+/* one line of the recursive prefilter, in place (stride in elements); float32 like the reference's data.float() */
+static void spline_filter_line(float* c, int64_t n, int64_t stride, int order) {
+  const float z = order == 2 ? -0.17157287525380990f : -0.26794919243112270f; /* sqrt(8) - 3, sqrt(3) - 2 */
+  if (n < 2) return;
+  const float gain = (1.0f - z) * (1.0f - 1.0f / z);
+  for (int64_t i = 0; i < n; i++) c[i * stride] = c[i * stride] * gain;
+  /* causal initialisation for the half-sample symmetric extension (closed form of the infinite mirrored sum) */
+  float z_i = z;
+  float z_n = 1.0f; /* z^n by repeated multiplication: the same n products on every implementation (no pow) */
+  for (int64_t i = 0; i < n; i++) z_n = z_n * z;
+  const float c0 = c[0];
+  float acc = c[0] + z_n * c[(n - 1) * stride];
+  for (int64_t i = 1; i < n; i++) {
+    acc = acc + z_i * (c[i * stride] + z_n * c[(n - 1 - i) * stride]);
+    z_i = z_i * z;
+  }
+  acc = acc * (z / (1.0f - z_n * z_n));
+  c[0] = acc + c0;
+  for (int64_t i = 1; i < n; i++) c[i * stride] = c[i * stride] + z * c[(i - 1) * stride];
+  c[(n - 1) * stride] = c[(n - 1) * stride] * (z / (z - 1.0f));
+  for (int64_t i = n - 2; i >= 0; i--) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
+}
+
+int tio_oracle_bspline_prefilter(const void* x, float* y, int32_t dtype, int64_t n_bc, const int32_t shape[3], int32_t order,
+                                 void* stream) {
+  (void)stream;
+  if (!x || !y || !shape || (order != 2 && order != 3) || dtype_size(dtype) == 0) return TIO_ERR_INVALID_ARGUMENT;
+  const int64_t I = shape[0], J = shape[1], K = shape[2], n = I * J * K;
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < n_bc; v++) {
+    float* c = y + v * n;
+    for (int64_t q = 0; q < n; q++) c[q] = load_as_float(x, dtype, v * n + q);
+    for (int64_t j = 0; j < J; j++)
+      for (int64_t k = 0; k < K; k++) spline_filter_line(c + j * K + k, I, J * K, order);
+    for (int64_t i = 0; i < I; i++)
+      for (int64_t k = 0; k < K; k++) spline_filter_line(c + i * J * K + k, J, K, order);
+    for (int64_t i = 0; i < I; i++)
+      for (int64_t j = 0; j < J; j++) spline_filter_line(c + (i * J + j) * K, K, 1, order);
+  }
+  return TIO_OK;
+}
+
 int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
                           const tio_resample_image* images, void* stream) {
   (void)stream;
@@ -441,6 +545,11 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
               const int64_t base_in = ((int64_t)b * img->channels + c) * n_in;
               const int64_t base_out = ((int64_t)b * img->channels + c) * n_out;
               float val;
+              if (img->interp == TIO_QUADRATIC || img->interp == TIO_CUBIC) { /* coefficients in, float32 out */
+                ((float*)img->out)[base_out + o_idx] =
+                    spline_sample((const float*)img->in + base_in, I, J, K, vi, vj, vk, img->interp == TIO_QUADRATIC ? 2 : 3);
+                continue;
+              }
               if (img->interp == TIO_LINEAR_ADJOINT) { /* backward of TIO_LINEAR: d(val)/d(in[tap]) = w[tap] */
                 if (img->fill_dev && !(mask > 0.5f)) continue; /* the fill was taken: no gradient */
                 const float gv = ((const float*)img->out)[base_out + o_idx];

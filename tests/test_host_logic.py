@@ -93,7 +93,7 @@ def test_constructor_validation_matches_reference_errors():
 def test_unsupported_modes_raise_instead_of_falling_back():
     s = subject()
     with pytest.raises(NotImplementedError, match="not implemented by the HIP engine"):
-        tio.Affine(degrees=(5, 5), image_interpolation="cubic")(s)
+        tio.Affine(degrees=(5, 5), image_interpolation="fourth")(s)  # (orders 2 and 3 are: tests/test_bspline.py)
     with pytest.raises(NotImplementedError, match="one_hot_label_interpolation"):
         tio.Affine(degrees=(5, 5), label_interpolation="label", one_hot_label_interpolation="cubic")(s)
 

@@ -18,7 +18,7 @@ UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing
 # tio_dtype (values fixed by include/tio_hip.h)
 F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
 # tio_interp
-NEAREST, LINEAR, LABEL_PV, LINEAR_ADJOINT = 0, 1, 2, 3
+NEAREST, LINEAR, LABEL_PV, LINEAR_ADJOINT, QUADRATIC, CUBIC = 0, 1, 2, 3, 4, 5
 # tio_pad_mode
 PAD_CONSTANT, PAD_REFLECT, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2, 3
 # tio_precision
@@ -108,6 +108,7 @@ PROTOTYPES = {
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, _I32x3,
          C.POINTER(PatchPlacement), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "bspline_prefilter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, _I32x3, C.c_int32, C.c_void_p]),
     "interpolate3d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, _I32x3, _I32x3, C.c_int32, C.c_void_p]),
     "axis_gather_lerp": (
         C.c_int,

@@ -358,3 +358,90 @@ extern "C" int tio_pad3d(const void* x, void* y, int32_t dtype, int32_t batch, i
     default: return launch_stream(pad_kernel<8>, a, total, s, "tio_pad3d");
   }
 }
+
+// =====================================================================================================================
+// tio_bspline_prefilter: B-spline coefficients of orders 2 / 3, half-sample-symmetric boundary (include/tio_hip.h).
+// One thread per line of the axis being filtered, the line in place in global memory, the same operations in the same
+// order as oracle/tio_oracle.c (spline_filter_line).  Lines along I and J are coalesced across a wave (neighbouring
+// threads = neighbouring k); lines along K are not — this is the straightforward version of a path the headline
+// pipeline does not use.
+// =====================================================================================================================
+namespace tio {
+
+template <int DT>
+__global__ __launch_bounds__(256) void bspline_load_kernel(const void* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = Elem<DT>::load(x, i);
+}
+
+__global__ __launch_bounds__(256) void bspline_axis_kernel(float* __restrict__ c, int64_t n_lines, int I, int J, int K, int axis, int order) {
+  const int64_t line = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (line >= n_lines) return;
+  int64_t base, stride;
+  int n;
+  if (axis == 0) {  // lines (v, j, k)
+    const int64_t jk = static_cast<int64_t>(J) * K;
+    const int64_t v = line / jk, r = line - v * jk;
+    base = v * I * jk + r; stride = jk; n = I;
+  } else if (axis == 1) {  // lines (v, i, k)
+    const int64_t vi = line / K, k = line - vi * K;
+    base = vi * J * K + k; stride = K; n = J;
+  } else {  // lines (v, i, j)
+    base = line * K; stride = 1; n = K;
+  }
+  if (n < 2) return;
+  float* p = c + base;
+  const float z = order == 2 ? -0.17157287525380990f : -0.26794919243112270f;
+  const float gain = __fmul_rn(__fsub_rn(1.0f, z), __fsub_rn(1.0f, __fdiv_rn(1.0f, z)));
+  for (int i = 0; i < n; i++) p[i * stride] = __fmul_rn(p[i * stride], gain);
+  float z_n = 1.0f;
+  for (int i = 0; i < n; i++) z_n = __fmul_rn(z_n, z);
+  float z_i = z;
+  const float c0 = p[0];
+  float acc = __fadd_rn(p[0], __fmul_rn(z_n, p[(n - 1) * stride]));
+  for (int i = 1; i < n; i++) {
+    acc = __fadd_rn(acc, __fmul_rn(z_i, __fadd_rn(p[i * stride], __fmul_rn(z_n, p[(n - 1 - i) * stride]))));
+    z_i = __fmul_rn(z_i, z);
+  }
+  acc = __fmul_rn(acc, __fdiv_rn(z, __fsub_rn(1.0f, __fmul_rn(z_n, z_n))));
+  float prev = __fadd_rn(acc, c0);
+  p[0] = prev;
+  for (int i = 1; i < n; i++) {
+    prev = __fadd_rn(p[i * stride], __fmul_rn(z, prev));
+    p[i * stride] = prev;
+  }
+  prev = __fmul_rn(prev, __fdiv_rn(z, __fsub_rn(z, 1.0f)));
+  p[(n - 1) * stride] = prev;
+  for (int i = n - 2; i >= 0; i--) {
+    prev = __fmul_rn(z, __fsub_rn(prev, p[i * stride]));
+    p[i * stride] = prev;
+  }
+}
+
+}  // namespace tio
+
+extern "C" int tio_bspline_prefilter(const void* x, float* y, int32_t dtype, int64_t n_bc, const int32_t shape[3], int32_t order,
+                                     void* stream) {
+  using namespace tio;
+  if (x == nullptr || y == nullptr || shape == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bspline_prefilter: null argument");
+  if (order != 2 && order != 3) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bspline_prefilter: order %d (2 and 3 are implemented)", order);
+  if (dtype_size(dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_bspline_prefilter: dtype %d", dtype);
+  if (n_bc < 0 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bspline_prefilter: bad shape");
+  if (n_bc == 0) return TIO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int I = shape[0], J = shape[1], K = shape[2];
+  const int64_t n = n_bc * I * J * K;
+  const unsigned blocks = static_cast<unsigned>((n + 255) / 256);
+  switch (dtype) {
+#define TIO_CASE(DT) case DT: hipLaunchKernelGGL((bspline_load_kernel<DT>), dim3(blocks), dim3(256), 0, s, x, y, n); break;
+    TIO_CASE(TIO_F32) TIO_CASE(TIO_F64) TIO_CASE(TIO_F16) TIO_CASE(TIO_BF16) TIO_CASE(TIO_U8) TIO_CASE(TIO_I8) TIO_CASE(TIO_I16)
+    TIO_CASE(TIO_I32) TIO_CASE(TIO_I64)
+#undef TIO_CASE
+    default: return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_bspline_prefilter: dtype %d", dtype);
+  }
+  for (int axis = 0; axis < 3; axis++) {
+    const int64_t lines = n / shape[axis];
+    hipLaunchKernelGGL(bspline_axis_kernel, dim3(static_cast<unsigned>((lines + 255) / 256)), dim3(256), 0, s, y, lines, I, J, K, axis, order);
+  }
+  return check_launch("tio_bspline_prefilter");
+}

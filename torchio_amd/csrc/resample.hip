@@ -243,8 +243,66 @@ namespace tio {
 // LABEL_PV = true: the same coordinates, every image resampled in the "label"
 // partial-volume mode (resample_label.hpp); launched separately so that the intensity
 // kernels carry none of its registers.
-template <bool ELASTIC_POSSIBLE, int DTMODE, bool LABEL_PV = false>
+// B-spline orders 2 / 3 (include/tio_hip.h: TIO_QUADRATIC): same operations, same order as oracle/tio_oracle.c
+__device__ __forceinline__ int spline_reflect(int i, int n) {
+  const int n2 = 2 * n;
+  if (i < 0) i = -i - 1;
+  i %= n2;
+  return i >= n ? n2 - i - 1 : i;
+}
+
+__device__ __forceinline__ void spline_weights(float x, int order, int& low, float (&w)[4]) {
+  if (order == 2) {
+    const float c = floorf(__fadd_rn(x, 0.5f));
+    const float t = __fsub_rn(x, c);
+    low = static_cast<int>(c) - 1;
+    const float m = __fsub_rn(0.5f, t), p = __fadd_rn(0.5f, t);
+    w[0] = __fmul_rn(__fmul_rn(0.5f, m), m);
+    w[1] = __fsub_rn(0.75f, __fmul_rn(t, t));
+    w[2] = __fmul_rn(__fmul_rn(0.5f, p), p);
+    w[3] = 0.0f;
+  } else {
+    const float f = floorf(x);
+    const float t = __fsub_rn(x, f);
+    const float u = __fsub_rn(1.0f, t);
+    low = static_cast<int>(f) - 1;
+    w[0] = __fdiv_rn(__fmul_rn(__fmul_rn(u, u), u), 6.0f);
+    w[1] = __fdiv_rn(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn(t, t), __fsub_rn(t, 2.0f)), 3.0f), 4.0f), 6.0f);
+    w[2] = __fdiv_rn(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn(u, u), __fsub_rn(u, 2.0f)), 3.0f), 4.0f), 6.0f);
+    w[3] = __fdiv_rn(__fmul_rn(__fmul_rn(t, t), t), 6.0f);
+  }
+}
+
+__device__ __forceinline__ float spline_sample(const float* __restrict__ coef, int I, int J, int K, float vi, float vj, float vk, int order) {
+  const float tiny = 5e-2f;
+  if (!((vi > -tiny) & (vi < __fadd_rn(static_cast<float>(I - 1), tiny)) & (vj > -tiny) & (vj < __fadd_rn(static_cast<float>(J - 1), tiny)) &
+        (vk > -tiny) & (vk < __fadd_rn(static_cast<float>(K - 1), tiny))))
+    return 0.0f;
+  int li, lj, lk;
+  float wi[4], wj[4], wk[4];
+  spline_weights(vi, order, li, wi);
+  spline_weights(vj, order, lj, wj);
+  spline_weights(vk, order, lk, wk);
+  float val = 0.0f;
+  for (int p = 0; p <= order; p++) {
+    const int64_t ia = spline_reflect(li + p, I);
+    for (int q = 0; q <= order; q++) {
+      const int64_t jb = spline_reflect(lj + q, J);
+      const float wab = __fmul_rn(wi[p], wj[q]);
+      for (int r = 0; r <= order; r++) {
+        const int64_t kc = spline_reflect(lk + r, K);
+        const float wabc = __fmul_rn(wab, wk[r]);
+        val = __fadd_rn(val, __fmul_rn(wabc, coef[(ia * J + jb) * K + kc]));
+      }
+    }
+  }
+  return val;
+}
+
+// MODE: 0 = nearest / trilinear images, 1 = "label" partial-volume images, 2 = B-spline images (coefficients in, float32 out)
+template <bool ELASTIC_POSSIBLE, int DTMODE, int MODE = 0>
 __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const ResampleArgs a) {
+  constexpr bool LABEL_PV = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) float s_cp[];
 
   // tile decode: XCD-contiguous chunks of (b, it, jt, kt), kt fastest
@@ -360,6 +418,18 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
       vk = TIO_AFFINE_ROW(m20, m21, m22, m23, ci, cj, ck);
     }
 #undef TIO_AFFINE_ROW
+    if constexpr (MODE == 2) {  // grid_pull takes the voxel coordinates as they are (spatial.py:1749-1760)
+      const int64_t o_idx = io * slab + row;
+      for (int im = 0; im < a.n_images; im++) {
+        const ImgArgs& g = a.img[im];
+        for (int c = 0; c < g.channels; c++) {
+          const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
+          static_cast<float*>(g.out)[bc * n_out + o_idx] =
+              spline_sample(static_cast<const float*>(g.in) + bc * n_in, a.I, a.J, a.K, vi, vj, vk, g.interp == TIO_QUADRATIC ? 2 : 3);
+        }
+      }
+      continue;
+    }
     // torchio axis i ≡ grid x ≡ ATen W ; j ≡ y ≡ H ; k ≡ z ≡ D
     const float x = normalise_roundtrip(vi, a.den[0], a.rden[0], hx);
     const float y = normalise_roundtrip(vj, a.den[1], a.rden[1], hy);
@@ -545,9 +615,11 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   // "label" partial-volume images go through their own launch of the gather kernel (same
   // coordinates); everything else shares one launch of the brick / gather kernel
   ResampleArgs pv = a;
+  ResampleArgs spl = a;  // B-spline images (TIO_QUADRATIC / TIO_CUBIC): their own launch of the gather kernel as well
   a.n_images = 0;
   pv.n_images = 0;
   pv.any_linear = 1;
+  spl.n_images = 0;
   int dtmode = 0;
   bool any_adjoint = false;
   for (int i = 0; i < n_images; i++) {
@@ -555,8 +627,15 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     if (s.in == nullptr || s.out == nullptr || s.channels < 1)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d has null data or no channels", i);
     if (dtype_size(s.dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d dtype %d", i, s.dtype);
-    if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR && s.interp != TIO_LABEL_PV && s.interp != TIO_LINEAR_ADJOINT)
+    if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR && s.interp != TIO_LABEL_PV && s.interp != TIO_LINEAR_ADJOINT &&
+        s.interp != TIO_QUADRATIC && s.interp != TIO_CUBIC)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d interp %d", i, s.interp);
+    if (s.interp == TIO_QUADRATIC || s.interp == TIO_CUBIC) {
+      if (s.dtype != TIO_F32)
+        return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d: B-spline images hold float32 coefficients (tio_bspline_prefilter)", i);
+      spl.img[spl.n_images++] = ImgArgs{s.in, s.out, nullptr, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, nullptr, nullptr};
+      continue;
+    }
     if (s.interp == TIO_LINEAR_ADJOINT) {
       if (s.dtype != TIO_F32) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d: the adjoint works on float32 gradients", i);
       any_adjoint = true;
@@ -590,9 +669,24 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     const dim3 grid(static_cast<unsigned>(blocks)), block(kRowsPerBlock * kLanes);
     const size_t lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? static_cast<size_t>(n_cp) * sizeof(float) : 0;
     if (pv.cp != nullptr)
-      hipLaunchKernelGGL((resample_kernel<true, 2, true>), grid, block, lds, s, pv);
+      hipLaunchKernelGGL((resample_kernel<true, 2, 1>), grid, block, lds, s, pv);
     else
-      hipLaunchKernelGGL((resample_kernel<false, 2, true>), grid, block, lds, s, pv);
+      hipLaunchKernelGGL((resample_kernel<false, 2, 1>), grid, block, lds, s, pv);
+    if (a.n_images == 0 && spl.n_images == 0) return check_launch("tio_resample3d");
+  }
+  if (spl.n_images > 0) {
+    spl.tiles_k = (spl.Ko + kLanes - 1) / kLanes;
+    spl.tiles_j = (spl.Jo + kRowsPerBlock - 1) / kRowsPerBlock;
+    spl.tiles_i = (spl.Io + kTileI - 1) / kTileI;
+    const int64_t blocks = static_cast<int64_t>(spl.B) * spl.tiles_i * spl.tiles_j * spl.tiles_k;
+    if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+    if (static_cast<int64_t>(spl.I) * spl.J * spl.K >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: volume too large");
+    const dim3 grid(static_cast<unsigned>(blocks)), block(kRowsPerBlock * kLanes);
+    const size_t lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? static_cast<size_t>(n_cp) * sizeof(float) : 0;
+    if (spl.cp != nullptr)
+      hipLaunchKernelGGL((resample_kernel<true, 0, 2>), grid, block, lds, s, spl);
+    else
+      hipLaunchKernelGGL((resample_kernel<false, 0, 2>), grid, block, lds, s, spl);
     if (a.n_images == 0) return check_launch("tio_resample3d");
   }
 

@@ -30,7 +30,10 @@ _DTYPE_CODES = {
     torch.int64: _abi.I64,
 }
 FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
-INTERP_CODES = {"nearest": _abi.NEAREST, "linear": _abi.LINEAR, "label": _abi.LABEL_PV, "linear_adjoint": _abi.LINEAR_ADJOINT}
+INTERP_CODES = {
+    "nearest": _abi.NEAREST, "linear": _abi.LINEAR, "label": _abi.LABEL_PV, "linear_adjoint": _abi.LINEAR_ADJOINT,
+    "quadratic": _abi.QUADRATIC, "cubic": _abi.CUBIC,  # the image handed over holds B-spline coefficients (bspline_prefilter)
+}
 
 
 PRECISION_CODES = {"exact": _abi.PRECISION_EXACT, "fast": _abi.PRECISION_FAST}
@@ -430,6 +433,25 @@ class Engine:
 
                 outputs[n] = _AttachBackward.apply(source, outputs[n], backward)
         return outputs
+
+    def bspline_prefilter(self, data: Tensor, order: int) -> Tensor:
+        """B-spline coefficients (float32) of a ``(B, C, I, J, K)`` tensor for ``resample3d``'s ``"quadratic"`` (order 2) /
+        ``"cubic"`` (order 3) images: the recursive prefilter with the half-sample-symmetric boundary that
+        ``interpol.grid_pull(prefilter=True, bound="dct2")`` applies before sampling (spatial.py:1753-1760)."""
+        if data.ndim != 5:
+            raise ValueError("expected a (B, C, I, J, K) tensor")
+        if order not in (2, 3):
+            raise NotImplementedError(f"B-spline order {order} is not implemented (2 and 3 are)")
+        if _wants_grad(data):
+            raise EngineError("bspline_prefilter: B-spline resampling is not differentiable here (use reference_binding)")
+        data = data.detach().contiguous()
+        self._check("bspline_prefilter", data)
+        out = torch.empty(data.shape, dtype=torch.float32, device=data.device)
+        self._call(
+            "bspline_prefilter", data, _ptr(data), _ptr(out), dtype_code(data.dtype), data.shape[0] * data.shape[1],
+            _i32x3(data.shape[2:]), int(order), self._stream(data),
+        )
+        return out
 
     def channel_min(self, data: Tensor) -> Tensor:
         """Per-channel minimum of the first batch element as a ``(C,)`` float32 device tensor."""

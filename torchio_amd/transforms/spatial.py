@@ -549,18 +549,19 @@ def _apply_spatial_to_batch(
         if len(present) != len(fields):
             cp_skip = ops.h2d(torch.tensor([f is None for f in fields], dtype=torch.uint8), device)
 
-    passthrough = None
+    passthrough_all = None
     if per_sample is not None and target_space is None:
         flags = [m is None and f is None for m, f in zip(matrices, fields, strict=True)]
         if any(flags):
-            passthrough = ops.h2d(torch.tensor(flags, dtype=torch.uint8), device)
+            passthrough_all = ops.h2d(torch.tensor(flags, dtype=torch.uint8), device)
     else:
         flags = [False] * batch_size
 
     engine = ops.engine()
     mapping_dev = _identity_mapping(device) if mapping is None else ops.h2d(torch.from_numpy(mapping), device)
 
-    def resample(tensors, interps, fills, **label_arguments):
+    def resample(tensors, interps, fills, gated=True, **label_arguments):
+        passthrough = passthrough_all if gated else None
         # images of another shape than the first (Resample onto a named image of a multi-resolution subject) are
         # sampled with the first image's grid like in the reference (spatial.py:1136-1191): one call per shape
         shapes = [tuple(t.shape[2:]) for t in tensors]
@@ -631,9 +632,23 @@ def _apply_spatial_to_batch(
                 fill = None
                 table = engine.unique_labels(data)  # torch.unique(data), sorted; sizes the reference's one-hot (spatial.py:1360)
                 pad = float(default_pad_label)
-        elif _ORDERS[interpolation] > 1:
+        elif _ORDERS[interpolation] in (2, 3):
+            # interpol.grid_pull(data.float(), grid, interpolation=order, bound="dct2", extrapolate=False, prefilter=True)
+            # .to(data.dtype) (spatial.py:1734-1761, 1860-1878): coefficients first, then the (order + 1)^3-tap sum at the
+            # voxel coordinates; zero outside the field of view (the reference does not apply its fill value here).
+            # Gated-out elements are restored on this side: the launch would copy their COEFFICIENTS.
+            work = _antialias(engine, data, in_affine, out_affine) if antialias and not is_label else data
+            coefficients = engine.bspline_prefilter(work, _ORDERS[interpolation])
+            sampled = resample([coefficients], [interpolation], [None], gated=False)[0].to(data.dtype)
+            if any(flags) and tuple(sampled.shape) == tuple(data.shape):
+                rows = ops.h2d(torch.tensor(flags, dtype=torch.bool), data.device)
+                sampled = torch.where(rows.view(-1, 1, 1, 1, 1), data, sampled)
+            finished[name] = sampled
+            continue
+        elif _ORDERS[interpolation] > 3:
             raise NotImplementedError(
-                f'interpolation "{interpolation}" is not implemented by the HIP engine (supported: "nearest", "linear")'
+                f'interpolation "{interpolation}" is not implemented by the HIP engine (B-spline orders 2 and 3 are: '
+                '"quadratic", "cubic"; besides "nearest", "linear")'
             )
         else:
             fill = _fill_value(engine, img_batch, default_pad_value=default_pad_value, default_pad_label=default_pad_label)
