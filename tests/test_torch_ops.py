@@ -9,7 +9,7 @@ from __future__ import annotations
 import pytest
 import torch
 
-OPS = ("resample3d", "separable_conv3d", "bias_field_apply", "add_noise", "gamma_pow", "channel_min")
+OPS = ("resample3d", "separable_conv3d", "bias_field_apply", "add_noise", "gamma_pow", "channel_min", "bspline_prefilter")
 
 
 def test_library_loads_and_registers_every_op():
@@ -54,5 +54,6 @@ def test_custom_ops_equal_the_ctypes_engine(hip):
     gamma = torch.tensor([0.8, 1.3], device="cuda")
     assert torch.equal(torch.ops.tio_hip.gamma_pow(x - 0.5, gamma), hip.gamma_pow(x - 0.5, gamma))
     assert torch.equal(torch.ops.tio_hip.channel_min(x), hip.channel_min(x))
+    assert torch.equal(torch.ops.tio_hip.bspline_prefilter(x, 3), hip.bspline_prefilter(x, 3))
     with pytest.raises(RuntimeError, match="require grad"):
         torch.ops.tio_hip.gamma_pow(x.clone().requires_grad_(True), gamma)

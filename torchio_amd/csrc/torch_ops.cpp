@@ -1,7 +1,8 @@
 // torch_ops.cpp — PyTorch-ROCm custom-op registration of the C ABI (BASELINE.json north_star:
 // "exposed through PyTorch-ROCm custom ops").
 //
-//   TORCH_LIBRARY(tio_hip, m): resample3d, separable_conv3d, bias_field_apply, add_noise, gamma_pow, channel_min
+//   TORCH_LIBRARY(tio_hip, m): resample3d, separable_conv3d, bias_field_apply, add_noise, gamma_pow, channel_min,
+//                              bspline_prefilter
 //
 // Each op is a thin shim: it checks device / dtype / shapes (TORCH_CHECK -> Python RuntimeError), allocates the
 // outputs with the caching allocator (inputs are borrowed, nothing is written in place), takes the CURRENT HIP
@@ -117,7 +118,8 @@ std::vector<at::Tensor> resample3d(at::TensorList images, at::IntArrayRef modes,
     d.channels = static_cast<int32_t>(in.size(1));
     d.dtype = dtype_code(in.scalar_type());
     d.interp = static_cast<int32_t>(modes[i]);
-    TORCH_CHECK(d.interp == TIO_NEAREST || d.interp == TIO_LINEAR, "resample3d: modes are 0 (nearest) or 1 (linear)");
+    TORCH_CHECK(d.interp == TIO_NEAREST || d.interp == TIO_LINEAR || d.interp == TIO_QUADRATIC || d.interp == TIO_CUBIC,
+                "resample3d: modes are 0 (nearest), 1 (linear), 4 / 5 (quadratic / cubic B-spline over bspline_prefilter's coefficients)");
     const c10::optional<at::Tensor> f = fill.get(i);
     if (f.has_value() && f->defined()) TORCH_CHECK(f->numel() == in.size(1), "resample3d: a fill tensor holds one value per channel");
     d.fill_dev = opt_f32(f, keep, device, "resample3d");
@@ -241,6 +243,18 @@ at::Tensor channel_min(const at::Tensor& x) {
   return out;
 }
 
+// bspline_prefilter(Tensor x, int order) -> Tensor (float32): B-spline coefficients for resample3d's modes 4 / 5
+at::Tensor bspline_prefilter(const at::Tensor& x, int64_t order) {
+  check_volume(x, "bspline_prefilter");
+  const at::Tensor in = x.contiguous();
+  at::Tensor out = at::empty(in.sizes(), in.options().dtype(at::kFloat));
+  const int32_t shape[3] = {static_cast<int32_t>(in.size(2)), static_cast<int32_t>(in.size(3)), static_cast<int32_t>(in.size(4))};
+  check_status(tio_bspline_prefilter(in.data_ptr(), out.data_ptr<float>(), dtype_code(in.scalar_type()), in.size(0) * in.size(1), shape,
+                                     static_cast<int32_t>(order), current_stream(x)),
+               "tio_bspline_prefilter");
+  return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(tio_hip, m) {
@@ -252,6 +266,7 @@ TORCH_LIBRARY(tio_hip, m) {
         "Tensor? keep=None) -> Tensor");
   m.def("gamma_pow(Tensor x, Tensor gamma) -> Tensor");
   m.def("channel_min(Tensor x) -> Tensor");
+  m.def("bspline_prefilter(Tensor x, int order) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(tio_hip, CUDA, m) {
@@ -261,4 +276,5 @@ TORCH_LIBRARY_IMPL(tio_hip, CUDA, m) {
   m.impl("add_noise", add_noise);
   m.impl("gamma_pow", gamma_pow);
   m.impl("channel_min", channel_min);
+  m.impl("bspline_prefilter", bspline_prefilter);
 }
