@@ -119,3 +119,18 @@ def test_orders_above_three_say_so(oracle):
     subject = tio.Subject(t1=tio.ScalarImage(torch.rand(1, 8, 8, 8)))
     with use_engine(oracle), pytest.raises(NotImplementedError, match="orders 2 and 3"):
         tio.Affine(degrees=5, image_interpolation="fifth")(tio.SubjectsBatch.from_subjects([subject]))
+
+
+def test_label_mode_with_cubic_one_hot_channels(oracle):
+    """`label_interpolation="label", one_hot_label_interpolation="cubic"`: the materialised one-hot road with B-spline channels."""
+    g = torch.Generator().manual_seed(8)
+    seg = (torch.rand(1, 14, 14, 14, generator=g) * 3).to(torch.int16)
+    subject = tio.Subject(t1=tio.ScalarImage(torch.rand(1, 14, 14, 14, generator=g)), seg=tio.LabelMap(seg))
+    with use_engine(oracle):
+        torch.manual_seed(9)
+        cubic = tio.Affine(degrees=(10, 10), label_interpolation="label", one_hot_label_interpolation="cubic", default_pad_label=7)(subject)
+        torch.manual_seed(9)
+        linear = tio.Affine(degrees=(10, 10), label_interpolation="label", default_pad_label=7)(subject)
+    assert cubic.seg.data.dtype == torch.int16 and set(cubic.seg.data.unique().tolist()) <= {0, 1, 2, 7}
+    agreement = (cubic.seg.data == linear.seg.data).float().mean().item()
+    assert 0.6 < agreement < 1.0  # mostly the same winner, not everywhere (a smoother interpolant of the same channels)

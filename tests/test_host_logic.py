@@ -95,7 +95,7 @@ def test_unsupported_modes_raise_instead_of_falling_back():
     with pytest.raises(NotImplementedError, match="not implemented by the HIP engine"):
         tio.Affine(degrees=(5, 5), image_interpolation="fourth")(s)  # (orders 2 and 3 are: tests/test_bspline.py)
     with pytest.raises(NotImplementedError, match="one_hot_label_interpolation"):
-        tio.Affine(degrees=(5, 5), label_interpolation="label", one_hot_label_interpolation="cubic")(s)
+        tio.Affine(degrees=(5, 5), label_interpolation="label", one_hot_label_interpolation="fifth")(s)
 
 
 # -- "label" partial-volume mode ------------------------------------------------------

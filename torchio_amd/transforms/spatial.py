@@ -606,10 +606,10 @@ def _apply_spatial_to_batch(
         data = img_batch.data
         table, pad = None, 0.0
         if interpolation == LABEL_INTERPOLATION:  # only reachable for label maps (validated by the constructors)
-            if _ORDERS[one_hot_label_interpolation] > 1:
+            if _ORDERS[one_hot_label_interpolation] > 3:
                 raise NotImplementedError(
                     f'one_hot_label_interpolation "{one_hot_label_interpolation}" is not implemented by the HIP engine'
-                    ' (supported: "nearest", "linear")'
+                    ' (supported: "nearest", "linear", "quadratic", "cubic")'
                 )
             if data.shape[1] > 1:
                 # already one-hot / probabilistic: channels resampled as they are, zero outside,
@@ -617,6 +617,15 @@ def _apply_spatial_to_batch(
                 work = data.float()
                 if antialias:
                     work = _antialias(engine, work, in_affine, out_affine)
+                if _ORDERS[one_hot_label_interpolation] in (2, 3):
+                    coefficients = engine.bspline_prefilter(work, _ORDERS[one_hot_label_interpolation])
+                    sampled = resample([coefficients], [one_hot_label_interpolation], [None], gated=False)[0]
+                    sampled = sampled.to(data.dtype) if data.dtype.is_floating_point else sampled
+                    if any(flags) and tuple(sampled.shape) == tuple(data.shape):
+                        rows = ops.h2d(torch.tensor(flags, dtype=torch.bool), data.device)
+                        sampled = torch.where(rows.view(-1, 1, 1, 1, 1), data.to(sampled.dtype), sampled)
+                    finished[name] = sampled
+                    continue
                 if data.dtype.is_floating_point and data.dtype != torch.float32:
                     finished[name] = resample([work], [one_hot_label_interpolation], [None])[0].to(data.dtype)
                     continue
@@ -719,7 +728,11 @@ def _label_partial_volume_composite(
     one_hot = (data[:, :1] == labels.view(1, -1, 1, 1, 1)).float()
     if antialias:
         one_hot = _antialias(engine, one_hot, in_affine, out_affine)
-    sampled = resample([one_hot], [one_hot_label_interpolation], [None])[0]
+    if _ORDERS[one_hot_label_interpolation] in (2, 3):  # B-spline channels (interpol.grid_pull in the reference; §4.9 of DESIGN.md)
+        coefficients = engine.bspline_prefilter(one_hot, _ORDERS[one_hot_label_interpolation])
+        sampled = resample([coefficients], [one_hot_label_interpolation], [None], gated=False)[0]
+    else:
+        sampled = resample([one_hot], [one_hot_label_interpolation], [None])[0]
     resampled = labels[sampled.argmax(dim=1)]
     in_bounds = _cascade_sum_channels(sampled) > 0.5
     resampled = torch.where(in_bounds, resampled, torch.full_like(resampled, default_pad_label))
