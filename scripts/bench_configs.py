@@ -41,6 +41,9 @@ def timed(transform, batch, steps=20, warmup=3):
 
 def main() -> None:
     warnings.simplefilter("ignore")
+    precision = os.environ.get("TIO_CONFIGS_PRECISION", "fast")  # like bench.py: the throughput mode; "exact" = the library default
+    tio.set_resample_precision(precision)
+    print(json.dumps({"resample_precision": precision, "note": "launches with a label map are always exact (config 5)"}))
     device = torch.device("cuda", 0)
     torch.manual_seed(0)
     g = torch.Generator(device=device).manual_seed(1)
