@@ -164,9 +164,15 @@ class Spatial(SpatialTransform):
             self.__dict__["_scalar_plan_cache"] = cached
         return cached[1]
 
-    def _sample_one(self, shape, affine, *, build: bool = True):
-        """Parameters of one element; with ``build=False`` the affine is returned as its three tuples."""
-        plan = self._scalar_plan()
+    _NO_PLAN = object()
+
+    def _sample_one(self, shape, affine, *, build: bool = True, plan=_NO_PLAN):
+        """Parameters of one element; with ``build=False`` the affine is returned as its three tuples.
+
+        ``plan``: the scalar draw plan when the caller already holds it (one look-up per batch instead of one per
+        element: the cache key is built from the four ranges' values)."""
+        if plan is Spatial._NO_PLAN:
+            plan = self._scalar_plan()
         displacement = None
         if plan is not None:
             values = plan.sample()
@@ -238,11 +244,12 @@ class Spatial(SpatialTransform):
 
         keep = self._keep_mask(batch, n)
         matrices, fields, displacements, any_geometry = [], [], [], False
+        plan = self._scalar_plan()
         for index in range(n):
             if keep is not None and not bool(keep[index]):
                 matrices.append(None), fields.append(None), displacements.append(None)
                 continue
-            forward, field, displacement, has_geometry = self._sample_one(shape, affine, build=False)
+            forward, field, displacement, has_geometry = self._sample_one(shape, affine, build=False, plan=plan)
             any_geometry = any_geometry or has_geometry
             matrices.append(forward)
             fields.append(None if field is None else field.detach().to(device="cpu", dtype=torch.float32))
