@@ -8,7 +8,6 @@ timeout 150 $B --cases parity --path $K 2>&1 | grep -v "^dtype" | grep -v "misma
 run() { echo "== $*"; timeout 60 env "$@" $B --cases perf --reps 20 --path ${P:-fast} 2>&1 | grep -E "fast" | grep -E "(affine f32 fill|elastic f32 fill|nofill)" | cut -c1-130; }
 P="fast" run TIO_X=0
 P="$K" run TIO_X=0
-P="$K" run TIO_FAST_BPC=2
 P="$K" run TIO_TILE_ABLATE=1
 P="$K" run TIO_TILE_ABLATE=2
 P="$K" run TIO_TILE_ABLATE=3

@@ -633,3 +633,23 @@ def test_scalar_draw_plan_follows_reassigned_ranges(oracle):
     matrix = torch.as_tensor(out.applied_transforms[-1].params["affine_matrix"], dtype=torch.float64)
     off_diagonal = matrix[:3, :3] - torch.diag(torch.diagonal(matrix[:3, :3]))
     assert float(off_diagonal.abs().max()) < 1e-12, "the stale plan still rotated"
+
+
+# -- round 2: packed uploads, the folded minimum's bookkeeping ------------------------------------------------
+def test_h2d_packed_passes_host_tensors_through_on_a_cpu_target():
+    from torchio_amd import ops
+
+    a, b = torch.arange(6, dtype=torch.float32).view(2, 3), torch.ones(5)
+    out = ops.h2d_packed([a, None, b], "cpu")
+    assert out[1] is None and torch.equal(out[0], a) and torch.equal(out[2], b)
+
+
+def test_folded_channel_min_record_is_dropped_by_an_in_place_write():
+    from torchio_amd import ops
+
+    data = torch.rand(2, 1, 4, 4, 4)
+    assert ops.folded_channel_min(data) is None
+    data._tio_channel_min = (data._version, torch.tensor([0.25]))
+    assert torch.equal(ops.folded_channel_min(data), torch.tensor([0.25]))
+    data.mul_(2.0)  # the values changed: the record no longer describes the tensor
+    assert ops.folded_channel_min(data) is None
