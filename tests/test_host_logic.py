@@ -653,3 +653,31 @@ def test_folded_channel_min_record_is_dropped_by_an_in_place_write():
     assert torch.equal(ops.folded_channel_min(data), torch.tensor([0.25]))
     data.mul_(2.0)  # the values changed: the record no longer describes the tensor
     assert ops.folded_channel_min(data) is None
+
+
+@pytest.mark.parametrize("count", [2, 3, 8])
+@pytest.mark.parametrize(
+    "kwargs",
+    [
+        dict(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5)),
+        dict(degrees=(-10, 10), scales=(0.8, 1.2), isotropic=True),
+        dict(degrees=(0, 0, 5, 15, -3, 3)),
+        dict(max_displacement=7.5),
+        dict(max_displacement=(2.0, 9.0), num_control_points=(5, 6, 7)),
+        dict(max_displacement=(0.0, 4.0, 7.5, 7.5, 1.0, 2.0), degrees=(-5, 5), locked_borders=1),
+        dict(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5), max_displacement=(1.0, 6.0), num_control_points=4 + 1),
+    ],
+)
+def test_batched_parameter_draw_equals_the_per_element_loop(kwargs, count):
+    """`Spatial._sample_many`: same values, same generator state as `count` calls of `_sample_one` (the reference's order)."""
+    transform = tio.Spatial(**kwargs)
+    shape, affine = (16, 16, 16), tio.AffineMatrix()
+    torch.manual_seed(123)
+    loop = [transform._sample_one(shape, affine, build=False) for _ in range(count)]
+    state_loop = torch.get_rng_state()
+    torch.manual_seed(123)
+    many = transform._sample_many(shape, affine, count)
+    assert torch.equal(state_loop, torch.get_rng_state())
+    for (fa, ca, da, ga), (fb, cb, db, gb) in zip(loop, many, strict=True):
+        assert fa == fb and da == db and ga == gb
+        assert (ca is None) == (cb is None) and (ca is None or torch.equal(ca, cb))

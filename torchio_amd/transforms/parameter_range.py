@@ -127,6 +127,39 @@ class ScalarDrawPlan:
 
     def sample(self) -> list[float]:
         uniforms = torch.empty(self.n_random).uniform_(0.0, 1.0).tolist() if self.n_random else []
+        return self.map(uniforms)
+
+    def map_block(self, uniforms: np.ndarray) -> list[list[float]]:
+        """``[self.map(row) for row in uniforms]`` for a ``(rows, n_random)`` float32 block, vectorised.
+
+        ``fma(u, slope, offset)`` in float32 is the float64 ``u * slope + offset`` (the product is exact) rounded once
+        more — except when that float64 sum sits exactly on a float32 midpoint (see ``_fma32``); those entries, found
+        by their bit pattern, are redone with the scalar routine.
+        """
+        rows = uniforms.shape[0]
+        slopes = np.array([slope for constant, slope, _ in self.entries if constant is None], dtype=np.float64)
+        offsets = np.array([offset for constant, _, offset in self.entries if constant is None], dtype=np.float64)
+        u = uniforms.astype(np.float64)
+        total = u * slopes + offsets
+        mapped = total.astype(np.float32).astype(np.float64)
+        ties = (total.view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)  # a float32 midpoint held in float64
+        for r, c in zip(*np.nonzero(ties)):
+            mapped[r, c] = _fma32(float(u[r, c]), float(slopes[c]), float(offsets[c]))
+        drawn = mapped.tolist()
+        out = []
+        for r in range(rows):
+            position, values = 0, []
+            for constant, _, _ in self.entries:
+                if constant is not None:
+                    values.append(constant)
+                else:
+                    values.append(drawn[r][position])
+                    position += 1
+            out.append(values)
+        return out
+
+    def map(self, uniforms: list[float]) -> list[float]:
+        """The plan's values for ``n_random`` uniforms drawn elsewhere (a batch's draws come as one block)."""
         position = 0
         values = []
         for constant, slope, offset in self.entries:

@@ -212,6 +212,53 @@ class Spatial(SpatialTransform):
                 )
         return forward, field, displacement, (has_affine or field is not None)
 
+    def _sample_many(self, shape, affine, count: int):
+        """``[_sample_one(shape, affine, build=False) for _ in range(count)]`` with ONE draw for the whole batch.
+
+        The CPU generator hands out the same uniforms whether they are asked for element by element (a handful of
+        scalars, then ``prod(grid) * 3`` control values, per element) or as one block, so the values AND the generator
+        state afterwards are those of the loop (``tests/test_host_logic.py`` holds the two against each other); what
+        the block saves is the per-element dispatcher round trips (8 x (uniform_ + rand + 3 tensor ops) per transform).
+        Falls back to the loop when a draw decides whether later draws happen (a displacement that comes out as
+        exactly zero draws no field), when the scalar draws need the general path, or for user-given control points.
+        """
+        plan = self._scalar_plan()
+        loop = lambda: [self._sample_one(shape, affine, build=False, plan=plan) for _ in range(count)]  # noqa: E731
+        if plan is None or count < 2 or self.control_points is not None:
+            return loop()
+        n_scale = 1 if self.isotropic else 3
+        displacement_entries = plan.entries[n_scale + 6 : n_scale + 9]
+        never_field = all(constant == 0.0 for constant, _, _ in displacement_entries)
+        grid = tuple(self.num_control_points)
+        n_field = 0 if never_field else grid[0] * grid[1] * grid[2] * 3
+        width = plan.n_random + n_field
+        if width == 0:
+            return loop()
+        state = torch.get_rng_state() if not never_field else None
+        block = torch.rand(count, width, dtype=torch.float32)
+        rows = plan.map_block(block[:, : plan.n_random].numpy()) if plan.n_random else [plan.map([]) for _ in range(count)]
+        displacements = [tuple(values[n_scale + 6 : n_scale + 9]) for values in rows]
+        if not never_field and any(all(value == 0.0 for value in d) for d in displacements):
+            torch.set_rng_state(state)  # measure zero: that element draws no field in the reference, the stream shifts
+            return loop()
+        fields = None
+        if not never_field:
+            fields = block[:, plan.n_random :].reshape(count, *grid, 3)
+            fields -= 0.5
+            fields *= torch.tensor([[2.0 * m for m in d] for d in displacements], dtype=torch.float32).view(count, 1, 1, 1, 3)
+            if self.locked_borders > 0:
+                fields = torch.where(_interior_mask(grid, self.locked_borders), fields, torch.zeros((), dtype=torch.float32))
+        out = []
+        for index, values in enumerate(rows):
+            scales = (values[0],) * 3 if self.isotropic else tuple(values[:3])
+            degrees = tuple(values[n_scale : n_scale + 3])
+            translation = tuple(values[n_scale + 3 : n_scale + 6])
+            has_affine = not (_all_close(scales, 1.0) and _all_close(degrees, 0.0) and _all_close(translation, 0.0))
+            field = None if fields is None else fields[index]
+            displacement = None if field is None else displacements[index]
+            out.append(((scales, degrees, translation) if has_affine else None, field, displacement, has_affine or field is not None))
+        return out
+
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
         images = self._get_images(batch)
         if not images:
@@ -244,12 +291,13 @@ class Spatial(SpatialTransform):
 
         keep = self._keep_mask(batch, n)
         matrices, fields, displacements, any_geometry = [], [], [], False
-        plan = self._scalar_plan()
+        kept = [index for index in range(n) if keep is None or bool(keep[index])]
+        drawn = iter(self._sample_many(shape, affine, len(kept)))  # gated-out elements draw nothing
         for index in range(n):
             if keep is not None and not bool(keep[index]):
                 matrices.append(None), fields.append(None), displacements.append(None)
                 continue
-            forward, field, displacement, has_geometry = self._sample_one(shape, affine, build=False, plan=plan)
+            forward, field, displacement, has_geometry = next(drawn)
             any_geometry = any_geometry or has_geometry
             matrices.append(forward)
             fields.append(None if field is None else field.detach().to(device="cpu", dtype=torch.float32))
