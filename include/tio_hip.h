@@ -8,16 +8,19 @@
  *
  * Conventions
  *   - every pointer named *_dev (and x / y / in / out) is DEVICE memory unless
- *     the comment says HOST; nothing here allocates, frees or synchronises;
+ *     the comment says HOST; nothing here allocates or frees the caller's tensors, and nothing synchronises in the
+ *     steady state (two entry points keep a small scratch array per (device, stream) for themselves — the brick plan
+ *     of large tio_resample3d launches, the keys of tio_channel_min — allocated on first use and grown on demand,
+ *     which synchronises that one time; do not capture their first call into a graph);
  *   - tensors are dense row-major (B, C, I, J, K) — K fastest — exactly the
  *     layout of ImagesBatch.data (reference src/torchio/data/batch.py:21-50);
  *   - inputs are borrowed, outputs must not alias inputs;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - every function returns TIO_OK (0) or a negative tio_status; the failing
  *     call's message is available through tio_last_error() (thread-local);
- *   - re-entrant: no global mutable state besides the thread-local error text
- *     (the reference calls transforms from Queue worker threads,
- *     src/torchio/data/queue.py:119-123).
+ *   - re-entrant: no global mutable state besides the thread-local error text and those mutex-guarded scratch tables
+ *     (the reference calls transforms from Queue worker threads, src/torchio/data/queue.py:119-123); calls that share
+ *     a stream are ordered by it, calls on different streams use different scratch.
  *
  * The CPU restatement in oracle/ exports the same functions with the prefix
  * tio_oracle_ and HOST pointers (stream ignored); it is test infrastructure.
