@@ -145,7 +145,7 @@ def test_the_references_own_test_files_pass_through_the_binding():
     assert set(rows) >= {"test_spatial.py", "test_blur.py", "test_bias_field.py", "test_noise.py", "test_gamma.py"}, done.stdout[-2000:]
     for name, (passed, failed, which) in rows.items():
         if name == "test_spatial.py":
-            assert passed >= 103 and failed <= 7, (name, passed, failed, which)
+            assert passed >= 109 and failed <= 1, (name, passed, failed, which)  # (test_target_file_path needs nibabel)
             assert all(("HighOrder" in w) or ("higher_order" in w) or ("integer_order" in w) or ("file_path" in w) for w in which.split(", ")), which
         else:
             assert failed == 0 and passed > 0, (name, passed, failed, which)
