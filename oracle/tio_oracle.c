@@ -472,6 +472,10 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
               size_t es = dtype_size(img->dtype);
               for (int32_t c = 0; c < img->channels; c++) {
                 int64_t off = ((int64_t)b * img->channels + c) * n_out + o_idx;
+                if (img->interp == TIO_LINEAR_ADJOINT) { /* backward of the copy: identity; `out` (the gradient) is only read */
+                  ((float*)img->in)[off] += ((const float*)img->out)[off];
+                  continue;
+                }
                 memcpy((char*)img->out + off * es, (const char*)img->in + off * es, es);
               }
             }

@@ -50,6 +50,50 @@ def test_adjoint_launch_is_the_transpose_of_the_forward(oracle, elastic, with_fi
     _adjoint_identity(oracle, "cpu", elastic, with_fill)
 
 
+def _passthrough_gradient(engine, device):
+    """A gated-out element (forward = bit-exact copy) passes its gradient through unchanged, the incoming gradient is left
+    untouched, and the other elements still get the adjoint launch (the pass branch used to copy the zeroed
+    accumulator OVER the incoming gradient)."""
+    g = torch.Generator().manual_seed(17)
+    shape = (3, 1, 12, 10, 16)
+    x = torch.rand(shape, generator=g).to(device)
+    grad = torch.rand(shape, generator=g).to(device)
+    grad_before = grad.clone()
+    mapping, cp = _geometry(device, True)
+    gate = torch.tensor([0, 1, 0], dtype=torch.uint8, device=device)
+    common = dict(out_shape=shape[2:], mapping=mapping, control_points=cp, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True,
+                  passthrough=gate)
+    leaf = x.clone().requires_grad_(True)
+    (out,) = engine.resample3d([leaf], interps=["linear"], fills=[None], **common)
+    assert torch.equal(out[1].detach(), x[1])
+    (out * grad).sum().backward()
+    assert torch.equal(grad, grad_before), "the adjoint launch wrote into the incoming gradient"
+    assert torch.equal(leaf.grad[1], grad[1]), "gated-out element: d(copy)/dx is the identity"
+    # the other rows: same as a launch without the gate
+    del common["passthrough"]
+    leaf2 = x.clone().requires_grad_(True)
+    (out2,) = engine.resample3d([leaf2], interps=["linear"], fills=[None], **common)
+    (out2 * grad).sum().backward()
+    assert torch.allclose(leaf.grad[[0, 2]], leaf2.grad[[0, 2]], rtol=1e-5, atol=1e-6)
+
+
+def test_gated_out_element_backpropagates_the_identity(oracle):
+    _passthrough_gradient(oracle, "cpu")
+
+
+def test_ops_accept_tensors_that_require_grad_when_grad_is_disabled(oracle):
+    """Under ``torch.no_grad()`` a tensor that requires grad is just data (`_check` used to refuse it in some ops)."""
+    leaf = (torch.rand(1, 1, 8, 8, 8) + 0.2).requires_grad_(True)
+    with torch.no_grad():
+        assert not oracle.gamma_pow(leaf, 1.3).requires_grad
+        assert not oracle.add_noise(leaf, 0.0, 0.1, philox_seed=3).requires_grad
+        assert not oracle.flip3d(leaf, axes=(0,)).requires_grad
+        assert not oracle.pad3d(leaf, (1, 1, 0, 0, 2, 0)).requires_grad
+        assert not oracle.bias_field_apply(leaf, torch.zeros(1, 1, 2, 2, 2)).requires_grad
+        taps = torch.tensor([[[0.25, 0.5, 0.25]] * 3])
+        assert not oracle.separable_conv3d(leaf, taps, [1, 1, 1]).requires_grad
+
+
 def _pipeline():
     return tio.Compose([
         tio.Affine(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-2, 2)), tio.ElasticDeformation(), tio.BiasField(), tio.Blur(std=(0.5, 1.5)),
@@ -126,6 +170,7 @@ def test_gradients_equal_the_references_autograd(oracle):
 def test_adjoint_and_compose_backward_on_the_gpu(hip, oracle):
     for elastic in (False, True):
         _adjoint_identity(hip, "cuda", elastic, True)
+    _passthrough_gradient(hip, "cuda")
     data = (torch.rand(1, 40, 36, 44, generator=torch.Generator().manual_seed(4)) + 0.2)
     grads = []
     for device, engine in (("cpu", oracle), ("cuda", hip)):

@@ -192,8 +192,11 @@ __device__ __forceinline__ float key_to_float(uint32_t key) {
   const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
   return __uint_as_float(bits);
 }
-// `*cap` keys (all ones) followed by `*cap` tickets (zero), *cap >= entries, one pair of arrays per (device, stream): set
-// up once, every user restores what it touched before it ends.  Calls on one stream are ordered.
-uint32_t* min_workspace(hipStream_t s, int entries, int* cap);
+// `*cap` keys (all ones) followed by `*cap` tickets (zero), *cap >= entries, one pair of arrays per (device, stream, kind):
+// set up once, every user restores what it touched before it ends.  kind 0 = tio_channel_min (ONE self-contained launch
+// per call, so calls that share a stream are ordered by it), kind 1 = the folded minimum of a planned resampling launch
+// (two kernels, enqueued under the plan lease of resample.hip).  A grown array never frees its predecessor: another host
+// thread may have been handed that pointer and not launched with it yet (a few KiB per growth, a handful per process).
+uint32_t* min_workspace(hipStream_t s, int entries, int* cap, int kind = 0);
 
 }  // namespace tio

@@ -1147,8 +1147,8 @@ __global__ __launch_bounds__(kBlock) void gamma_kernel(const void* __restrict__ 
 
 // keys (all ones) + tickets (zero) of tio_channel_min, one pair of arrays per (device, stream): set up once, every
 // launch restores them.  Calls on one stream are ordered; different streams get different arrays.
-uint32_t* min_workspace(hipStream_t s, int entries, int* cap_out) {
-  struct Slot { int device; hipStream_t stream; uint32_t* ptr; int cap; };
+uint32_t* min_workspace(hipStream_t s, int entries, int* cap_out, int kind) {
+  struct Slot { int device; hipStream_t stream; int kind; uint32_t* ptr; int cap; };
   static std::mutex mu;
   static std::vector<Slot> slots;
   int device = 0;
@@ -1156,7 +1156,7 @@ uint32_t* min_workspace(hipStream_t s, int entries, int* cap_out) {
   std::lock_guard<std::mutex> lock(mu);
   Slot* found = nullptr;
   for (Slot& sl : slots)
-    if (sl.device == device && sl.stream == s) found = &sl;
+    if (sl.device == device && sl.stream == s && sl.kind == kind) found = &sl;
   if (found != nullptr && found->cap >= entries) {
     *cap_out = found->cap;
     return found->ptr;
@@ -1164,16 +1164,16 @@ uint32_t* min_workspace(hipStream_t s, int entries, int* cap_out) {
   const int cap = entries < 1024 ? 1024 : entries;
   uint32_t* ptr = nullptr;
   if (hipMalloc(&ptr, sizeof(uint32_t) * 2 * cap) != hipSuccess) return nullptr;
-  (void)hipStreamSynchronize(s);  // (a smaller array of this stream may still be in use)
-  if (hipMemset(ptr, 0xFF, sizeof(uint32_t) * cap) != hipSuccess || hipMemset(ptr + cap, 0, sizeof(uint32_t) * cap) != hipSuccess) {
+  if (hipMemset(ptr, 0xFF, sizeof(uint32_t) * cap) != hipSuccess || hipMemset(ptr + cap, 0, sizeof(uint32_t) * cap) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {  // (the memsets run on the null stream: finished before any launch on `s` reads them)
     (void)hipFree(ptr);
     return nullptr;
   }
   if (found != nullptr) {
-    (void)hipFree(found->ptr);
+    // the predecessor is NOT freed: a concurrent caller on this stream may hold it and launch with it after we return
     found->ptr = ptr; found->cap = cap;
   } else {
-    slots.push_back(Slot{device, s, ptr, cap});
+    slots.push_back(Slot{device, s, kind, ptr, cap});
   }
   *cap_out = cap;
   return ptr;

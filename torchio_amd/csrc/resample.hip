@@ -352,6 +352,13 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
         const int es = dtype_size(g.dtype);
         for (int c = 0; c < g.channels; c++) {
           const int64_t off = (static_cast<int64_t>(b) * g.channels + c) * n_out + o_idx;
+          if (g.interp == TIO_LINEAR_ADJOINT) {
+            // backward of the bit-exact copy: the identity.  `in` is the gradient accumulator, `out` the incoming
+            // gradient, which is only ever READ in this mode (every voxel is visited once: no atomic needed)
+            float* acc = const_cast<float*>(static_cast<const float*>(g.in));
+            acc[off] = __fadd_rn(acc[off], static_cast<const float*>(g.out)[off]);
+            continue;
+          }
           const char* s = static_cast<const char*>(g.in) + off * es;
           char* d = static_cast<char*>(g.out) + off * es;
           for (int e = 0; e < es; e++) d[e] = s[e];
@@ -524,30 +531,56 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 #include "resample_tile.hpp"
 #include "resample_fast.hpp"
 
-// Device scratch for the brick plan of a FAST launch (resample_fast.hpp): one buffer per (device, stream), grown on demand
-// and kept — launches on one stream are ordered, so the plan of a launch is consumed before the next one overwrites it.
-static int* plan_workspace(hipStream_t s, size_t bytes) {
-  struct Slot { int device; hipStream_t stream; int* ptr; size_t cap; };
-  static std::mutex mu;
-  static std::vector<Slot> slots;
+// Device scratch for the brick plan of a planned launch (resample_fast.hpp): one buffer per (device, stream), grown on
+// demand and kept.  A planned launch is a PAIR of kernels on the caller's stream — plan_bricks_kernel writes the buffer,
+// the sampling kernel reads it — so the buffer is LEASED: the lease holds the slot's mutex from the lookup until both
+// kernels are enqueued.  Two host threads that share a stream (the reference's Queue workers on the default stream,
+// data/queue.py:119-123; ctypes drops the GIL around these calls) therefore enqueue planA, sampleA, planB, sampleB and
+// never planA, planB, sampleA; the stream then orders the pairs on the device.  Growing (hipStreamSynchronize + hipFree +
+// hipMalloc) also happens under the lease, i.e. while no other call holds a pointer it has not launched with yet.
+namespace {
+struct PlanSlot {
+  int device;
+  hipStream_t stream;
+  int* ptr = nullptr;
+  size_t cap = 0;
+  std::mutex busy;
+};
+struct PlanLease {
+  std::unique_lock<std::mutex> hold;
+  int* ptr = nullptr;
+};
+}  // namespace
+
+static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
+  static std::mutex registry_mu;
+  static std::vector<PlanSlot*> registry;  // slots are never destroyed: their addresses (and mutexes) stay valid
+  PlanLease lease;
   int device = 0;
-  if (hipGetDevice(&device) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  for (Slot& sl : slots)
-    if (sl.device == device && sl.stream == s) {
-      if (sl.cap >= bytes) return sl.ptr;
-      (void)hipStreamSynchronize(s);
-      (void)hipFree(sl.ptr);
-      sl.ptr = nullptr; sl.cap = 0;
-      if (hipMalloc(&sl.ptr, bytes) != hipSuccess) return nullptr;
-      sl.cap = bytes;
-      return sl.ptr;
+  if (hipGetDevice(&device) != hipSuccess) return lease;
+  PlanSlot* slot = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(registry_mu);
+    for (PlanSlot* sl : registry)
+      if (sl->device == device && sl->stream == s) slot = sl;
+    if (slot == nullptr) {
+      slot = new PlanSlot();
+      slot->device = device; slot->stream = s;
+      registry.push_back(slot);
     }
-  Slot sl{device, s, nullptr, 0};
-  if (hipMalloc(&sl.ptr, bytes) != hipSuccess) return nullptr;
-  sl.cap = bytes;
-  slots.push_back(sl);
-  return sl.ptr;
+  }
+  lease.hold = std::unique_lock<std::mutex>(slot->busy);
+  if (slot->cap < bytes) {
+    if (slot->ptr != nullptr) {
+      (void)hipStreamSynchronize(s);  // the previous (smaller) plan of this stream may still be read
+      (void)hipFree(slot->ptr);
+      slot->ptr = nullptr; slot->cap = 0;
+    }
+    if (hipMalloc(&slot->ptr, bytes) != hipSuccess) { slot->ptr = nullptr; return lease; }
+    slot->cap = bytes;
+  }
+  lease.ptr = slot->ptr;
+  return lease;
 }
 
 // `folded` comes back true when the launch itself produced every requested out_min_dev (planned FAST bricks)
@@ -789,7 +822,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         a.cp_lds = 0;
         const size_t lds_p = static_cast<size_t>(cap_p) * sizeof(float);
         const int n_items = static_cast<int>(blocks);
-        int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
+        PlanLease lease = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
+        int* plan = lease.ptr;  // (the lease is released when this function returns: after both kernels are enqueued)
         if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
         const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
         const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
@@ -805,7 +839,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           for (int i = 0; i < a.n_images; i++) min_channels += a.img[i].out_min != nullptr ? a.img[i].channels : 0;
           if (min_channels > 0 && min_channels <= kMinChannels && pv.n_images == 0) {
             int cap = 0;
-            min_keys = min_workspace(s, min_channels * kMinSlots, &cap);
+            min_keys = min_workspace(s, min_channels * kMinSlots, &cap, /*kind=*/1);  // its own array: tio_channel_min may be enqueued between this launch's two kernels
             if (min_keys == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the reduction workspace");
             int slot = 0;
             for (int i = 0; i < a.n_images; i++)
@@ -846,6 +880,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     // is staged; the corner evaluation and its reductions leave the head of every block); TIO_EXACT_PLAN=0 switches it off,
     // =2 forces it for small launches (A/B, tests).
     const int* plan_exact = nullptr;
+    PlanLease exact_lease;  // held until the brick kernel is enqueued (end of this function)
     {
       // Measured (8 x 256^3): affine 0.497 -> 0.478 ms; elastic launches LOSE (0.588 -> 0.610: 27 vertices with their
       // control-point reads per brick cost the planner more than the brick kernel's own reduction), and so do small ones.
@@ -861,10 +896,11 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         const int64_t items64 = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
         if (items64 < (1LL << 26)) {
           const int n_items = static_cast<int>(items64);
-          int* plan = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
+          exact_lease = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
+          int* plan = exact_lease.ptr;
           if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
           const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
-        const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
+          const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
           const dim3 plan_grid((plan_threads + 255) / 256);
           if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
           else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);

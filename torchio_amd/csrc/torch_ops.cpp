@@ -13,6 +13,7 @@
 // differentiable; torchio_amd.reference_binding routes such inputs to the reference).
 #include <ATen/ATen.h>
 #include <ATen/hip/HIPContext.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <vector>
@@ -73,6 +74,7 @@ std::vector<at::Tensor> resample3d(at::TensorList images, at::IntArrayRef modes,
   TORCH_CHECK(in_spacing.size() == 3 && out_spacing.size() == 3 && out_shape.size() == 3, "resample3d: spacings and out_shape have 3 entries");
   const at::Tensor& first = images[0];
   check_volume(first, "resample3d");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(first.device());  // kernels, scratch and the stream below belong to the DATA's device
   const at::Device device = first.device();
   std::vector<at::Tensor> keep;
   tio_resample_geom geom{};
@@ -131,6 +133,7 @@ std::vector<at::Tensor> resample3d(at::TensorList images, at::IntArrayRef modes,
 // separable_conv3d(Tensor x, Tensor taps(1|B,3,stride), int[3] radius, Tensor? skip(B)) -> Tensor
 at::Tensor separable_conv3d(const at::Tensor& x, const at::Tensor& taps, at::IntArrayRef radius, const c10::optional<at::Tensor>& skip) {
   check_volume(x, "separable_conv3d");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());  // kernels, scratch and the stream below belong to the DATA's device
   TORCH_CHECK(at::isFloatingType(x.scalar_type()), "separable_conv3d: floating dtype expected");
   TORCH_CHECK(radius.size() == 3, "separable_conv3d: radius has 3 entries");
   TORCH_CHECK(taps.device() == x.device() && taps.dim() == 3 && taps.size(1) == 3 && (taps.size(0) == 1 || taps.size(0) == x.size(0)),
@@ -158,6 +161,7 @@ at::Tensor separable_conv3d(const at::Tensor& x, const at::Tensor& taps, at::Int
 // bias_field_apply(Tensor x, Tensor coarse(B,C,si,sj,sk), bool divide, Tensor? skip(B)) -> Tensor
 at::Tensor bias_field_apply(const at::Tensor& x, const at::Tensor& coarse, bool divide, const c10::optional<at::Tensor>& skip) {
   check_volume(x, "bias_field_apply");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());  // kernels, scratch and the stream below belong to the DATA's device
   TORCH_CHECK(coarse.device() == x.device() && coarse.dim() == 5 && coarse.size(0) == x.size(0) && coarse.size(1) == x.size(1),
               "bias_field_apply: coarse field must be (B, C, si, sj, sk) on the data's device");
   std::vector<at::Tensor> keep;
@@ -176,6 +180,7 @@ at::Tensor bias_field_apply(const at::Tensor& x, const at::Tensor& coarse, bool 
 at::Tensor add_noise(const at::Tensor& x, const at::Tensor& mean, const at::Tensor& std_, bool rician, const c10::optional<at::Tensor>& base,
                      const c10::optional<at::Tensor>& base2, int64_t philox_seed, const c10::optional<at::Tensor>& keep_rows) {
   check_volume(x, "add_noise");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());  // kernels, scratch and the stream below belong to the DATA's device
   const int64_t batch = x.size(0);
   TORCH_CHECK((mean.numel() == 1 || mean.numel() == batch) && (std_.numel() == 1 || std_.numel() == batch), "add_noise: mean / std hold 1 or B values");
   std::vector<at::Tensor> keep;
@@ -214,6 +219,7 @@ at::Tensor add_noise(const at::Tensor& x, const at::Tensor& mean, const at::Tens
 // gamma_pow(Tensor x, Tensor gamma(1|B)) -> Tensor
 at::Tensor gamma_pow(const at::Tensor& x, const at::Tensor& gamma) {
   check_volume(x, "gamma_pow");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());  // kernels, scratch and the stream below belong to the DATA's device
   const int64_t batch = x.size(0);
   TORCH_CHECK(gamma.numel() == 1 || gamma.numel() == batch, "gamma_pow: gamma holds 1 or B values");
   const at::Tensor in = x.contiguous();
@@ -235,6 +241,7 @@ at::Tensor gamma_pow(const at::Tensor& x, const at::Tensor& gamma) {
 // channel_min(Tensor x) -> Tensor (C floats, device): per-channel minimum of the FIRST batch element
 at::Tensor channel_min(const at::Tensor& x) {
   check_volume(x, "channel_min");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());  // kernels, scratch and the stream below belong to the DATA's device
   const at::Tensor in = x.contiguous();
   at::Tensor out = at::empty({in.size(1)}, in.options().dtype(at::kFloat));
   check_status(tio_channel_min(in.data_ptr(), dtype_code(in.scalar_type()), static_cast<int32_t>(in.size(1)),
@@ -246,6 +253,7 @@ at::Tensor channel_min(const at::Tensor& x) {
 // bspline_prefilter(Tensor x, int order) -> Tensor (float32): B-spline coefficients for resample3d's modes 4 / 5
 at::Tensor bspline_prefilter(const at::Tensor& x, int64_t order) {
   check_volume(x, "bspline_prefilter");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(x.device());  // kernels, scratch and the stream below belong to the DATA's device
   const at::Tensor in = x.contiguous();
   at::Tensor out = at::empty(in.sizes(), in.options().dtype(at::kFloat));
   const int32_t shape[3] = {static_cast<int32_t>(in.size(2)), static_cast<int32_t>(in.size(3)), static_cast<int32_t>(in.size(4))};

@@ -233,7 +233,7 @@ class Engine:
                     f" to the GPU (`subject.to('cuda')`), or keep using `torchio` itself with"
                     " `torchio_amd.reference_binding.bind()`: there, host tensors stay on the reference's own code"
                 )
-            if t.requires_grad:
+            if t.requires_grad and torch.is_grad_enabled():  # (with grad disabled a tensor that requires grad is just data)
                 raise EngineError(
                     f"{what}: this {self.name} engine op has no backward (differentiable: trilinear resampling, bias field, blur,"
                     " noise, gamma, flip) — detach the tensor, or use `torchio` with `torchio_amd.reference_binding.bind()`,"

@@ -33,16 +33,28 @@ _ORIGINALS: dict[tuple[Any, str], Any] = {}
 
 
 def _with_fallback(ours, original, tensors_of):
+    """``ours`` for device tensors, ``original`` (the reference's own code) for everything the engine does not take.
+
+    The decision is made UP FRONT from the tensors of the call: a tensor that does not live where the engine computes
+    (a host tensor, for the HIP engine) goes to the reference without touching the engine.  Errors of the engine path
+    fall back only while nothing has been written (the images of the batch are still the same tensor objects); an error
+    after the first image was replaced is re-raised — falling back then would apply the transform to that image twice.
+    """
     @functools.wraps(original)
     def seam(*args, **kwargs):
         try:
-            list(tensors_of(*args, **kwargs))
+            before = list(tensors_of(*args, **kwargs))
         except Exception:  # noqa: BLE001 - an unexpected call shape is the reference's business
             return original(*args, **kwargs)
+        wanted = ops._ENGINE.device_type if ops._ENGINE is not None else "cuda"
+        if any(getattr(t, "device", None) is None or t.device.type != wanted for t in before):
+            return original(*args, **kwargs)  # the engine only reads device memory
         try:
             return ours(*args, **kwargs)
-        except (ops.EngineError, NotImplementedError):
-            # nothing was written: seam functions validate / dispatch before they replace a tensor
+        except (ops.EngineError, NotImplementedError, TypeError, ValueError):
+            after = list(tensors_of(*args, **kwargs))
+            if len(after) != len(before) or any(a is not b for a, b in zip(after, before)):
+                raise
             return original(*args, **kwargs)
 
     seam.__tio_amd_original__ = original
