@@ -81,6 +81,8 @@ constexpr int kLdsFloatsPerCU = 40960;   // 160 KiB
 constexpr int kPlannedMinBricks = 12288;  // below: one kernel with in-kernel boxes (the plan costs a launch)
 constexpr int kTileMinCap = 6144;       // the per-voxel fallback parks 8 planes x 3 coordinates x 256 threads there
 constexpr int kTileBlocksPerCU = 3;       // resident blocks the default LDS budget is sized for
+constexpr int kPlanned2Bpb = 0;           // bricks per block of the planned FAST launches (0 = the round-2 one-brick kernel)
+constexpr int kPlanned2Split = 1;         // DMA wait phases per brick (1, 2 or 4)
 
 // IEEE-754 correctly rounded n / d from r = RN(1/d): q0 = RN(n r), two Markstein
 // refinements (each: exact remainder by FMA, correction by FMA).  Checked
@@ -552,6 +554,9 @@ struct PlanLease {
 };
 }  // namespace
 
+static int* g_debug_last_plan = nullptr;   // profiling only (tio_debug_last_plan)
+static size_t g_debug_last_plan_bytes = 0;
+
 static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
   static std::mutex registry_mu;
   static std::vector<PlanSlot*> registry;  // slots are never destroyed: their addresses (and mutexes) stay valid
@@ -580,7 +585,17 @@ static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
     slot->cap = bytes;
   }
   lease.ptr = slot->ptr;
+  g_debug_last_plan = slot->ptr;
+  g_debug_last_plan_bytes = bytes;
   return lease;
+}
+
+// profiling only (not part of include/tio_hip.h): the device buffer of the most recent brick plan of this process
+extern "C" int tio_debug_last_plan(void** ptr, size_t* bytes) {
+  if (ptr == nullptr || bytes == nullptr) return TIO_ERR_INVALID_ARGUMENT;
+  *ptr = g_debug_last_plan;
+  *bytes = g_debug_last_plan_bytes;
+  return TIO_OK;
 }
 
 // `folded` comes back true when the launch itself produced every requested out_min_dev (planned FAST bricks)
@@ -820,8 +835,23 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         if (cap_p > kLdsFloatsPerCU) cap_p = kLdsFloatsPerCU;
         a.tile_cap = cap_p;
         a.cp_lds = 0;
-        const size_t lds_p = static_cast<size_t>(cap_p) * sizeof(float);
+        size_t lds_p = static_cast<size_t>(cap_p) * sizeof(float);
         const int n_items = static_cast<int>(blocks);
+        // planned2 (resample_fast.hpp, round 3): BPB bricks per block + split DMA wait.  TIO_PLANNED_V2="bpb:split"
+        // selects an instantiation (A/B, tests); "0" = the round-2 kernel.
+        int v2_bpb = kPlanned2Bpb, v2_split = kPlanned2Split;
+        if (const char* env = getenv("TIO_PLANNED_V2")) {
+          v2_bpb = atoi(env);
+          const char* colon = strchr(env, ':');
+          v2_split = colon != nullptr ? atoi(colon + 1) : 1;
+        }
+        if (a.cp != nullptr && n_cp > kMaxCpLds) v2_bpb = 0;  // the control points must fit next to the tile
+        if (a.cp != nullptr && v2_bpb > 0) {
+          a.cp_lds = (n_cp + 3) & ~3;
+          a.tile_cap = cap_p - a.cp_lds;  // same LDS per block: the planner sizes the boxes for what is left
+          if (a.tile_cap < kTileMinCap) { a.tile_cap = kTileMinCap; lds_p = static_cast<size_t>(a.tile_cap + a.cp_lds) * sizeof(float); }
+        }
+        if (const char* env = getenv("TIO_TILE_ABLATE")) a.ablate = atoi(env);
         PlanLease lease = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
         int* plan = lease.ptr;  // (the lease is released when this function returns: after both kernels are enqueued)
         if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
@@ -863,6 +893,23 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
             hipLaunchKernelGGL(min_finish_kernel, dim3(static_cast<unsigned>(min_channels)), dim3(kMinSlots), 0, s, min_keys, min_outs, min_channels);
           return check_launch("tio_resample3d");
         };
+        if (v2_bpb > 0 && min_channels == 0) {
+          auto launch_v2 = [&](auto kernel, int bpb) -> int {
+            if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(lds_p)) != hipSuccess)
+              return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
+            hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>((n_items + bpb - 1) / bpb)), dim3(256), lds_p, s, a, static_cast<const int*>(plan), n_items);
+            return check_launch("tio_resample3d");
+          };
+#define TIO_V2(BPB, SPLIT)                                                                                   \
+  if (v2_bpb == BPB && v2_split == SPLIT) {                                                                  \
+    if (a.cp != nullptr) return launch_v2(resample_planned2_kernel<true, BPB, SPLIT>, BPB);                    \
+    return launch_v2(resample_planned2_kernel<false, BPB, SPLIT>, BPB);                                       \
+  }
+          TIO_V2(1, 1) TIO_V2(1, 2) TIO_V2(1, 4) TIO_V2(2, 1) TIO_V2(2, 4) TIO_V2(4, 1) TIO_V2(4, 2) TIO_V2(4, 4) TIO_V2(8, 1) TIO_V2(8, 4)
+#undef TIO_V2
+          return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: TIO_PLANNED_V2=%d:%d is not an instantiated variant", v2_bpb, v2_split);
+        }
         if (a.cp != nullptr) return launch_planned(resample_planned_kernel<true, 16, 16, 16, 3>);
         return launch_planned(resample_planned_kernel<false, 16, 16, 16, 3>);
       }

@@ -538,12 +538,16 @@ class Engine:
                 mean_f, std_f = float(mean), float(std)
         out = torch.empty_like(data)
         tmp = torch.empty((2, *data.shape), dtype=torch.float32, device=data.device)
-        with torch.cuda.device(data.device):
-            status = self._fn["blur_fused"](
-                _ptr(data), _ptr(out), _ptr(tmp), dtype_code(data.dtype), batch, channels, _i32x3(data.shape[2:]), _ptr(taps),
-                int(taps.shape[0] == batch and batch > 1), taps.shape[2], _i32x3(radius), _ptr(bias_coarse), coarse_shape,
-                noise_on, mean_f, std_f, _ptr(mean_t), _ptr(std_t), batched, int(seed) & (2**64 - 1), self._stream(data),
-            )
+        arguments = (
+            _ptr(data), _ptr(out), _ptr(tmp), dtype_code(data.dtype), batch, channels, _i32x3(data.shape[2:]), _ptr(taps),
+            int(taps.shape[0] == batch and batch > 1), taps.shape[2], _i32x3(radius), _ptr(bias_coarse), coarse_shape,
+            noise_on, mean_f, std_f, _ptr(mean_t), _ptr(std_t), batched, int(seed) & (2**64 - 1), self._stream(data),
+        )
+        if self.device_type == "cuda" and data.device.index != torch.cuda.current_device():
+            with torch.cuda.device(data.device):
+                status = self._fn["blur_fused"](*arguments)
+        else:
+            status = self._fn["blur_fused"](*arguments)
         if status == _abi.UNSUPPORTED_CONFIG:
             return None
         if status != _abi.OK:
