@@ -23,7 +23,6 @@
 #include "../../include/tio_hip.h"
 
 extern "C" int tio_oracle_resample3d(const tio_resample_geom*, int32_t, const tio_resample_image*, void*);
-extern "C" int tio_debug_last_plan(void** ptr, size_t* bytes);  // profiling hook of libtio_hip.so (not in the public header)
 
 #define HIP_CHECK(x)                                                                  \
   do {                                                                                \
@@ -174,11 +173,8 @@ static const Paths kPaths[] = {
     // bricks of resample_fast.hpp (the product path of large launches; forced here whatever the size) and the brick
     // kernel's FAST instantiation (small launches, A/B)
     {"fast", "tile", "0", 1, "planned", "0"}, {"fast-brick", "tile", "0", 1, "brick", "0"},
-    // round 3: BPB bricks per block + split DMA wait (TIO_PLANNED_V2 = "bpb:split")
-    {"fast-v2-1:1", "tile", "0", 1, "planned", "1:1"}, {"fast-v2-1:2", "tile", "0", 1, "planned", "1:2"}, {"fast-v2-1:4", "tile", "0", 1, "planned", "1:4"},
-    {"fast-v2-2:1", "tile", "0", 1, "planned", "2:1"}, {"fast-v2-2:4", "tile", "0", 1, "planned", "2:4"},
-    {"fast-v2-4:1", "tile", "0", 1, "planned", "4:1"}, {"fast-v2-4:2", "tile", "0", 1, "planned", "4:2"}, {"fast-v2-4:4", "tile", "0", 1, "planned", "4:4"},
-    {"fast-v2-8:1", "tile", "0", 1, "planned", "8:1"}, {"fast-v2-8:4", "tile", "0", 1, "planned", "8:4"}};
+    // round 3 A/B: the general planned kernel for a single-channel image too (TIO_PLANNED_LEAN=0)
+    {"fast-general", "tile", "0", 1, "planned", "nolean"}};
 
 static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
   if (!g_case_filter.empty() && cs.name.find(g_case_filter) == std::string::npos) return 0;
@@ -276,7 +272,8 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     setenv("TIO_RESAMPLE_PATH", kPaths[p].path, 1);
     setenv("TIO_TILE_VARIANT", kPaths[p].variant, 1);
     if (kPaths[p].kernel) setenv("TIO_FAST_KERNEL", kPaths[p].kernel, 1); else unsetenv("TIO_FAST_KERNEL");
-    if (kPaths[p].v2) setenv("TIO_PLANNED_V2", kPaths[p].v2, 1); else unsetenv("TIO_PLANNED_V2");
+    const std::string mix = kPaths[p].v2 ? kPaths[p].v2 : "";
+    setenv("TIO_PLANNED_LEAN", mix == "nolean" ? "0" : "1", 1);
     geom.precision = kPaths[p].fast ? TIO_PRECISION_FAST : TIO_PRECISION_EXACT;
     bool all_f32_linear = true;
     for (const Image& im : cs.images) all_f32_linear &= im.dtype == TIO_F32 && im.interp == TIO_LINEAR;
@@ -294,40 +291,6 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
       HIP_CHECK(hipEventSynchronize(e1));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       ms /= reps;
-    }
-    if (getenv("TIO_STAMPS") != nullptr && kPaths[p].v2 != nullptr && atoi(kPaths[p].v2) > 0) {
-      // shader-clock stamps left in the plan by resample_planned2_kernel (TIO_TILE_ABLATE & 16): phases of a brick's life
-      void* plan_dev = nullptr; size_t plan_bytes = 0;
-      tio_debug_last_plan(&plan_dev, &plan_bytes);
-      std::vector<uint64_t> plan(plan_bytes / 8);
-      HIP_CHECK(hipMemcpy(plan.data(), plan_dev, plan_bytes, hipMemcpyDeviceToHost));
-      const size_t first = static_cast<size_t>(B) * 16 / 2, n_bricks = (plan_bytes / 8 - first) / 8;
-      double sum[5] = {0, 0, 0, 0, 0};
-      uint64_t t_min = ~0ull, t_max = 0;
-      std::vector<double> life;
-      size_t counted = 0;
-      for (size_t k = 0; k < n_bricks; k++) {
-        const uint64_t* w = &plan[first + 8 * k];
-        if (w[7] != 0x5354414D50ull) continue;  // not a stamped (staged) brick
-        const uint64_t start = (w[6] & 0xFFFFFFFFull) == 0 ? w[0] : w[1];  // later bricks of a block: from their descriptor
-        sum[0] += static_cast<double>(w[1] - start); sum[1] += static_cast<double>(w[2] - w[1]); sum[2] += static_cast<double>(w[3] - w[2]);
-        sum[3] += static_cast<double>(w[4] - w[3]); sum[4] += static_cast<double>(w[5] - w[4]);
-        life.push_back(static_cast<double>(w[5] - w[0]));
-        t_min = w[0] < t_min ? w[0] : t_min; t_max = w[5] > t_max ? w[5] : t_max;
-        counted++;
-      }
-      if (counted) {
-        double life_sum = 0.0;
-        for (double v : life) life_sum += v;
-        std::sort(life.begin(), life.end());
-        const double span = static_cast<double>(t_max - t_min);
-        printf("  stamps %s: resident blocks per CU (sum of entry->drained lives / span / 256) %.2f; life median %.0f p90 %.0f ticks\n", kPaths[p].name,
-               life_sum / span / 256.0, life[life.size() / 2], life[life.size() * 9 / 10]);
-        const double tick_ns = time_it ? ms * 1e6 / span : 0.0;  // the last launch's span in ticks against its measured duration
-        printf("  stamps %s: %zu bricks, span %.0f ticks (%.3f ns/tick if the span is one launch); per brick [ticks]: entry->descriptor %.0f, ->DMA issued %.0f, "
-               "->landed %.0f, ->sampled %.0f, ->stores drained %.0f\n", kPaths[p].name, counted, span, tick_ns, sum[0] / counted, sum[1] / counted,
-               sum[2] / counted, sum[3] / counted, sum[4] / counted);
-      }
     }
     size_t diff_first = 0, diff_oracle = 0;
     double max_rel = 0.0;

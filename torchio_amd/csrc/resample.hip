@@ -71,6 +71,7 @@ struct ResampleArgs {
   int cp_lds;    // floats of LDS reserved for the control points (0 = read them from global)
   int tile_cap;  // floats of LDS available for one staged input brick (tile kernel)
   int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
+  int dma_packed;  // planned bricks: DMA instructions cover rows across x-plane boundaries (A/B: TIO_DMA_PACKED=0)
 };
 
 constexpr int kTileI = 8;          // output slabs walked by one block
@@ -81,8 +82,6 @@ constexpr int kLdsFloatsPerCU = 40960;   // 160 KiB
 constexpr int kPlannedMinBricks = 12288;  // below: one kernel with in-kernel boxes (the plan costs a launch)
 constexpr int kTileMinCap = 6144;       // the per-voxel fallback parks 8 planes x 3 coordinates x 256 threads there
 constexpr int kTileBlocksPerCU = 3;       // resident blocks the default LDS budget is sized for
-constexpr int kPlanned2Bpb = 0;           // bricks per block of the planned FAST launches (0 = the round-2 one-brick kernel)
-constexpr int kPlanned2Split = 1;         // DMA wait phases per brick (1, 2 or 4)
 
 // IEEE-754 correctly rounded n / d from r = RN(1/d): q0 = RN(n r), two Markstein
 // refinements (each: exact remainder by FMA, correction by FMA).  Checked
@@ -554,9 +553,6 @@ struct PlanLease {
 };
 }  // namespace
 
-static int* g_debug_last_plan = nullptr;   // profiling only (tio_debug_last_plan)
-static size_t g_debug_last_plan_bytes = 0;
-
 static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
   static std::mutex registry_mu;
   static std::vector<PlanSlot*> registry;  // slots are never destroyed: their addresses (and mutexes) stay valid
@@ -585,17 +581,7 @@ static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
     slot->cap = bytes;
   }
   lease.ptr = slot->ptr;
-  g_debug_last_plan = slot->ptr;
-  g_debug_last_plan_bytes = bytes;
   return lease;
-}
-
-// profiling only (not part of include/tio_hip.h): the device buffer of the most recent brick plan of this process
-extern "C" int tio_debug_last_plan(void** ptr, size_t* bytes) {
-  if (ptr == nullptr || bytes == nullptr) return TIO_ERR_INVALID_ARGUMENT;
-  *ptr = g_debug_last_plan;
-  *bytes = g_debug_last_plan_bytes;
-  return TIO_OK;
 }
 
 // `folded` comes back true when the launch itself produced every requested out_min_dev (planned FAST bricks)
@@ -829,28 +815,22 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           if (n_ctl[d] > 2 && (n_vox[d] - 1) < 16 * (n_ctl[d] - 1)) planned = false;
       }
       if (planned) {
+        // one single-channel image (what a FAST intensity launch almost always is): the lean kernel (resample_fast.hpp),
+        // whose bricks may be 8 planes thick (half the tile: twice the blocks per CU)
+        const bool lean = a.n_images == 1 && a.img[0].channels == 1 && a.img[0].out_min == nullptr &&
+                    !(getenv("TIO_PLANNED_LEAN") != nullptr && atoi(getenv("TIO_PLANNED_LEAN")) == 0);
+        const int64_t items64 = blocks;
         int cap_p = kLdsFloatsPerCU / kTileBlocksPerCU - 512;
         if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_p = v; }
         if (cap_p < kTileMinCap) cap_p = kTileMinCap;
         if (cap_p > kLdsFloatsPerCU) cap_p = kLdsFloatsPerCU;
         a.tile_cap = cap_p;
         a.cp_lds = 0;
-        size_t lds_p = static_cast<size_t>(cap_p) * sizeof(float);
-        const int n_items = static_cast<int>(blocks);
-        // planned2 (resample_fast.hpp, round 3): BPB bricks per block + split DMA wait.  TIO_PLANNED_V2="bpb:split"
-        // selects an instantiation (A/B, tests); "0" = the round-2 kernel.
-        int v2_bpb = kPlanned2Bpb, v2_split = kPlanned2Split;
-        if (const char* env = getenv("TIO_PLANNED_V2")) {
-          v2_bpb = atoi(env);
-          const char* colon = strchr(env, ':');
-          v2_split = colon != nullptr ? atoi(colon + 1) : 1;
-        }
-        if (a.cp != nullptr && n_cp > kMaxCpLds) v2_bpb = 0;  // the control points must fit next to the tile
-        if (a.cp != nullptr && v2_bpb > 0) {
-          a.cp_lds = (n_cp + 3) & ~3;
-          a.tile_cap = cap_p - a.cp_lds;  // same LDS per block: the planner sizes the boxes for what is left
-          if (a.tile_cap < kTileMinCap) { a.tile_cap = kTileMinCap; lds_p = static_cast<size_t>(a.tile_cap + a.cp_lds) * sizeof(float); }
-        }
+        const size_t lds_p = static_cast<size_t>(cap_p) * sizeof(float);
+        const int n_items = static_cast<int>(items64);
+        // round 3: DMA instructions that cover rows across x-plane boundaries (resample_fast.hpp: stream_stage_packed);
+        // TIO_DMA_PACKED=0 switches them off in the general kernel (A/B)
+        a.dma_packed = !(getenv("TIO_DMA_PACKED") != nullptr && atoi(getenv("TIO_DMA_PACKED")) == 0);
         if (const char* env = getenv("TIO_TILE_ABLATE")) a.ablate = atoi(env);
         PlanLease lease = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
         int* plan = lease.ptr;  // (the lease is released when this function returns: after both kernels are enqueued)
@@ -893,22 +873,28 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
             hipLaunchKernelGGL(min_finish_kernel, dim3(static_cast<unsigned>(min_channels)), dim3(kMinSlots), 0, s, min_keys, min_outs, min_channels);
           return check_launch("tio_resample3d");
         };
-        if (v2_bpb > 0 && min_channels == 0) {
-          auto launch_v2 = [&](auto kernel, int bpb) -> int {
+        if (lean && min_channels == 0) {
+          LeanArgs la{};
+          la.in = static_cast<const float*>(a.img[0].in); la.out = static_cast<float*>(a.img[0].out); la.fill = a.img[0].fill;
+          la.plan = plan; la.cp = a.cp;
+          la.I = a.I; la.J = a.J; la.K = a.K; la.Io = a.Io; la.Jo = a.Jo; la.Ko = a.Ko;
+          la.B = a.B; la.n_items = n_items;
+          la.bricks_per_element = static_cast<unsigned>(a.tiles_i) * a.tiles_j * a.tiles_k;
+          la.bpe_magic = la.bricks_per_element > 1 ? 0xFFFFFFFFu / la.bricks_per_element + 1u : 0u;
+          la.ni = a.ni; la.nj = a.nj; la.nk = a.nk; la.cp_batched = a.cp_batched;
+          la.sci = a.scale_i; la.scj = a.scale_j; la.sck = a.scale_k;
+          for (int e = 0; e < 3; e++) la.dsc[e] = a.rsp[e] * (a.affine_first ? a.half_h[e] / a.dh[e] : 1.0f);
+          la.hx = a.size_m1[0]; la.hy = a.size_m1[1]; la.hz = a.size_m1[2];
+          la.affine_first = a.affine_first; la.ablate = a.ablate;
+          auto launch_lean = [&](auto kernel) -> int {
             if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         static_cast<int>(lds_p)) != hipSuccess)
               return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
-            hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>((n_items + bpb - 1) / bpb)), dim3(256), lds_p, s, a, static_cast<const int*>(plan), n_items);
+            hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(256), lds_p, s, la);
             return check_launch("tio_resample3d");
           };
-#define TIO_V2(BPB, SPLIT)                                                                                   \
-  if (v2_bpb == BPB && v2_split == SPLIT) {                                                                  \
-    if (a.cp != nullptr) return launch_v2(resample_planned2_kernel<true, BPB, SPLIT>, BPB);                    \
-    return launch_v2(resample_planned2_kernel<false, BPB, SPLIT>, BPB);                                       \
-  }
-          TIO_V2(1, 1) TIO_V2(1, 2) TIO_V2(1, 4) TIO_V2(2, 1) TIO_V2(2, 4) TIO_V2(4, 1) TIO_V2(4, 2) TIO_V2(4, 4) TIO_V2(8, 1) TIO_V2(8, 4)
-#undef TIO_V2
-          return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: TIO_PLANNED_V2=%d:%d is not an instantiated variant", v2_bpb, v2_split);
+          if (a.cp != nullptr) return launch_lean(resample_planned_lean_kernel<true, 16, 16, 16>);
+          return launch_lean(resample_planned_lean_kernel<false, 16, 16, 16>);
         }
         if (a.cp != nullptr) return launch_planned(resample_planned_kernel<true, 16, 16, 16, 3>);
         return launch_planned(resample_planned_kernel<false, 16, 16, 16, 3>);

@@ -382,6 +382,59 @@ __device__ __forceinline__ int stream_stage(float* __restrict__ tile, const floa
   return issued;
 }
 
+// The same box with the DMA instructions PACKED (round 3): the rows of the box are one dense sequence in LDS (x-plane
+// after x-plane), and a wave instruction simply covers the next rpi rows of that sequence, whatever x-plane they belong
+// to.  stream_stage issues ceil(Ly / rpi) instructions per x-plane — for the bench geometry (Ly ~ 21, rpi = 10) three,
+// the third carrying a single row — i.e. 63 instructions for a box of 44 KiB; packed, the same box takes 45.  A
+// vector-memory instruction costs this kernel's CU about the same whatever it moves (profiles/r03_resample.md), so the
+// count is what matters.  The price is a per-lane address (row -> x-plane and row inside it, advanced incrementally)
+// instead of scalar pointer increments: a handful of vector instructions per DMA instruction.
+template <int NW>
+__device__ __forceinline__ int stream_stage_packed(float* __restrict__ tile, const float* __restrict__ src, const StreamBox& bx, int I, int J,
+                                                    int K, int wave, int lane, StageLanes& sl) {
+  typedef __attribute__((address_space(1))) const char* global_byte_ptr;
+  stage_lanes(sl, bx.cpr, K, lane);
+  const int rpi = sl.rpi;
+  const int total_rows = bx.Lx * bx.Ly;
+  // (uniform float divisions of small integers: exact after the half-step nudge)
+  const int n_instr = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(total_rows + rpi - 1) + 0.5f) * __builtin_amdgcn_rcpf(static_cast<float>(rpi))));
+  const int step = NW * rpi;  // rows between two instructions of this wave
+  const float rcp_ly = __builtin_amdgcn_rcpf(static_cast<float>(bx.Ly));
+  const int step_p = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(step) + 0.5f) * rcp_ly));
+  const int step_r = step - step_p * bx.Ly;
+  // this lane's first row of the sequence -> (x-plane, row)
+  int row = wave * rpi + sl.row_l;
+  int p = static_cast<int>((static_cast<float>(row) + 0.5f) * rcp_ly);
+  int r = row - p * bx.Ly;
+  const unsigned plane_b = static_cast<unsigned>(J) * static_cast<unsigned>(K) * 4u, row_b = static_cast<unsigned>(K) * 4u;
+  // byte offset of this lane's chunk from the box origin (inside one channel: < 2^32, resample.hip checks n_in < 2^30)
+  unsigned off = static_cast<unsigned>(p) * plane_b + static_cast<unsigned>(r) * row_b + static_cast<unsigned>(sl.gz_rel) * 4u;
+  const unsigned step_b = static_cast<unsigned>(step_p) * plane_b + static_cast<unsigned>(step_r) * row_b;
+  const unsigned wrap_b = plane_b - static_cast<unsigned>(bx.Ly) * row_b;  // one x-plane further, Ly rows back
+  global_byte_ptr origin = (global_byte_ptr)(src) + ((static_cast<int64_t>(bx.bx0) * J + bx.by0) * K + bx.za) * 4;
+  const int dgroup = rpi * bx.cpr * 4;  // LDS floats per instruction
+  float* lp = tile + wave * dgroup;
+  int issued = 0;
+  const bool ch_ok = static_cast<unsigned>(bx.za + sl.gz_rel) < static_cast<unsigned>(K);
+  for (int n = wave; n < n_instr; n += NW) {
+    const bool in_box = sl.lane_ok & (row < total_rows);
+    if (bx.interior) {
+      if (in_box) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
+      issued++;
+    } else {
+      const bool in_vol = in_box & ch_ok & (static_cast<unsigned>(bx.bx0 + p) < static_cast<unsigned>(I)) &
+                          (static_cast<unsigned>(bx.by0 + r) < static_cast<unsigned>(J));
+      if (__builtin_amdgcn_ballot_w64(in_vol) != 0ull) issued++;
+      if (in_vol) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
+      else if (in_box) *reinterpret_cast<float4*>(lp + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    row += step; p += step_p; r += step_r; off += step_b;
+    if (r >= bx.Ly) { r -= bx.Ly; p += 1; off += wrap_b; }
+    lp += NW * dgroup;
+  }
+  return issued;
+}
+
 typedef FastFrameT<const float*> FastFrameG;
 
 struct PipePlan {
@@ -492,9 +545,7 @@ __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, 
     f.cp = f.elastic ? a.cp + (a.cp_batched ? static_cast<int64_t>(p.b) * (a.ni * a.nj * a.nk * 3) : 0) : nullptr;
   }
   pipe_brick_frame(f, p.j_lo, p.k_lo);
-  // ext[7..9]: the largest first x-tap over the vertices of ONE plane level (first plane, last plane, the control-cell
-  // boundary between them) — what the split DMA wait of resample_planned2_kernel is sized from
-  int ext[10] = {-0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, 0, -0x40000000, -0x40000000, -0x40000000};
+  int ext[7] = {-0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, 0};
   const int n_vert = f.elastic ? 27 : 8;
   if (v < n_vert) {
     int r[6]; bool bad;
@@ -502,48 +553,14 @@ __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, 
 #pragma unroll
     for (int q = 0; q < 6; q++) ext[q] = r[q];
     ext[6] = bad ? 1 : 0;
-    const int level = f.elastic ? v % 3 : (v & 1);  // pipe_vertex: 0 = first plane, 1 = last plane, 2 = cell boundary
-    ext[7 + level] = r[1];
   }
 #pragma unroll
   for (int s = GROUP / 2; s > 0; s >>= 1) {
 #pragma unroll
-    for (int q = 0; q < 10; q++) ext[q] = max(ext[q], __shfl_xor(ext[q], s));
+    for (int q = 0; q < 7; q++) ext[q] = max(ext[q], __shfl_xor(ext[q], s));
   }
   if (v != 0) return;
-  d[10] = p.b; d[11] = p.i_begin; d[12] = p.j_lo; d[13] = p.k_lo;
-  {
-    // Split hints: bytes 0..2 of d[15] = how many x-planes of the box must have landed before the output planes of
-    // quarter 0, 1, 2 (4 planes each) can be sampled; 255 = all of them.  For a fixed column the x-coordinate is linear
-    // in the plane index inside one control cell, so the maximum over the brick's columns is CONVEX there: it stays below
-    // the chord between the two plane levels the planner has evaluated (first plane / cell boundary / last plane).
-    // Each level value is the floor of the largest coordinate + margin; +1 makes it an upper bound of the coordinate.
-    const int u_lo = p.i_begin, u_hi = p.i_begin + p.i_count - 1;
-    bool dense_i = false;
-    const float u_mid = f.elastic ? fast_breakpoint(f.sci, f.ni, u_lo, u_hi, dense_i) : static_cast<float>(u_lo);
-    const float x_lo = static_cast<float>(ext[7] + 1), x_hi = static_cast<float>(ext[8] + 1);
-    const float x_mid = f.elastic ? static_cast<float>(ext[9] + 1) : x_lo;
-    const bool has_mid = f.elastic && u_mid > static_cast<float>(u_lo) && u_mid < static_cast<float>(u_hi);
-    auto bound_at = [&](float t) -> float {
-      float ta = static_cast<float>(u_lo), tb = static_cast<float>(u_hi), xa = x_lo, xb = x_hi;
-      if (has_mid) { if (t <= u_mid) { tb = u_mid; xb = x_mid; } else { ta = u_mid; xa = x_mid; } }
-      if (!(tb > ta)) return fmaxf(xa, xb);
-      const float w = fminf(fmaxf((t - ta) / (tb - ta), 0.0f), 1.0f);
-      return fmaxf(xa + w * (xb - xa), fminf(xa, xb)) + 0.0625f;  // (float rounding of the chord itself)
-    };
-    unsigned hints = 0;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const float t0 = static_cast<float>(min(u_lo + 4 * q, u_hi)), t1 = static_cast<float>(min(u_lo + 4 * q + 3, u_hi));
-      float need = fmaxf(bound_at(t0), bound_at(t1));
-      if (has_mid && u_mid >= t0 && u_mid <= t1) need = fmaxf(need, x_mid + 0.0625f);
-      // second tap = floor(x) + 1 <= floor(need) + 1; planes needed = that index - xmin + 1
-      int planes = static_cast<int>(floorf(need)) + 2 + ext[0];  // ext[0] = -xmin
-      planes = max(planes, 1);
-      hints |= static_cast<unsigned>(planes >= 255 ? 255 : planes) << (8 * q);
-    }
-    d[15] = static_cast<int>(hints);
-  }
+  d[10] = p.b; d[11] = p.i_begin; d[12] = p.j_lo; d[13] = p.k_lo; d[15] = 0;
   const int xmin = -ext[0], xmax = ext[1], ymin = -ext[2], ymax = ext[3], zmin = -ext[4], zmax = ext[5];
   const bool wrd = weird | (ext[6] != 0);
   const int interior = (xmin >= 0) & (xmax + 1 <= a.I - 1) & (ymin >= 0) & (ymax + 1 <= a.J - 1) & (zmin >= 0) & (zmax + 1 <= a.K - 1) & !wrd;
@@ -715,7 +732,10 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
       const bool has_fill = g.fill != nullptr;
       const float fillv = has_fill ? ((const_float_ptr)g.fill)[c] : 0.0f;
       if (!first) __syncthreads();  // the previous channel's taps are read
-      if (!(a.ablate & 1)) stream_stage<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+      if (!(a.ablate & 1)) {
+        if (a.dma_packed) stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+        else stream_stage<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+      }
       if (first) {
 #pragma unroll
         for (int r = 0; r < 3; r++) col3[r] = __builtin_fmaf(f.m[4 * r + 1], fv, f.m[4 * r + 2] * fw);
@@ -736,12 +756,11 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
       uint32_t kmin = 0xFFFFFFFFu;
       if (col_active && !(a.ablate & 2)) {
         for (;;) {
+          char* o_run = out_chan + static_cast<int64_t>(run0) * slab_b;
           if (track)
-            fast_sample_line<4, true>(run1 - run0, A3, B3, ta, out_chan + static_cast<int64_t>(run0) * slab_b, urow, slab_b, has_fill & !bx.interior, ox,
-                                      oy, oz, hx, hy, hz, fillv, kmin);
+            fast_sample_line<4, true>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, has_fill & !bx.interior, ox, oy, oz, hx, hy, hz, fillv, kmin);
           else
-            fast_sample_line<4, false>(run1 - run0, A3, B3, ta, out_chan + static_cast<int64_t>(run0) * slab_b, urow, slab_b, has_fill & !bx.interior, ox,
-                                       oy, oz, hx, hy, hz, fillv, kmin);
+            fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, has_fill & !bx.interior, ox, oy, oz, hx, hy, hz, fillv, kmin);
           run0 = run1;
           if (run0 >= u1) break;
           run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3);
@@ -753,268 +772,197 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
 }
 
 
-// =====================================================================================================================
-// Round 3: the planned bricks as a SHORT CHAIN per block (profiles/r03_resample.md).
-//
-// resample_planned_kernel's four parts — block start, fetch, sampling, store drain — add up because a CU holds three
-// one-brick blocks (LDS) and a block's life is a chain of latencies.  Two changes to the chain, same arithmetic:
-//   * BPB bricks per block, one after the other through the same LDS tile.  The next brick's descriptor is loaded while
-//     the current one is sampled, its DMA is issued right after the barrier that ends the sampling, and — the point —
-//     the stores of brick n drain UNDER the fetch of brick n + 1 instead of holding the block's LDS until they are
-//     acknowledged (a wave cannot end with stores outstanding).  One block start per BPB bricks.
-//   * the DMA wait is SPLIT: every wave issues its x-planes in ascending order; plan_bricks_kernel says how many
-//     x-planes the output planes of each quarter (4 planes) can touch (d[15], a convexity bound), so sampling of
-//     quarter 0 starts when roughly half of the box has landed, under a counted `s_waitcnt vmcnt(N)`, and the rest
-//     lands under the arithmetic.  N = this wave's DMA instructions that may still be outstanding + the stores it has
-//     issued since (vector memory operations of a wave complete in order on gfx9-family hardware; the compiler's own
-//     wait insertion relies on the same property).
-// The waits and barriers are ONE asm statement with a memory clobber: `__syncthreads()` would drain vmcnt (and the
-// stores with it), a bare `__builtin_amdgcn_s_barrier()` does not order the LDS reads around it.
-// =====================================================================================================================
-#define TIO_WB_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-__device__ __forceinline__ void wait_vmcnt_then_barrier(int n) {  // n: wave uniform
-  switch (n) {
-    TIO_WB_CASE(0) TIO_WB_CASE(1) TIO_WB_CASE(2) TIO_WB_CASE(3) TIO_WB_CASE(4) TIO_WB_CASE(5) TIO_WB_CASE(6) TIO_WB_CASE(7)
-    TIO_WB_CASE(8) TIO_WB_CASE(9) TIO_WB_CASE(10) TIO_WB_CASE(11) TIO_WB_CASE(12) TIO_WB_CASE(13) TIO_WB_CASE(14) TIO_WB_CASE(15)
-    TIO_WB_CASE(16) TIO_WB_CASE(17) TIO_WB_CASE(18) TIO_WB_CASE(19) TIO_WB_CASE(20) TIO_WB_CASE(21) TIO_WB_CASE(22) TIO_WB_CASE(23)
-    TIO_WB_CASE(24) TIO_WB_CASE(25) TIO_WB_CASE(26) TIO_WB_CASE(27) TIO_WB_CASE(28) TIO_WB_CASE(29) TIO_WB_CASE(30) TIO_WB_CASE(31)
-    TIO_WB_CASE(32) TIO_WB_CASE(33) TIO_WB_CASE(34) TIO_WB_CASE(35) TIO_WB_CASE(36) TIO_WB_CASE(37) TIO_WB_CASE(38) TIO_WB_CASE(39)
-    TIO_WB_CASE(40) TIO_WB_CASE(41) TIO_WB_CASE(42) TIO_WB_CASE(43) TIO_WB_CASE(44) TIO_WB_CASE(45) TIO_WB_CASE(46) TIO_WB_CASE(47)
-    TIO_WB_CASE(48) TIO_WB_CASE(49) TIO_WB_CASE(50) TIO_WB_CASE(51) TIO_WB_CASE(52) TIO_WB_CASE(53) TIO_WB_CASE(54) TIO_WB_CASE(55)
-    TIO_WB_CASE(56) TIO_WB_CASE(57) TIO_WB_CASE(58) TIO_WB_CASE(59) TIO_WB_CASE(60) TIO_WB_CASE(61) TIO_WB_CASE(62)
-    default: asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-  }
-}
-#undef TIO_WB_CASE
-__device__ __forceinline__ void lds_reads_done_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool ELASTIC_POSSIBLE, int BPB, int SPLIT>
-__global__ __launch_bounds__(256, 3) void resample_planned2_kernel(const ResampleArgs a, const int* __restrict__ plan, int n_items) {
-  constexpr int TI = 16, TJ = 16, TK = 16, NW = 4;
-  constexpr int QS = TI / SPLIT;  // output planes per wait
-  static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT");
+// =====================================================================================================================
+// Round 3: the LEAN planned kernel — one float32 trilinear image with one channel, which is what a FAST launch of an
+// intensity image almost always is (the bench's two launches; multi-image / multi-channel launches keep
+// resample_planned_kernel above).
+//
+// Shader-clock stamps in the general kernel (profiles/r03_planned2_stamps.log) showed where a block's life goes:
+// 900 ticks to its descriptor, **6 400 from the descriptor to the last DMA instruction issued**, 2 400 until the box has
+// landed, 5 900 of sampling, 600 until the stores are acknowledged.  The 6 400 are not the DMA: halving the number of
+// vector-memory instructions (packed DMA rows, 16-byte stores) changed nothing.  They are the PROLOGUE — ~550
+// instructions and five dependent scalar-load round trips (grid size -> plan pointer -> descriptor -> mapping ->
+// image table -> fill value) generated from a 900-byte argument struct with image and channel loops, 64 spilled scalar
+// registers — executed by waves that are nearly alone on their SIMDs (~9 clocks per dependent instruction).  Same
+// arithmetic here, organised for the shortest road to the first DMA instruction: a 150-byte argument block that arrives
+// in the first scalar loads, the descriptor and the element's mapping requested TOGETHER (the element index comes from
+// the brick index by a multiply-high, not from the descriptor), lane constants formed in the shadow of those loads,
+// no loops over images or channels, the per-column constants after the DMA has been issued.
+// =====================================================================================================================
+struct LeanArgs {
+  const float* in;    // (B, 1, I, J, K)
+  float* out;         // (B, 1, Io, Jo, Ko)
+  const float* fill;  // one float, or nullptr (no fill rule)
+  const int* plan;    // plan_bricks_kernel's output
+  const float* cp;    // control points (ELASTIC_POSSIBLE) or nullptr
+  int I, J, K, Io, Jo, Ko;
+  int B, n_items;
+  unsigned bricks_per_element, bpe_magic;
+  int ni, nj, nk, cp_batched;
+  float sci, scj, sck;
+  float dsc[3];
+  float hx, hy, hz;
+  int affine_first, ablate;
+};
+
+// FAST trilinear sample straight from global memory (bricks whose box does not fit the tile, non-finite geometry): zero
+// padding, the staged path's lerp nest and separable fill rule
+__device__ __forceinline__ float lean_gather(const float* __restrict__ chan, int I, int J, int K, float x, float y, float z, bool has_fill,
+                                             float fillv, float hx, float hy, float hz) {
+  if (!(fabsf(x) <= 1e30f) | !(fabsf(y) <= 1e30f) | !(fabsf(z) <= 1e30f)) return has_fill ? fillv : 0.0f;  // NaN / Inf: nothing in bounds
+  const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+  FastTaps ts;
+  ts.fx = x - x0; ts.fy = y - y0; ts.fz = z - z0;
+  const float cx = fminf(fmaxf(x0, -2.0f), hx + 1.0f), cy = fminf(fmaxf(y0, -2.0f), hy + 1.0f), cz = fminf(fmaxf(z0, -2.0f), hz + 1.0f);
+  const int ix = static_cast<int>(cx), iy = static_cast<int>(cy), iz = static_cast<int>(cz);
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const int px = ix + (t & 1), py = iy + ((t >> 1) & 1), pz = iz + (t >> 2);
+    const bool ok = (static_cast<unsigned>(px) < static_cast<unsigned>(I)) & (static_cast<unsigned>(py) < static_cast<unsigned>(J)) &
+                    (static_cast<unsigned>(pz) < static_cast<unsigned>(K)) & (cx == x0) & (cy == y0) & (cz == z0);
+    ts.v[t] = ok ? chan[(static_cast<int64_t>(px) * J + py) * K + pz] : 0.0f;
+  }
+  float val = fast_finish(ts);
+  if (has_fill) val = (fast_mask(ts, x0, y0, z0, hx, hy, hz) > 0.5f) ? val : fillv;
+  return val;
+}
+
+// Brick shape TI x TJ x TK (planes x rows x lanes along K, TJ * TK = 256 threads); the planner is instantiated for the same
+// shape.  Tried and dropped (profiles/r03_resample.md): eight waves per 16-plane brick (two threads per column) — no
+// faster for affine launches, much slower for elastic ones; 8-plane bricks with five or six blocks per CU — no faster;
+// 16 x 8 x 32 bricks (longer rows: fewer, fuller cache lines) — boxes outgrow the tile, slower; 16-byte stores through a
+// quad transpose — a quarter of the store instructions, no faster (the transpose costs what the stores saved).
+template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK>
+__global__ __launch_bounds__(256, 3) void resample_planned_lean_kernel(const LeanArgs a) {
+  constexpr int NW = 4;
+  static_assert(TJ * TK == 256 && (TK & (TK - 1)) == 0, "one thread per column of the brick");
+  constexpr int PLANES = TI;  // output planes per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // elastic launches: the control points of the block's batch element live in LDS (a.cp_lds floats in front of the tile),
-  // so that the per-column control planes are ds_reads — a vector load from global memory would make the compiler wait
-  // for everything this wave has in flight (the DMA, the previous brick's stores) before the line can be formed
-  float* s_cp = smem;
-  float* s_tile = smem + (ELASTIC_POSSIBLE ? a.cp_lds : 0);
-  int cp_element = -1;  // batch element whose control points are staged
+  float* s_tile = smem;
   typedef __attribute__((address_space(4))) const int* const_int_ptr;
   typedef __attribute__((address_space(4))) const float* const_float_ptr;
 
-  const unsigned group = xcd_remap(blockIdx.x, gridDim.x);
+  // every argument the road to the first DMA needs, in scalar registers NOW: the loads go out back to back and share one
+  // wait (left to itself the compiler fetches each kernel argument right before its first use: five round trips)
+  {
+    const int* plan_p = a.plan; const float* in_p = a.in;
+    asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K),
+                 "s"(a.ablate));
+  }
+  const unsigned brick = xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items));
+  const int b = static_cast<int>(fastdiv(brick, a.bpe_magic, a.bricks_per_element));
+  // the two scalar loads everything waits for, requested together
+  const_int_ptr d = (const_int_ptr)(a.plan + a.B * 16) + static_cast<size_t>(brick) * kDescInts;
+  const_float_ptr fm = (const_float_ptr)(a.plan) + b * 16;
+  const int kind_w = d[0];
+  StreamBox bx;
+  bx.bx0 = d[1]; bx.by0 = d[2]; bx.za = d[3]; bx.Lx = d[4]; bx.Ly = d[5]; bx.cpr = d[6];
+  const float C3[3] = {__int_as_float(d[7]), __int_as_float(d[8]), __int_as_float(d[9])};
+  const int i_begin = d[11], j_lo = d[12], k_lo = d[13];
+  const bool elastic = ELASTIC_POSSIBLE && d[14] != 0;
+  FastFrameG f;
+#pragma unroll
+  for (int q = 0; q < 12; q++) f.m[q] = fm[q];
+
+  // lane constants (no dependence on the loads above)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tk = tid % TK, tj = tid / TK;
-  const int64_t n_in = static_cast<int64_t>(a.I) * a.J * a.K;
-  const int64_t n_out = static_cast<int64_t>(a.Io) * a.Jo * a.Ko;
+  const int tk = tid & (TK - 1), tj = tid / TK;
+  constexpr int part = 0;
   const int slab = a.Jo * a.Ko;
   const int64_t slab_b = static_cast<int64_t>(slab) * 4;
-  const float hx = a.size_m1[0], hy = a.size_m1[1], hz = a.size_m1[2];
-  const float ratio[3] = {a.half_h[0] / a.dh[0], a.half_h[1] / a.dh[1], a.half_h[2] / a.dh[2]};
-  const bool check = (a.ablate & 8) != 0;  // self-check of the split hints (tests): a tap beyond the promised planes poisons the output
-  // profiling (TIO_TILE_ABLATE & 16, tests/native/resample_bench --stamps): wave 0 overwrites its brick's descriptor with
-  // shader-clock stamps — entry, descriptor in registers, DMA issued, box landed, sampling done, stores acknowledged
-  const bool stamps = (a.ablate & 16) != 0;
-  const uint64_t t_entry = stamps ? __builtin_amdgcn_s_memtime() : 0;
+  const int64_t n_in = static_cast<int64_t>(a.I) * a.J * a.K;
+  const int64_t n_out = static_cast<int64_t>(a.Io) * slab;
+  const float* in_chan = a.in + static_cast<int64_t>(b) * n_in;
+  char* out_chan = reinterpret_cast<char*>(a.out + static_cast<int64_t>(b) * n_out);
 
-  StageLanes sl;
-  sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
-  bool tile_in_use = false;  // block uniform: somebody may still be reading the tile
+  const int kind = kind_w & 0xFF;
+  bx.kind = kind; bx.interior = kind_w >> 8;
+  if (kind == kDescStaged && !(a.ablate & 1)) {  // the road to the first DMA instruction ends here
+    StageLanes sl;
+    sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
+    stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+  }
 
-  const unsigned first_brick = group * BPB;
-  const_int_ptr d_base = (const_int_ptr)(plan + a.B * 16);
-#pragma unroll 1
-  for (int nb = 0; nb < BPB; nb++) {
-    const unsigned brick = first_brick + nb;
-    if (brick >= static_cast<unsigned>(n_items)) break;
-    const_int_ptr d = d_base + static_cast<size_t>(brick) * kDescInts;
-    const int kind_w = d[0];
-    const int kind = kind_w & 0xFF;
-    StreamBox bx;
-    bx.kind = kind; bx.interior = kind_w >> 8;
-    bx.bx0 = d[1]; bx.by0 = d[2]; bx.za = d[3]; bx.Lx = d[4]; bx.Ly = d[5]; bx.cpr = d[6];
-    const float C3[3] = {__int_as_float(d[7]), __int_as_float(d[8]), __int_as_float(d[9])};
-    const int b = d[10], i_begin = d[11], j_lo = d[12], k_lo = d[13];
-    const bool elastic = ELASTIC_POSSIBLE && d[14] != 0;
-    const unsigned hints = static_cast<unsigned>(d[15]);
-    uint64_t t_desc = 0, t_issued = 0, t_landed = 0, t_sampled = 0;
-    if (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_desc = __builtin_amdgcn_s_memtime(); }
+  const int i_count = min(TI, a.Io - i_begin), nv = min(TJ, a.Jo - j_lo), nw = min(TK, a.Ko - k_lo);
+  const bool col_active = (tj < nv) & (tk < nw);
+  const int jv = min(tj, nv - 1), kw = min(tk, nw - 1);
+  const int col_off = (j_lo + jv) * a.Ko + (k_lo + kw);
+  const unsigned urow = static_cast<unsigned>(col_off) * 4u;
+  const int u_ref = i_begin;  // plane the descriptor's line constants refer to
+  const int u0 = min(i_begin + part * PLANES, i_begin + i_count), u1 = min(u0 + PLANES, i_begin + i_count);
+  const bool has_fill = a.fill != nullptr;
+  const float fillv = has_fill ? ((const_float_ptr)a.fill)[0] : 0.0f;
+  const float hx = a.hx, hy = a.hy, hz = a.hz;
 
-    const int i_count = min(TI, a.Io - i_begin), nv = min(TJ, a.Jo - j_lo), nw = min(TK, a.Ko - k_lo);
-    const bool col_active = (tj < nv) & (tk < nw);
-    const bool wave_active = __builtin_amdgcn_ballot_w64(col_active) != 0ull;
-    const int jv = min(tj, nv - 1), kw = min(tk, nw - 1);
-    const int col_off = (j_lo + jv) * a.Ko + (k_lo + kw);
-    const unsigned urow = static_cast<unsigned>(col_off) * 4u;
-    const int u0 = i_begin, u1 = i_begin + i_count;
-
-    if (kind == kDescGated || kind == kDescOutside) {  // gated-out element: bit-exact copy; nothing of the volume in sight: fill (or 0)
-      for (int im = 0; im < a.n_images; im++) {
-        const ImgArgs& g = a.img[im];
-        for (int c = 0; c < g.channels; c++) {
-          const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
-          char* out_chan = static_cast<char*>(g.out) + bc * n_out * 4;
-          const float* in_chan = static_cast<const float*>(g.in) + bc * n_in;
-          const float fillv = g.fill != nullptr ? ((const_float_ptr)g.fill)[c] : 0.0f;
-          if (col_active) {
-            for (int t = u0; t < u1; t++) {
-              const float val = kind == kDescGated ? in_chan[static_cast<int64_t>(t) * slab + col_off] : fillv;
-              *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
-            }
-          }
-        }
-      }
-      continue;
-    }
-
-    FastFrame f;  // (control points in LDS)
-    {
-      const_float_ptr fm = (const_float_ptr)(plan) + b * 16;
-#pragma unroll
-      for (int q = 0; q < 12; q++) f.m[q] = fm[q];
-    }
-    f.affine_first = a.affine_first != 0;
-    f.ni = a.ni; f.nj = a.nj; f.nk = a.nk; f.sci = a.scale_i; f.scj = a.scale_j; f.sck = a.scale_k;
-    f.elastic = elastic;
-    f.cp = (fast_lds_ptr)s_cp;
-    f.j_lo = j_lo; f.k_lo = k_lo;
-#pragma unroll
-    for (int e = 0; e < 3; e++) { f.dsc[e] = a.rsp[e] * (f.affine_first ? ratio[e] : 1.0f); f.c[e] = 0.0; }
-
-    if (kind == kDescSlow) {  // box beyond the LDS budget / non-finite geometry: per-voxel evaluation, global gathers (rare)
-      FastFrameG fg;
-#pragma unroll
-      for (int q = 0; q < 12; q++) fg.m[q] = f.m[q];
-      fg.affine_first = f.affine_first; fg.ni = f.ni; fg.nj = f.nj; fg.nk = f.nk; fg.sci = f.sci; fg.scj = f.scj; fg.sck = f.sck;
-      fg.elastic = elastic;
-      fg.cp = elastic ? a.cp + (a.cp_batched ? static_cast<int64_t>(b) * (a.ni * a.nj * a.nk * 3) : 0) : nullptr;
-#pragma unroll
-      for (int e = 0; e < 3; e++) fg.dsc[e] = f.dsc[e];
-      pipe_brick_frame(fg, j_lo, k_lo);
-      for (int im = 0; im < a.n_images; im++) {
-        const ImgArgs& g = a.img[im];
-        if (col_active) {
-          for (int t = u0; t < u1; t++) {
-            float x, y, z;
-            fast_coord(fg, static_cast<float>(t), static_cast<float>(jv), static_cast<float>(kw), x, y, z);
-            gather_voxel<0>(g, a, b, n_in, n_out, t * slab + col_off, x, y, z, false);
-          }
-        }
-      }
-      continue;
-    }
-
-    if constexpr (ELASTIC_POSSIBLE) {
-      if (elastic && cp_element != b) {  // (block uniform; once per block unless its bricks straddle two batch elements)
-        if (tile_in_use) lds_reads_done_barrier();  // columns may still be reading the previous element's control planes
-        const int n_cp = a.ni * a.nj * a.nk * 3;
-        const float* src = a.cp + (a.cp_batched ? static_cast<int64_t>(b) * n_cp : 0);
-        for (int t = tid; t < n_cp; t += 256) s_cp[t] = src[t];
-        __syncthreads();
-        cp_element = b;
+  if (kind == kDescGated || kind == kDescOutside) {  // gated-out element: bit-exact copy; nothing of the volume in sight: fill (or 0)
+    if (col_active) {
+      for (int t = u0; t < u1; t++) {
+        const float val = kind == kDescGated ? in_chan[static_cast<int64_t>(t) * slab + col_off] : fillv;
+        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
       }
     }
-    // per-column constants of this brick
-    const float fv = static_cast<float>(jv), fw = static_cast<float>(kw);
-    float col3[3];
+    return;
+  }
+
+  f.affine_first = a.affine_first != 0;
+  f.ni = a.ni; f.nj = a.nj; f.nk = a.nk; f.sci = a.sci; f.scj = a.scj; f.sck = a.sck;
+  f.elastic = elastic;
+  f.cp = elastic ? a.cp + (a.cp_batched ? static_cast<int64_t>(b) * (a.ni * a.nj * a.nk * 3) : 0) : nullptr;
+  f.j_lo = j_lo; f.k_lo = k_lo;
 #pragma unroll
-    for (int r = 0; r < 3; r++) col3[r] = __builtin_fmaf(f.m[4 * r + 1], fv, f.m[4 * r + 2] * fw);
-    Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
-    if constexpr (ELASTIC_POSSIBLE) {
-      if (elastic) {
-        lj = lerp_index(j_lo + jv, a.nj, a.Jo, a.scale_j);
-        lk = lerp_index(k_lo + kw, a.nk, a.Ko, a.scale_k);
+  for (int e = 0; e < 3; e++) { f.dsc[e] = a.dsc[e]; f.c[e] = 0.0; }
+
+  if (kind == kDescSlow) {  // box beyond the LDS budget / non-finite geometry: per-voxel evaluation, global gathers (rare)
+    pipe_brick_frame(f, j_lo, k_lo);
+    if (col_active) {
+      for (int t = u0; t < u1; t++) {
+        float x, y, z;
+        fast_coord(f, static_cast<float>(t), static_cast<float>(jv), static_cast<float>(kw), x, y, z);
+        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = lean_gather(in_chan, a.I, a.J, a.K, x, y, z, has_fill, fillv, hx, hy, hz);
       }
     }
-    FastAddr ta;
-    ta.sYb = bx.cpr * 16; ta.sXb = bx.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
-    ta.sYf = static_cast<float>(ta.sYb); ta.sXf = static_cast<float>(ta.sXb);
-    ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
-    const float ox = static_cast<float>(bx.bx0), oy = static_cast<float>(bx.by0), oz = static_cast<float>(bx.za);
+    return;
+  }
 
-    for (int im = 0; im < a.n_images; im++) {
-      const ImgArgs& g = a.img[im];
-      for (int c = 0; c < g.channels; c++) {
-        const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
-        char* out_chan = static_cast<char*>(g.out) + bc * n_out * 4;
-        const float* in_chan = static_cast<const float*>(g.in) + bc * n_in;
-        const bool has_fill = g.fill != nullptr;
-        const float fillv = has_fill ? ((const_float_ptr)g.fill)[c] : 0.0f;
-        ColumnPlanes planes;
-        planes.cell = -2;
+  // per-column constants, formed while the box is on its way
+  const float fv = static_cast<float>(jv), fw = static_cast<float>(kw);
+  float col3[3];
 #pragma unroll
-        for (int e = 0; e < 3; e++) { planes.P0[e] = 0.0f; planes.P1[e] = 0.0f; }
-        float A3[3], B3[3];
-        int run0 = u0;
-        if (tile_in_use) lds_reads_done_barrier();  // the previous brick's / channel's taps are read
-        const int issued = stream_stage<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
-        tile_in_use = true;
-        if (stamps) t_issued = __builtin_amdgcn_s_memtime();
-        int run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3);
-        // this wave's DMA instructions per x-plane (interior boxes: the same for every plane) and planes
-        const int planes_w = bx.Lx > wave ? (bx.Lx - wave + NW - 1) / NW : 0;
-        const int ipp = planes_w > 0 ? issued / planes_w : 0;
-        const bool split = SPLIT > 1 && bx.interior != 0 && i_count == TI && ipp * planes_w == issued;
-        int stores = 0;  // store instructions of this wave since its DMA was issued
-#pragma unroll 1
-        for (int q = 0; q < SPLIT; q++) {
-          const int p_begin = u0 + q * QS;
-          if (p_begin >= u1) break;
-          const int p_end = min(p_begin + QS, u1);
-          int promised = 255;  // x-planes landed for sure after the wait below
-          if (q == 0 || split) {
-            int allowed = 0;
-            if (split && q < SPLIT - 1) {
-              // quarters covered by this wait: 4-plane quarters q * (4 / SPLIT) ... ; the hint of the LAST one is the largest
-              // only for increasing coordinates, so take the maximum over the covered ones
-              int need = 0;
+  for (int r = 0; r < 3; r++) col3[r] = __builtin_fmaf(f.m[4 * r + 1], fv, f.m[4 * r + 2] * fw);
+  Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
+  if constexpr (ELASTIC_POSSIBLE) {
+    if (elastic) {
+      lj = lerp_index(j_lo + jv, a.nj, a.Jo, a.scj);
+      lk = lerp_index(k_lo + kw, a.nk, a.Ko, a.sck);
+    }
+  }
+  ColumnPlanes planes;
+  planes.cell = -2;
 #pragma unroll
-              for (int h = 0; h < 3; h++)
-                if (h >= q * (4 / SPLIT) && h < (q + 1) * (4 / SPLIT)) need = max(need, static_cast<int>((hints >> (8 * h)) & 255u));
-              if (need < 255 && need < bx.Lx) {
-                promised = need;
-                const int done_w = need > wave ? min((need - wave + NW - 1) / NW, planes_w) : 0;
-                allowed = (planes_w - done_w) * ipp;
-              }
-            }
-            wait_vmcnt_then_barrier(min(allowed + stores, 63));
-            if (stamps && q == 0) t_landed = __builtin_amdgcn_s_memtime();
-          }
-          int p = p_begin;
-          while (p < p_end) {
-            if (p >= run1) { run0 = run1; run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3); }
-            const int e = min(run1, p_end);
-            const float off = static_cast<float>(p - run0);
-            const float A[3] = {__builtin_fmaf(off, B3[0], A3[0]), __builtin_fmaf(off, B3[1], A3[1]), __builtin_fmaf(off, B3[2], A3[2])};
-            if (col_active) {
-              uint32_t kmin = 0xFFFFFFFFu;
-              fast_sample_line<4, false>(e - p, A, B3, ta, out_chan + static_cast<int64_t>(p) * slab_b, urow, slab_b, has_fill & !bx.interior, ox, oy, oz,
-                                         hx, hy, hz, fillv, kmin);
-              if (check && promised < 255) {  // the second x-tap of every plane of this piece must lie inside the promised planes
-                const float xa = A[0], xb = __builtin_fmaf(static_cast<float>(e - p - 1), B3[0], A[0]);
-                if (!(floorf(fmaxf(xa, xb)) + 1.0f <= static_cast<float>(promised - 1)))
-                  *reinterpret_cast<float*>(out_chan + static_cast<int64_t>(p) * slab_b + urow) = __int_as_float(0x7FC00000);
-              }
-            }
-            if (wave_active) stores += e - p;
-            p = e;
-          }
-        }
-        if (stamps) {
-          t_sampled = __builtin_amdgcn_s_memtime();
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const uint64_t t_drained = __builtin_amdgcn_s_memtime();
-          if (tid == 0) {
-            uint64_t* w = reinterpret_cast<uint64_t*>(const_cast<int*>(plan + a.B * 16) + static_cast<size_t>(brick) * kDescInts);
-            w[0] = t_entry; w[1] = t_desc; w[2] = t_issued; w[3] = t_landed; w[4] = t_sampled; w[5] = t_drained;
-            w[6] = (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) << 32) | static_cast<uint64_t>(nb);
-            w[7] = 0x5354414D50ull;  // "STAMP": the host side only reads descriptors that carry it
-          }
-        }
-      }
+  for (int e = 0; e < 3; e++) { planes.P0[e] = 0.0f; planes.P1[e] = 0.0f; }
+  FastAddr ta;
+  ta.sYb = bx.cpr * 16; ta.sXb = bx.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
+  ta.sYf = static_cast<float>(ta.sYb); ta.sXf = static_cast<float>(ta.sXb);
+  ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
+  const float ox = static_cast<float>(bx.bx0), oy = static_cast<float>(bx.by0), oz = static_cast<float>(bx.za);
+
+  float A3[3], B3[3];
+  int run0 = u0;
+  int run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
+  tile_dma_wait();
+  __syncthreads();
+  if (col_active && u0 < u1 && !(a.ablate & 2)) {
+    uint32_t kmin = 0xFFFFFFFFu;
+    const bool needs_mask = has_fill & !bx.interior;
+    for (;;) {
+      char* o_run = out_chan + static_cast<int64_t>(run0) * slab_b;
+      fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, needs_mask, ox, oy, oz, hx, hy, hz, fillv, kmin);
+      run0 = run1;
+      if (run0 >= u1) break;
+      run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
     }
   }
 }
