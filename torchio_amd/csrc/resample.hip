@@ -817,8 +817,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       if (planned) {
         // one single-channel image (what a FAST intensity launch almost always is): the lean kernel (resample_fast.hpp),
         // whose bricks may be 8 planes thick (half the tile: twice the blocks per CU)
-        const bool lean = a.n_images == 1 && a.img[0].channels == 1 && a.img[0].out_min == nullptr &&
-                    !(getenv("TIO_PLANNED_LEAN") != nullptr && atoi(getenv("TIO_PLANNED_LEAN")) == 0);
+        bool lean = !(getenv("TIO_PLANNED_LEAN") != nullptr && atoi(getenv("TIO_PLANNED_LEAN")) == 0);
+        for (int i = 0; i < a.n_images; i++) lean = lean && a.img[i].out_min == nullptr;
         const int64_t items64 = blocks;
         int cap_p = kLdsFloatsPerCU / kTileBlocksPerCU - 512;
         if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_p = v; }
@@ -875,7 +875,6 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         };
         if (lean && min_channels == 0) {
           LeanArgs la{};
-          la.in = static_cast<const float*>(a.img[0].in); la.out = static_cast<float*>(a.img[0].out); la.fill = a.img[0].fill;
           la.plan = plan; la.cp = a.cp;
           la.I = a.I; la.J = a.J; la.K = a.K; la.Io = a.Io; la.Jo = a.Jo; la.Ko = a.Ko;
           la.B = a.B; la.n_items = n_items;
@@ -886,15 +885,23 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           for (int e = 0; e < 3; e++) la.dsc[e] = a.rsp[e] * (a.affine_first ? a.half_h[e] / a.dh[e] : 1.0f);
           la.hx = a.size_m1[0]; la.hy = a.size_m1[1]; la.hz = a.size_m1[2];
           la.affine_first = a.affine_first; la.ablate = a.ablate;
-          auto launch_lean = [&](auto kernel) -> int {
-            if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        static_cast<int>(lds_p)) != hipSuccess)
-              return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
-            hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(256), lds_p, s, la);
-            return check_launch("tio_resample3d");
-          };
-          if (a.cp != nullptr) return launch_lean(resample_planned_lean_kernel<true, 16, 16, 16>);
-          return launch_lean(resample_planned_lean_kernel<false, 16, 16, 16>);
+          auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16> : resample_planned_lean_kernel<false, 16, 16, 16>;
+          if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      static_cast<int>(lds_p)) != hipSuccess)
+            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
+          // one plan, one launch per channel of every image (the geometry, hence the plan, is shared)
+          for (int i = 0; i < a.n_images; i++) {
+            const ImgArgs& g = a.img[i];
+            la.in_stride = static_cast<int64_t>(g.channels) * n_in;
+            la.out_stride = static_cast<int64_t>(g.channels) * n_out;
+            for (int c = 0; c < g.channels; c++) {
+              la.in = static_cast<const float*>(g.in) + static_cast<int64_t>(c) * n_in;
+              la.out = static_cast<float*>(g.out) + static_cast<int64_t>(c) * n_out;
+              la.fill = g.fill != nullptr ? g.fill + c : nullptr;
+              hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(256), lds_p, s, la);
+            }
+          }
+          return check_launch("tio_resample3d");
         }
         if (a.cp != nullptr) return launch_planned(resample_planned_kernel<true, 16, 16, 16, 3>);
         return launch_planned(resample_planned_kernel<false, 16, 16, 16, 3>);

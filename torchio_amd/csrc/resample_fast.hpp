@@ -774,9 +774,9 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
 
 
 // =====================================================================================================================
-// Round 3: the LEAN planned kernel — one float32 trilinear image with one channel, which is what a FAST launch of an
-// intensity image almost always is (the bench's two launches; multi-image / multi-channel launches keep
-// resample_planned_kernel above).
+// Round 3: the LEAN planned kernel — ONE channel of one float32 trilinear image per launch; a FAST call with several images
+// or channels is one plan and one lean launch per channel (resample_planned_kernel above, with its image / channel loops,
+// remains for launches that fold the minimum of their output).
 //
 // Shader-clock stamps in the general kernel (profiles/r03_planned2_stamps.log) showed where a block's life goes:
 // 900 ticks to its descriptor, **6 400 from the descriptor to the last DMA instruction issued**, 2 400 until the box has
@@ -791,8 +791,9 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
 // no loops over images or channels, the per-column constants after the DMA has been issued.
 // =====================================================================================================================
 struct LeanArgs {
-  const float* in;    // (B, 1, I, J, K)
-  float* out;         // (B, 1, Io, Jo, Ko)
+  const float* in;    // channel c of a (B, C, I, J, K) image: base pointer of (0, c), batch elements in_stride apart
+  float* out;         // the same channel of the (B, C, Io, Jo, Ko) output, batch elements out_stride apart
+  int64_t in_stride, out_stride;
   const float* fill;  // one float, or nullptr (no fill rule)
   const int* plan;    // plan_bricks_kernel's output
   const float* cp;    // control points (ELASTIC_POSSIBLE) or nullptr
@@ -873,10 +874,8 @@ __global__ __launch_bounds__(256, 3) void resample_planned_lean_kernel(const Lea
   constexpr int part = 0;
   const int slab = a.Jo * a.Ko;
   const int64_t slab_b = static_cast<int64_t>(slab) * 4;
-  const int64_t n_in = static_cast<int64_t>(a.I) * a.J * a.K;
-  const int64_t n_out = static_cast<int64_t>(a.Io) * slab;
-  const float* in_chan = a.in + static_cast<int64_t>(b) * n_in;
-  char* out_chan = reinterpret_cast<char*>(a.out + static_cast<int64_t>(b) * n_out);
+  const float* in_chan = a.in + static_cast<int64_t>(b) * a.in_stride;
+  char* out_chan = reinterpret_cast<char*>(a.out + static_cast<int64_t>(b) * a.out_stride);
 
   const int kind = kind_w & 0xFF;
   bx.kind = kind; bx.interior = kind_w >> 8;
