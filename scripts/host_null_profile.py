@@ -36,6 +36,8 @@ engine = ops.Engine(_Null(), "cpu", "null")
 ops._ENGINE = engine
 _pending.eligible = lambda data: _pending.enabled() and data.dtype == torch.float32 and data.ndim == 5 and not data.requires_grad
 ops.h2d = lambda tensor, device: tensor
+from torchio_amd.transforms import spatial as _sp
+_sp._folding_grid_spacing = lambda extent, mesh: float("inf")  # (16^3 stand-in volumes: the 256^3 bench never trips the folding warning)
 tio.set_noise_rng("philox")
 tio.set_resample_precision("fast")
 transform = bench.build_transform()

@@ -14,7 +14,7 @@ import bench  # noqa: E402
 import torchio_amd as tio  # noqa: E402
 
 warnings.simplefilter("ignore")
-tio.set_noise_rng("philox")
+tio.set_noise_rng("philox"); tio.set_resample_precision("fast")
 transform = bench.build_transform()
 batch = bench.make_batch(256, 8, 0, "cuda")
 for _ in range(10):

@@ -681,3 +681,34 @@ def test_batched_parameter_draw_equals_the_per_element_loop(kwargs, count):
     for (fa, ca, da, ga), (fb, cb, db, gb) in zip(loop, many, strict=True):
         assert fa == fb and da == db and ga == gb
         assert (ca is None) == (cb is None) and (ca is None or torch.equal(ca, cb))
+
+
+def test_gaussian_taps_from_one_block_equal_the_per_axis_form():
+    """`_stacked_gaussian_taps`: the all-axes-at-once chain (per-instance draws, every sigma positive) gives the bits of the
+    per-axis expressions it replaces (the reference's, blur.py:292-328)."""
+    import math
+
+    import numpy as np
+
+    from torchio_amd.transforms.blur import _stacked_gaussian_taps
+
+    def per_axis(sigmas):
+        n = sigmas.shape[0]
+        radii = np.array([[max(math.ceil(3 * v), 1) for v in row] for row in sigmas.tolist()], dtype=np.int64)
+        radius = [int(radii[:, a].max()) for a in range(3)]
+        taps = torch.zeros(n, 3, 2 * max(radius) + 1)
+        for axis in range(3):
+            r = radius[axis]
+            offsets = torch.arange(2 * r + 1, dtype=torch.float32) - r
+            column = torch.as_tensor(sigmas[:, axis], dtype=torch.float32)[:, None]
+            kernels = torch.exp(-0.5 * (offsets[None, :] / column) ** 2)
+            kernels = torch.where(offsets[None, :].abs() <= torch.as_tensor(radii[:, axis])[:, None], kernels, torch.zeros_like(kernels))
+            taps[:, axis, : 2 * r + 1] = kernels / kernels.sum(dim=1, keepdim=True)
+        return taps, radius
+
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        sigmas = rng.uniform(0.05, 2.7, size=(int(rng.integers(2, 9)), 3))
+        expected, expected_radius = per_axis(sigmas)
+        taps, radius, skip = _stacked_gaussian_taps(sigmas, per_element=True)
+        assert skip is None and radius == expected_radius and torch.equal(taps, expected)

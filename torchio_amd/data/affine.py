@@ -13,7 +13,7 @@ from torch import Tensor
 class AffineMatrix:
     """4x4 float64 matrix mapping voxel indices to world (mm) coordinates."""
 
-    __slots__ = ("_matrix", "_spacing_cache")
+    __slots__ = ("_matrix", "_spacing_cache", "_bytes_cache", "_inverse_cache")
 
     def __init__(self, matrix=None) -> None:
         if matrix is None:
@@ -28,6 +28,8 @@ class AffineMatrix:
             raise ValueError(f"AffineMatrix must be 4x4, got {tuple(value.shape)}")
         self._matrix = value
         self._spacing_cache = None  # (tensor version, spacing): the 4x4 may be edited in place through .data
+        self._bytes_cache = None    # (tensor version, the 128 bytes of the matrix): `same_values`
+        self._inverse_cache = None  # (tensor version, np.linalg.inv of the matrix): `inverse_numpy`
 
     @classmethod
     def from_spacing(cls, spacing, *, origin=(0.0, 0.0, 0.0), direction=None) -> "AffineMatrix":
@@ -55,7 +57,7 @@ class AffineMatrix:
         cached = self._spacing_cache
         if cached is not None and cached[0] == version:
             return cached[1]
-        norms = self._column_norms().tolist()
+        norms = self._column_norms().tolist()  # (ATen's float64 reduction: numpy adds the three squares in another order)
         value = (float(norms[0]), float(norms[1]), float(norms[2]))
         self._spacing_cache = (version, value)
         return value
@@ -96,6 +98,32 @@ class AffineMatrix:
             rotation[world, :] = 0  # a world axis is assigned once
         return (codes[0], codes[1], codes[2])
 
+    def _value_bytes(self) -> bytes:
+        version = self._matrix._version
+        cached = self._bytes_cache
+        if cached is not None and cached[0] == version:
+            return cached[1]
+        value = self._matrix.numpy().tobytes()
+        self._bytes_cache = (version, value)
+        return value
+
+    def same_values(self, other: "AffineMatrix") -> bool:
+        """``torch.equal(self.data, other.data)`` for host matrices (NaN-free grids: byte equality, except that +0.0 and
+        -0.0 compare unequal here — callers fall back to the tensor comparison on ``False``); cached per tensor version."""
+        return self is other or self._value_bytes() == other._value_bytes()
+
+    def inverse_numpy(self) -> np.ndarray:
+        """``np.linalg.inv(self.numpy())`` (read-only; cached per tensor version: the same grid is inverted by every
+        spatial transform of a pipeline)."""
+        version = self._matrix._version
+        cached = self._inverse_cache
+        if cached is not None and cached[0] == version:
+            return cached[1]
+        value = np.linalg.inv(self._matrix.numpy())
+        value.setflags(write=False)
+        self._inverse_cache = (version, value)
+        return value
+
     def to(self, *args, **kwargs) -> "AffineMatrix":
         """Affines stay float64 and — unlike image data — on the host.
 
@@ -110,9 +138,19 @@ class AffineMatrix:
     def clone(self) -> "AffineMatrix":
         new = AffineMatrix.__new__(AffineMatrix)
         new._matrix = self._matrix.clone()
+        # The copy inherits what is cached for these values.  The spacing is worked out HERE if nobody asked the source yet:
+        # a pipeline copies its input batch every step and asks the COPIES (four tensor ops per element and step, for ever);
+        # asked once of the source, every later copy starts with the answer.
+        if self._spacing_cache is None or self._spacing_cache[0] != self._matrix._version:
+            self.spacing  # noqa: B018 - fills the cache
         cached = self._spacing_cache
         # the copy starts at tensor version 0 with the same values: the spacing carries over
-        new._spacing_cache = (0, cached[1]) if cached is not None and cached[0] == self._matrix._version else None
+        version = self._matrix._version
+        new._spacing_cache = (0, cached[1]) if cached is not None and cached[0] == version else None
+        cached = self._bytes_cache
+        new._bytes_cache = (0, cached[1]) if cached is not None and cached[0] == version else None
+        cached = self._inverse_cache
+        new._inverse_cache = (0, cached[1]) if cached is not None and cached[0] == version else None
         return new
 
     def inverse(self) -> "AffineMatrix":

@@ -242,7 +242,8 @@ class Engine:
 
     def _stream(self, ref: Tensor):
         if self.device_type == "cuda":
-            return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+            # torch._C._cuda_getCurrentRawStream: the raw handle without building a torch.cuda.Stream object per call
+            return C.c_void_p(torch._C._cuda_getCurrentRawStream(ref.device.index if ref.device.index is not None else torch.cuda.current_device()))
         return None
 
     def _call(self, name: str, ref: Tensor, *args) -> None:
@@ -307,7 +308,8 @@ class Engine:
         batch = first.shape[0]
         in_shape = tuple(first.shape[2:])
         out_shape = tuple(int(s) for s in out_shape)
-        mapping = mapping.to(torch.float32).contiguous()
+        if mapping.dtype != torch.float32 or not mapping.is_contiguous():
+            mapping = mapping.to(torch.float32).contiguous()
         if mapping.ndim != 3 or mapping.shape[1:] != (3, 4) or mapping.shape[0] not in (1, batch):
             raise ValueError(f"mapping must be (1|B, 3, 4), got {tuple(mapping.shape)}")
         geom = _abi.ResampleGeom()
@@ -319,7 +321,8 @@ class Engine:
         geom.mapping_batched = int(mapping.shape[0] == batch and batch > 1)
         keep_alive = [mapping]
         if control_points is not None:
-            control_points = control_points.to(torch.float32).contiguous()
+            if control_points.dtype != torch.float32 or not control_points.is_contiguous():
+                control_points = control_points.to(torch.float32).contiguous()
             if control_points.ndim != 5 or control_points.shape[-1] != 3 or control_points.shape[0] not in (1, batch):
                 raise ValueError(f"control_points must be (1|B, ni, nj, nk, 3), got {tuple(control_points.shape)}")
             geom.control_points_dev = control_points.data_ptr()
@@ -340,15 +343,15 @@ class Engine:
         # images that take part in autograd (float, trilinear): the kernel sees the detached data, the result gets
         # the adjoint launch as its backward
         sources = list(images)
-        wants = [
-            _adjoint_of is None and _wants_grad(t) and t.dtype in FLOAT_DTYPES
-            and (INTERP_CODES[interps[n]] if isinstance(interps[n], str) else int(interps[n])) == _abi.LINEAR
-            for n, t in enumerate(images)
-        ]
-        images = [t.detach() if (_adjoint_of is None and t.requires_grad) else t for t in images]
-        for n, t in enumerate(sources):
-            if _adjoint_of is None and _wants_grad(t) and not wants[n]:
-                raise EngineError("resample3d: only floating-point images resampled trilinearly are differentiable")
+        codes = [INTERP_CODES[i] if isinstance(i, str) else int(i) for i in interps]
+        if _adjoint_of is None and any(t.requires_grad for t in images):
+            wants = [_wants_grad(t) and t.dtype in FLOAT_DTYPES and codes[n] == _abi.LINEAR for n, t in enumerate(images)]
+            images = [t.detach() if t.requires_grad else t for t in images]
+            for n, t in enumerate(sources):
+                if _wants_grad(t) and not wants[n]:
+                    raise EngineError("resample3d: only floating-point images resampled trilinearly are differentiable")
+        else:  # (the usual call: nothing takes part in autograd)
+            wants = [False] * len(images)
 
         # The folded minimum (opt-in, TIO_FOLDED_MIN=1): a large FAST launch can hand back the per-channel minimum of
         # element 0 of each output (tio_resample_image.out_min_dev), which is what the NEXT spatial transform's
@@ -357,12 +360,10 @@ class Engine:
         # one consumer that exists — a wash, and a loss for pipelines whose next transform is not spatial — so it is off
         # by default.  Requested only where the C side folds it (the rule of resample.hip's planned path, mirrored
         # loosely: a miss costs one tio_channel_min launch, never a wrong value).
-        codes = [INTERP_CODES[i] if isinstance(i, str) else int(i) for i in interps]
-        bricks = batch * -(-out_shape[0] // 16) * -(-out_shape[1] // 16) * -(-out_shape[2] // 16)
         fold_min = (
-            _adjoint_of is None and geom.precision == _abi.PRECISION_FAST and bricks >= 12288 and not any(wants)
+            _adjoint_of is None and geom.precision == _abi.PRECISION_FAST and os.environ.get("TIO_FOLDED_MIN", "") not in ("", "0")
+            and batch * -(-out_shape[0] // 16) * -(-out_shape[1] // 16) * -(-out_shape[2] // 16) >= 12288 and not any(wants)
             and len(images) <= _abi.MAX_IMAGES and all(t.dtype == torch.float32 for t in images) and all(c == _abi.LINEAR for c in codes)
-            and os.environ.get("TIO_FOLDED_MIN", "") not in ("", "0")
         )
         folded: list[Tensor | None] = []
 
@@ -374,10 +375,12 @@ class Engine:
                 data = images[n]
                 if data.ndim != 5 or data.shape[0] != batch or tuple(data.shape[2:]) != in_shape:
                     raise ValueError("all images must share the batch size and spatial shape")
-                data = data.contiguous()
+                if not data.is_contiguous():
+                    data = data.contiguous()
                 fill = fills[n]
                 if fill is not None:
-                    fill = h2d(fill.to(torch.float32), data.device).contiguous()
+                    if fill.dtype != torch.float32 or fill.device != data.device or not fill.is_contiguous():
+                        fill = h2d(fill.to(torch.float32), data.device).contiguous()
                     if fill.numel() != data.shape[1]:
                         raise ValueError("fill must have one value per channel")
                 self._check("resample3d", data, fill)
@@ -387,12 +390,11 @@ class Engine:
                         raise ValueError("gradient shape does not match the forward output")
                 else:
                     out = torch.empty((batch, data.shape[1], *out_shape), dtype=data.dtype, device=data.device)
-                interp = interps[n]
                 descs[slot].in_ = data.data_ptr()
                 descs[slot].out = out.data_ptr()
                 descs[slot].channels = data.shape[1]
                 descs[slot].dtype = dtype_code(data.dtype)
-                descs[slot].interp = INTERP_CODES[interp] if isinstance(interp, str) else int(interp)
+                descs[slot].interp = codes[n]
                 descs[slot].fill_dev = None if fill is None else fill.data_ptr()
                 if descs[slot].interp == _abi.LABEL_PV:
                     table = None if label_tables is None else label_tables[n]
@@ -457,13 +459,13 @@ class Engine:
         """Per-channel minimum of the first batch element as a ``(C,)`` float32 device tensor."""
         data = data.detach()  # a fill VALUE (the reference takes `.item()`): no gradient flows through it
         self._check("channel_min", data)
-        first = data[0].contiguous()
-        channels = first.shape[0]
+        first = data if data.is_contiguous() else data[0].contiguous()  # element 0 of a dense batch starts at the batch's pointer
+        channels = data.shape[1]
+        n_spatial = 1
+        for extent in data.shape[2:]:
+            n_spatial *= int(extent)
         out = torch.empty(channels, dtype=torch.float32, device=data.device)
-        self._call(
-            "channel_min", data, _ptr(first), dtype_code(first.dtype), channels,
-            first[0].numel(), _ptr(out), self._stream(data),
-        )
+        self._call("channel_min", data, _ptr(first), dtype_code(data.dtype), channels, n_spatial, _ptr(out), self._stream(data))
         return out
 
     # -- intensity ----------------------------------------------------------

@@ -122,6 +122,18 @@ def _gaussian_smooth(data: Tensor, sigmas) -> Tensor:
 _OFFSETS: dict[int, Tensor] = {}
 
 
+_DISTANCES: dict[int, Tensor] = {}
+_ZERO = torch.zeros((), dtype=torch.float32)
+
+
+def _tap_distance(r: int) -> Tensor:
+    """``|arange(2r + 1) - r|`` as int64 (read-only, cached per radius)."""
+    distance = _DISTANCES.get(r)
+    if distance is None:
+        distance = _DISTANCES[r] = (torch.arange(2 * r + 1, dtype=torch.int64) - r).abs()
+    return distance
+
+
 def _tap_offsets(r: int) -> Tensor:
     """``arange(2r + 1) - r`` as float32 (read-only, cached per radius)."""
     offsets = _OFFSETS.get(r)
@@ -147,6 +159,22 @@ def _stacked_gaussian_taps(sigmas: np.ndarray, per_element: bool = False):
     if per_element:
         radii = np.asarray(radii_rows, dtype=np.int64)
         positive = radii > 0
+        if bool(positive.all()):
+            # every element blurs every axis (the usual per-instance draw): the Gaussian of all three axes from ONE chain of
+            # tensor ops on the (n, 3, stride) block — exp(-0.5 (o / sigma)^2) is elementwise, so each value is the one the
+            # per-axis expression gives — zeroed beyond each element's own radius; only the normalisation stays per axis, on
+            # the (n, 2 r_axis + 1) slice the per-axis code sums (ATen's float32 row sum depends on the row's LENGTH: a row
+            # padded with zeros to the common stride rounds differently; tests/test_host_logic.py holds the two forms equal)
+            reach = max(radius)
+            offsets = _tap_offsets(reach)
+            sigma_block = torch.as_tensor(sigmas, dtype=torch.float32)[:, :, None]
+            kernels = torch.exp(-0.5 * (offsets[None, None, :] / sigma_block) ** 2)
+            kernels = torch.where(_tap_distance(reach)[None, None, :] <= torch.from_numpy(radii)[:, :, None], kernels, _ZERO)
+            for axis in range(3):
+                r = radius[axis]
+                window = kernels[:, axis, reach - r : reach + r + 1]
+                taps[:, axis, : 2 * r + 1] = window / window.sum(dim=1, keepdim=True)
+            return taps, radius, None
     for axis in range(3):
         r = radius[axis]
         if r == 0:

@@ -112,6 +112,12 @@ class ScalarDrawPlan:
                     low32, high32 = np.float32(low), np.float32(high)
                     self.entries.append((None, float(np.float32(high32 - low32)), float(low32)))
         self.n_random = sum(1 for constant, _, _ in self.entries if constant is None)
+        # column layout of `map_block_array`: where the constants and the drawn values go, and the fma constants as arrays
+        self._random_columns = np.array([i for i, (constant, _, _) in enumerate(self.entries) if constant is None], dtype=np.intp)
+        self._constant_columns = np.array([i for i, (constant, _, _) in enumerate(self.entries) if constant is not None], dtype=np.intp)
+        self._constant_values = np.array([constant for constant, _, _ in self.entries if constant is not None], dtype=np.float64)
+        self._slopes = np.array([slope for constant, slope, _ in self.entries if constant is None], dtype=np.float64)
+        self._offsets = np.array([offset for constant, _, offset in self.entries if constant is None], dtype=np.float64)
 
     @staticmethod
     def build(ranges: list, counts: list[int]) -> "ScalarDrawPlan | None":
@@ -129,34 +135,32 @@ class ScalarDrawPlan:
         uniforms = torch.empty(self.n_random).uniform_(0.0, 1.0).tolist() if self.n_random else []
         return self.map(uniforms)
 
-    def map_block(self, uniforms: np.ndarray) -> list[list[float]]:
-        """``[self.map(row) for row in uniforms]`` for a ``(rows, n_random)`` float32 block, vectorised.
+    def map_block_array(self, uniforms: np.ndarray) -> np.ndarray:
+        """``np.array([self.map(row) for row in uniforms])`` for a ``(rows, n_random)`` float32 block: ``(rows, entries)`` float64.
 
         ``fma(u, slope, offset)`` in float32 is the float64 ``u * slope + offset`` (the product is exact) rounded once
         more — except when that float64 sum sits exactly on a float32 midpoint (see ``_fma32``); those entries, found
         by their bit pattern, are redone with the scalar routine.
         """
         rows = uniforms.shape[0]
-        slopes = np.array([slope for constant, slope, _ in self.entries if constant is None], dtype=np.float64)
-        offsets = np.array([offset for constant, _, offset in self.entries if constant is None], dtype=np.float64)
-        u = uniforms.astype(np.float64)
-        total = u * slopes + offsets
-        mapped = total.astype(np.float32).astype(np.float64)
-        ties = (total.view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)  # a float32 midpoint held in float64
-        for r, c in zip(*np.nonzero(ties)):
-            mapped[r, c] = _fma32(float(u[r, c]), float(slopes[c]), float(offsets[c]))
-        drawn = mapped.tolist()
-        out = []
-        for r in range(rows):
-            position, values = 0, []
-            for constant, _, _ in self.entries:
-                if constant is not None:
-                    values.append(constant)
-                else:
-                    values.append(drawn[r][position])
-                    position += 1
-            out.append(values)
+        out = np.empty((rows, len(self.entries)), dtype=np.float64)
+        if self._constant_columns.size:
+            out[:, self._constant_columns] = self._constant_values
+        if self.n_random:
+            slopes, offsets = self._slopes, self._offsets
+            u = uniforms.astype(np.float64)
+            total = u * slopes + offsets
+            mapped = total.astype(np.float32).astype(np.float64)
+            ties = (total.view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)  # a float32 midpoint held in float64
+            if ties.any():
+                for r, c in zip(*np.nonzero(ties)):
+                    mapped[r, c] = _fma32(float(u[r, c]), float(slopes[c]), float(offsets[c]))
+            out[:, self._random_columns] = mapped
         return out
+
+    def map_block(self, uniforms: np.ndarray) -> list[list[float]]:
+        """``[self.map(row) for row in uniforms]`` for a ``(rows, n_random)`` float32 block (see ``map_block_array``)."""
+        return self.map_block_array(uniforms).tolist()
 
     def map(self, uniforms: list[float]) -> list[float]:
         """The plan's values for ``n_random`` uniforms drawn elsewhere (a batch's draws come as one block)."""

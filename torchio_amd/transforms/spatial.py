@@ -153,15 +153,22 @@ class Spatial(SpatialTransform):
     def _scalar_plan(self):
         """All scalar draws of one element as one small ``uniform_`` call (same values, same RNG state)."""
         draw_displacement = self.control_points is None
-        # keyed on the ranges' VALUES (a reassigned range object may reuse a freed object's id)
+        cached = self.__dict__.get("_scalar_plan_cache")
+        # fast check: the very `_axes` tuples the plan was built from are still in place (the cache holds them, so a new
+        # tuple can never reuse one of their ids); otherwise the ranges' VALUES decide
+        axes = (self.scales._axes, self.degrees._axes, self.translation._axes, self.max_displacement._axes)
+        if cached is not None and cached[2][0] is axes[0] and cached[2][1] is axes[1] and cached[2][2] is axes[2] and cached[2][3] is axes[3] \
+                and cached[3] == (self.isotropic, draw_displacement):
+            return cached[1]
         key = (_range_key(self.scales), _range_key(self.degrees), _range_key(self.translation), _range_key(self.max_displacement),
                self.isotropic, draw_displacement)
-        cached = self.__dict__.get("_scalar_plan_cache")
         if cached is None or cached[0] != key:
             ranges = [self.scales, self.degrees, self.translation] + ([self.max_displacement] if draw_displacement else [])
             counts = [1 if self.isotropic else 3, 3, 3] + ([3] if draw_displacement else [])
-            cached = (key, ScalarDrawPlan.build(ranges, counts))
-            self.__dict__["_scalar_plan_cache"] = cached
+            cached = (key, ScalarDrawPlan.build(ranges, counts), axes, (self.isotropic, draw_displacement))
+        else:
+            cached = (cached[0], cached[1], axes, (self.isotropic, draw_displacement))
+        self.__dict__["_scalar_plan_cache"] = cached
         return cached[1]
 
     _NO_PLAN = object()
@@ -212,20 +219,24 @@ class Spatial(SpatialTransform):
                 )
         return forward, field, displacement, (has_affine or field is not None)
 
-    def _sample_many(self, shape, affine, count: int):
-        """``[_sample_one(shape, affine, build=False) for _ in range(count)]`` with ONE draw for the whole batch.
+    def _sample_block(self, count: int):
+        """The draws of ``count`` elements as arrays, from ONE ``torch.rand`` call — or ``None`` when the per-element loop must run.
 
         The CPU generator hands out the same uniforms whether they are asked for element by element (a handful of
         scalars, then ``prod(grid) * 3`` control values, per element) or as one block, so the values AND the generator
         state afterwards are those of the loop (``tests/test_host_logic.py`` holds the two against each other); what
-        the block saves is the per-element dispatcher round trips (8 x (uniform_ + rand + 3 tensor ops) per transform).
-        Falls back to the loop when a draw decides whether later draws happen (a displacement that comes out as
-        exactly zero draws no field), when the scalar draws need the general path, or for user-given control points.
+        the block saves is the per-element dispatcher round trips (8 x (uniform_ + rand + 3 tensor ops) per transform)
+        and, with the arrays kept as arrays, the per-element Python bookkeeping behind them.
+        ``None``: a draw decides whether later draws happen (a displacement that comes out as exactly zero draws no
+        field), the scalar draws need the general path, or the control points are user-given.
+
+        Returns ``(scales, degrees, translation, has_affine, fields, displacements)``: ``(count, 3)`` float64 arrays, a
+        bool vector, the ``(count, ni, nj, nk, 3)`` float32 field block (or ``None``: no elastic part) and the ``(count, 3)``
+        displacement array (or ``None``).
         """
         plan = self._scalar_plan()
-        loop = lambda: [self._sample_one(shape, affine, build=False, plan=plan) for _ in range(count)]  # noqa: E731
         if plan is None or count < 2 or self.control_points is not None:
-            return loop()
+            return None
         n_scale = 1 if self.isotropic else 3
         displacement_entries = plan.entries[n_scale + 6 : n_scale + 9]
         never_field = all(constant == 0.0 for constant, _, _ in displacement_entries)
@@ -233,30 +244,45 @@ class Spatial(SpatialTransform):
         n_field = 0 if never_field else grid[0] * grid[1] * grid[2] * 3
         width = plan.n_random + n_field
         if width == 0:
-            return loop()
+            return None
         state = torch.get_rng_state() if not never_field else None
         block = torch.rand(count, width, dtype=torch.float32)
-        rows = plan.map_block(block[:, : plan.n_random].numpy()) if plan.n_random else [plan.map([]) for _ in range(count)]
-        displacements = [tuple(values[n_scale + 6 : n_scale + 9]) for values in rows]
-        if not never_field and any(all(value == 0.0 for value in d) for d in displacements):
+        values = plan.map_block_array(block[:, : plan.n_random].numpy())
+        displacements = values[:, n_scale + 6 : n_scale + 9]
+        if not never_field and bool((displacements == 0.0).all(axis=1).any()):
             torch.set_rng_state(state)  # measure zero: that element draws no field in the reference, the stream shifts
-            return loop()
+            return None
         fields = None
         if not never_field:
             fields = block[:, plan.n_random :].reshape(count, *grid, 3)
             fields -= 0.5
-            fields *= torch.tensor([[2.0 * m for m in d] for d in displacements], dtype=torch.float32).view(count, 1, 1, 1, 3)
+            fields *= torch.from_numpy((2.0 * displacements).astype(np.float32)).view(count, 1, 1, 1, 3)
             if self.locked_borders > 0:
                 fields = torch.where(_interior_mask(grid, self.locked_borders), fields, torch.zeros((), dtype=torch.float32))
+        scales = np.repeat(values[:, :1], 3, axis=1) if self.isotropic else values[:, :3]
+        degrees = values[:, n_scale : n_scale + 3]
+        translation = values[:, n_scale + 3 : n_scale + 6]
+        # np.allclose(v, target) with its default tolerances, per element (the reference's no-op test, spatial.py:2237-2243)
+        identity = (
+            (np.abs(scales - 1.0) <= 1e-8 + 1e-5).all(axis=1) & (np.abs(degrees) <= 1e-8).all(axis=1) & (np.abs(translation) <= 1e-8).all(axis=1)
+        )
+        return scales, degrees, translation, ~identity, fields, (None if never_field else displacements)
+
+    def _sample_many(self, shape, affine, count: int):
+        """``[_sample_one(shape, affine, build=False) for _ in range(count)]`` with ONE draw for the whole batch (``_sample_block``)."""
+        drawn = self._sample_block(count)
+        if drawn is None:
+            plan = self._scalar_plan()
+            return [self._sample_one(shape, affine, build=False, plan=plan) for _ in range(count)]
+        scales, degrees, translation, has_affine, fields, displacements = drawn
+        rows_s, rows_d, rows_t = scales.tolist(), degrees.tolist(), translation.tolist()
+        rows_m = None if displacements is None else displacements.tolist()
         out = []
-        for index, values in enumerate(rows):
-            scales = (values[0],) * 3 if self.isotropic else tuple(values[:3])
-            degrees = tuple(values[n_scale : n_scale + 3])
-            translation = tuple(values[n_scale + 3 : n_scale + 6])
-            has_affine = not (_all_close(scales, 1.0) and _all_close(degrees, 0.0) and _all_close(translation, 0.0))
+        for index in range(count):
+            forward = (tuple(rows_s[index]), tuple(rows_d[index]), tuple(rows_t[index])) if has_affine[index] else None
             field = None if fields is None else fields[index]
-            displacement = None if field is None else displacements[index]
-            out.append(((scales, degrees, translation) if has_affine else None, field, displacement, has_affine or field is not None))
+            displacement = None if field is None else tuple(rows_m[index])
+            out.append((forward, field, displacement, bool(has_affine[index]) or field is not None))
         return out
 
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
@@ -290,6 +316,25 @@ class Spatial(SpatialTransform):
             return params
 
         keep = self._keep_mask(batch, n)
+        drawn = self._sample_block(n) if keep is None else None
+        if drawn is not None:  # every element draws: the whole batch as arrays, lists only if somebody reads the history
+            scales, degrees, translation, has_affine, field_block, displacement_block = drawn
+            if bool(has_affine.any()) or field_block is not None:
+                _check_shared_space(images, shape, affine)
+            params["target"] = _serialize_space(_resolve_target_space(self.target, batch, shape, affine))
+            everyone = bool(has_affine.all())
+            built = _build_forward_affines_arrays(
+                scales if everyone else scales[has_affine], degrees if everyone else degrees[has_affine],
+                translation if everyone else translation[has_affine], center=self.center, shape=shape, affine=affine,
+            )
+            rows = iter(built)
+            matrices = _MatrixList([next(rows) if flag else None for flag in has_affine.tolist()])
+            matrices.stacked = built if everyone else None
+            params.set_lazy("affine_matrix", matrices)
+            params.set_lazy("control_points", [None] * n if field_block is None else _StackedFields(field_block))
+            params["max_displacement"] = [None] * n if displacement_block is None else displacement_block.tolist()
+            self._tag_batched(params, batch, n, keep, ["affine_matrix", "control_points", "max_displacement"])
+            return params
         matrices, fields, displacements, any_geometry = [], [], [], False
         kept = [index for index in range(n) if keep is None or bool(keep[index])]
         drawn = iter(self._sample_many(shape, affine, len(kept)))  # gated-out elements draw nothing
@@ -567,11 +612,14 @@ def _apply_spatial_to_batch(
 
     # output voxel -> input voxel: inv(A_in) @ inv(T) @ A_out in float64, cast to float32 (spatial.py:1582-1601)
     # (stacked: numpy runs the same LAPACK / BLAS routine per 4x4 slice as the one-at-a-time form)
-    in_inverse = np.linalg.inv(in_affine.numpy())
+    in_inverse = in_affine.inverse_numpy() if hasattr(in_affine, "inverse_numpy") else np.linalg.inv(in_affine.numpy())
     out_matrix = out_affine.numpy()
+    stacked_matrices = getattr(matrices, "stacked", None)
     present_matrices = [index for index, matrix in enumerate(matrices) if matrix is not None]
     mapping = None
-    if not present_matrices:
+    if stacked_matrices is not None:  # every element has a world affine, already one (n, 4, 4) array
+        mapping = ((in_inverse @ np.linalg.inv(stacked_matrices)) @ out_matrix)[:, :3].astype(np.float32)
+    elif not present_matrices:
         # pure elastic / gated-out batch: every element maps through inv(A_in) @ I @ A_out; when that IS the identity
         # in float32 (it need not be bit for bit: inv(A) @ A carries float64 rounding) one cached device tensor serves
         shared = ((in_inverse @ np.eye(4)) @ out_matrix)[:3].astype(np.float32)
@@ -585,8 +633,20 @@ def _apply_spatial_to_batch(
     out_spacing = np.asarray(out_affine.spacing, dtype=np.float64)
     field_tensor = None
     cp_skip = None
-    present = [f for f in fields if f is not None]
-    if present:
+    if isinstance(fields, _StackedFields):  # the whole batch's control points as one host block (make_params drew them so)
+        block = fields.stacked
+        limits = np.asarray(displacements, dtype=np.float64)
+        grid_spacing = np.asarray(
+            [_folding_grid_spacing(float(out_shape[axis]) * float(out_spacing[axis]), float(block.shape[1 + axis]) - _SPLINE_ORDER) for axis in range(3)]
+        )
+        if bool((limits > grid_spacing / 2).any()):  # (the warning, element by element, exactly as the loop below words it)
+            for f, displacement in zip(block.unbind(0), displacements, strict=True):
+                _check_folding(f.numpy(), displacement, out_shape, out_spacing)
+        field_tensor = ops.h2d(block, device)
+        present = [block]
+    else:
+        present = [f for f in fields if f is not None]
+    if present and field_tensor is None:
         shapes = {tuple(f.shape) for f in present}
         if len(shapes) != 1:
             raise RuntimeError(f"All control-point fields of a batch must share one shape, got {sorted(shapes)}")
@@ -606,7 +666,7 @@ def _apply_spatial_to_batch(
 
     passthrough_all = None
     if per_sample is not None and target_space is None:
-        flags = [m is None and f is None for m, f in zip(matrices, fields, strict=True)]
+        flags = [False] * batch_size if isinstance(fields, _StackedFields) else [m is None and f is None for m, f in zip(matrices, fields, strict=True)]
         if any(flags):
             passthrough_all = ops.h2d(torch.tensor(flags, dtype=torch.uint8), device)
     else:
@@ -732,10 +792,14 @@ def _apply_spatial_to_batch(
         img_batch = batch.images[name]
         originals = list(img_batch.affines)
         img_batch.data = finished[name]
+        keeps_values = target_space is None and hasattr(out_affine, "same_values")
         img_batch.affines[:] = [
-            # every resampled element adopts the output grid (spatial.py:1100-1107); when that IS the element's
-            # grid already (no target: the shared-space check has passed) the object is kept instead of cloned
-            originals[index] if flags[index] or (target_space is None and originals[index] is out_affine) else out_affine.clone()
+            # every resampled element adopts the output grid (spatial.py:1100-1107); when the element's own matrix already holds
+            # exactly those values (no target, and the shared-space check has passed) its object is kept instead of replaced
+            # by a clone of the first element's: the same 4x4, one tensor clone per element less
+            originals[index]
+            if flags[index] or (target_space is None and originals[index] is out_affine) or (keeps_values and originals[index].same_values(out_affine))
+            else out_affine.clone()
             for index in range(len(originals))
         ]
 
@@ -954,7 +1018,16 @@ def _build_forward_affines(parameters: list, *, center, shape, affine: AffineMat
     scaling = np.array([p[0] for p in parameters], dtype=np.float64)
     rotation = np.array([p[1] for p in parameters], dtype=np.float64)
     shift = np.array([p[2] for p in parameters], dtype=np.float64)
+    return _build_forward_affines_arrays(scaling, rotation, shift, center=center, shape=shape, affine=affine)
+
+
+def _build_forward_affines_arrays(scaling: np.ndarray, rotation: np.ndarray, shift: np.ndarray, *, center, shape, affine: AffineMatrix) -> np.ndarray:
+    """``_build_forward_affines`` for ``(n, 3)`` float64 arrays of scales, degrees and translations (not modified)."""
+    n = scaling.shape[0]
+    if n == 0:
+        return np.zeros((0, 4, 4), dtype=np.float64)
     if shape[-1] == 1:  # 2-D slice: suppress out-of-plane components
+        scaling, rotation, shift = scaling.copy(), rotation.copy(), shift.copy()
         scaling[:, 2] = 1.0
         rotation[:, :2] = 0.0
         shift[:, 2] = 0.0
@@ -979,10 +1052,33 @@ def _build_forward_affines(parameters: list, *, center, shape, affine: AffineMat
 
 
 class _MatrixList(list):
-    """Per-element 4x4 world affines (``np.ndarray`` or ``None``) that serialise as nested lists."""
+    """Per-element 4x4 world affines (``np.ndarray`` or ``None``) that serialise as nested lists.
+
+    ``stacked``: the same matrices as one ``(n, 4, 4)`` array when every element has one (saves re-stacking them)."""
+
+    stacked: np.ndarray | None = None
 
     def tolist(self) -> list:
         return [None if m is None else m.tolist() for m in self]
+
+
+class _StackedFields:
+    """The control-point fields of a batch as ONE ``(n, ni, nj, nk, 3)`` float32 host tensor that reads like the list of
+    per-element fields it stands for (``len``, indexing, iteration give ``(ni, nj, nk, 3)`` views)."""
+
+    __slots__ = ("stacked",)
+
+    def __init__(self, stacked: Tensor) -> None:
+        self.stacked = stacked
+
+    def __len__(self) -> int:
+        return int(self.stacked.shape[0])
+
+    def __getitem__(self, index):
+        return self.stacked[index]
+
+    def __iter__(self):
+        return iter(self.stacked.unbind(0))
 
 
 def _all_close(values, target: float) -> bool:
@@ -1044,12 +1140,16 @@ def _max_abs_displacement(control_points: Tensor) -> tuple[float, float, float]:
     return tuple(float(absolute[..., axis].max().item()) for axis in range(3))  # type: ignore[return-value]
 
 
+def _folding_grid_spacing(extent: float, mesh: float) -> float:
+    """``extent / mesh`` as plain floats with numpy's division-by-zero results (a 3-point grid has mesh 0)."""
+    return extent / mesh if mesh != 0 else (math.copysign(math.inf, extent) if extent != 0 else math.nan)
+
+
 def _check_folding(control_points: np.ndarray, max_displacement, shape, spacing: np.ndarray) -> None:
     """Warn when the displacement exceeds half the coarse-grid spacing (spatial.py:2192-2216)."""
     where = []
-    for axis in range(3):  # plain floats with numpy's division-by-zero results (a 3-point grid has mesh 0)
-        extent, mesh = float(shape[axis]) * float(spacing[axis]), float(control_points.shape[axis]) - _SPLINE_ORDER
-        grid_spacing = extent / mesh if mesh != 0 else (math.copysign(math.inf, extent) if extent != 0 else math.nan)
+    for axis in range(3):
+        grid_spacing = _folding_grid_spacing(float(shape[axis]) * float(spacing[axis]), float(control_points.shape[axis]) - _SPLINE_ORDER)
         if float(max_displacement[axis]) > grid_spacing / 2:
             where.append(axis)
     if where:
@@ -1066,8 +1166,9 @@ def _check_shared_space(images: dict[str, ImagesBatch], reference_shape, referen
         shape = _spatial_shape(img_batch)
         if shape != reference_shape:
             raise RuntimeError(f'Image "{name}" has shape {shape}, expected {reference_shape}')
+        fast_compare = hasattr(reference_affine, "same_values")  # (the reference's own AffineMatrix under reference_binding has none)
         for affine in img_batch.affines:
-            if affine is reference_affine or torch.equal(affine.data, reference_affine.data):
+            if affine is reference_affine or (fast_compare and affine.same_values(reference_affine)) or torch.equal(affine.data, reference_affine.data):
                 continue
             if not torch.allclose(affine.data, reference_affine.data, rtol=1e-6, atol=1e-6):
                 raise RuntimeError(
@@ -1096,10 +1197,14 @@ def _resolve_spatial_params(params: dict[str, Any]):
             None,
         )
     parked_matrices, raw_matrices = params.raw("affine_matrix") if isinstance(params, LazyParams) else (False, None)
-    matrices = list(raw_matrices) if parked_matrices else [matrix_of(m) for m in params["affine_matrix"]]
-    fields = list(raw_fields) if parked else [field_of(c) for c in params["control_points"]]
+    matrices = raw_matrices if parked_matrices and isinstance(raw_matrices, _MatrixList) else (
+        list(raw_matrices) if parked_matrices else [matrix_of(m) for m in params["affine_matrix"]])
+    if parked and isinstance(raw_fields, _StackedFields):
+        fields = raw_fields  # one block for the whole batch: handed to the launch as it is
+    else:
+        fields = list(raw_fields) if parked else [field_of(c) for c in params["control_points"]]
     displacements = [displacement_of(d) for d in params["max_displacement"]]
-    if all(m is None for m in matrices) and all(f is None for f in fields):
+    if all(m is None for m in matrices) and not isinstance(fields, _StackedFields) and all(f is None for f in fields):
         return None, None, None, None
     return None, None, None, _PerSampleGrids(matrices, fields, displacements)
 
