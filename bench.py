@@ -170,6 +170,63 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
     return result
 
 
+def other_configs(batch, size: int, device, timer) -> dict:
+    """The other configurations BASELINE.json names, on this GPU, in both resampling precisions:
+    the fused ``tio.Spatial`` (affine + elastic in ONE resampling — the north-star's named kernel) on the bench batch, and
+    config 5, the 512^3 multi-modal subject (2 x float32 + int16 label map, nearest for the labels)."""
+    from parity_harness import nested_spheres  # noqa: PLC0415
+
+    affine = dict(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5))
+    fused = tio.Spatial(**affine, max_displacement=7.5)
+    volume = size**3 * 4
+    out: dict = {}
+    previous = tio.get_resample_precision()
+
+    def timed(transform, data, steps):
+        for _ in range(3):
+            transform(data)
+        torch.cuda.synchronize()
+        timer.pairs, timer.active = [], True
+        start = time.perf_counter()
+        for _ in range(steps):
+            result = transform(data)
+        torch.cuda.synchronize()
+        elapsed = (time.perf_counter() - start) / steps
+        timer.active = False
+        del result
+        return elapsed, timer.mean_ms()
+
+    try:
+        for precision in ("fast", "exact"):
+            tio.set_resample_precision(precision)
+            seconds, launch_ms = timed(fused, batch, 10)
+            nbytes = 2 * volume * batch.batch_size
+            out[f"fused_spatial_8x{size}^3,resample={precision}"] = {
+                "volumes_per_s": batch.batch_size / seconds, "ms_per_step": 1e3 * seconds, "resample_launch_ms": launch_ms,
+                "launch_frac_of_hbm_peak": nbytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if launch_ms else None,
+                "step_frac_of_hbm_peak": nbytes / seconds / 1e9 / HBM_PEAK_GBS,
+            }
+        big = 2 * size
+        g = torch.Generator(device=device).manual_seed(5)
+        subject = tio.SubjectsBatch({
+            "t1": tio.ImagesBatch(torch.rand(1, 1, big, big, big, generator=g, device=device), [tio.AffineMatrix()], image_class=tio.ScalarImage),
+            "t2": tio.ImagesBatch(torch.rand(1, 1, big, big, big, generator=g, device=device) + 1, [tio.AffineMatrix()], image_class=tio.ScalarImage),
+            "seg": tio.ImagesBatch(nested_spheres(big).unsqueeze(0).to(device), [tio.AffineMatrix()], image_class=tio.LabelMap),
+        })
+        nbytes = 2 * (2 * 4 + 2) * big**3
+        for precision in ("fast", "exact"):
+            tio.set_resample_precision(precision)
+            seconds, launch_ms = timed(fused, subject, 5)
+            out[f"config5_subject_{big}^3_2xf32+i16,resample={precision}"] = {
+                "subjects_per_s": 1 / seconds, "ms_per_step": 1e3 * seconds, "resample_launch_ms": launch_ms,
+                "step_frac_of_hbm_peak": nbytes / seconds / 1e9 / HBM_PEAK_GBS,
+                "note": "one tio_resample3d call for the three images; the label map (nearest) pins the exact kernels for the whole launch",
+            }
+    finally:
+        tio.set_resample_precision(previous)
+    return out
+
+
 def load_traffic(precision: str) -> float | None:
     """Per-launch HBM bytes of the dominant kernel (of that precision mode) from the committed PMC summary, if any."""
     path = os.path.join(ROOT, "profiles", "resample_traffic.json")
@@ -197,6 +254,7 @@ def main() -> None:
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--cpu-volumes", type=int, default=8)
     parser.add_argument("--no-aten-baseline", action="store_true", help="skip the stock-ATen restatement of the pipeline (the honest 'before')")
+    parser.add_argument("--no-other-configs", action="store_true", help="skip the fused tio.Spatial and config-5 (512^3 subject) legs (rank 0, N=1 only)")
     parser.add_argument("--no-mode-matrix", action="store_true", help="skip the extra noise-rng / resample-precision legs (rank 0, N=1 only)")
     args = parser.parse_args()
 
@@ -336,6 +394,23 @@ def main() -> None:
                 "reference": modes["noise=reference,resample=exact"]["volumes_per_s"],
                 "note": "reference = bit-identical noise stream (host mt19937 draws, host bound); philox = in-kernel draws, a different stream",
             }
+        if args.gpus == 1 and not args.no_other_configs:
+            out = None
+            line["other_configs"] = other_configs(batch, args.size, device, timer)
+        # which GPU parity tests (tests/, -m gpu) cover each mode of the matrix above — the headline mode included
+        line["parity_coverage"] = {
+            "noise=philox,resample=fast (headline)": [
+                "tests/test_gpu_full_size.py::test_headline_mode_256_matches_oracle[1.0] (3 x 256^3 through the oracle's own Philox stream: fused blur + noise, planned lean bricks)",
+                "tests/test_gpu_full_size.py::test_headline_mode_256_matches_oracle[4095.0] (12-bit intensity range)",
+                "tests/test_gpu_lazy_fusion.py (fused BiasField / Blur / Noise launch == the three separate launches bit for bit, == oracle to 2e-5; asserts the fused branch ran)",
+                "tests/test_gpu_resample_planned.py, tests/test_gpu_full_size.py::test_fast_precision_256_* (FAST resampling vs exact kernel / oracle)",
+            ],
+            "noise=philox,resample=exact": ["tests/test_gpu_lazy_fusion.py", "tests/test_gpu_ops_parity.py (philox add_noise vs oracle philox)", "tests/test_gpu_golden.py (resampling: bit-exact)"],
+            "noise=reference,resample=exact (library default)": [
+                "tests/test_gpu_full_size.py::test_config3_compose_256_batch2_matches_oracle (labels bit-exact, intensities <= 1e-5)",
+                "tests/test_gpu_golden.py (85 transform + 25 feeding-side golden cases generated from the unmodified reference)",
+            ],
+        }
         if args.gpus == 1 and not args.no_aten_baseline:
             out = None
             torch.cuda.empty_cache()

@@ -32,4 +32,4 @@ for _ in range(50):
     transform(batch)
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats(sys.argv[1] if len(sys.argv) > 1 else "tottime").print_stats(45)
+pstats.Stats(pr).sort_stats(sys.argv[1] if len(sys.argv) > 1 else "tottime").print_stats(75)

@@ -9,8 +9,9 @@
 // stream and calls the extern "C" entry point of libtio_hip.so (include/tio_hip.h) — no synchronisation, no
 // .item(), re-entrant.  The kernels live in libtio_hip.so; this file contains no device code and is compiled by
 // the host compiler.  Registered for the CUDA (= HIP on ROCm) dispatch key only: CPU tensors get the
-// dispatcher's "no kernel for backend CPU" error, tensors that require grad are refused (the ops are not
-// differentiable; torchio_amd.reference_binding routes such inputs to the reference).
+// dispatcher's "no kernel for backend CPU" error.  Shape inference (fake / meta kernels) and the backward passes are
+// registered with the dispatcher from Python (torchio_amd/torch_ops.py: torch.library.register_fake /
+// register_autograd); the one backward that needs its own launch is an op of this library too: resample3d_adjoint.
 #include <ATen/ATen.h>
 #include <ATen/hip/HIPContext.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -44,7 +45,6 @@ void check_status(int status, const char* what) { TORCH_CHECK(status == TIO_OK, 
 void check_volume(const at::Tensor& x, const char* what) {
   TORCH_CHECK(x.dim() == 5, what, ": expected a (B, C, I, J, K) tensor, got ", x.dim(), " dimensions");
   TORCH_CHECK(x.is_cuda(), what, ": tensor must live on the GPU");
-  TORCH_CHECK(!x.requires_grad(), what, ": tensors that require grad are not supported (the op is not differentiable)");
 }
 
 const float* opt_f32(const c10::optional<at::Tensor>& t, std::vector<at::Tensor>& keep, const at::Device& device, const char* what) {
@@ -128,6 +128,59 @@ std::vector<at::Tensor> resample3d(at::TensorList images, at::IntArrayRef modes,
   }
   check_status(tio_resample3d(&geom, static_cast<int32_t>(descs.size()), descs.data(), current_stream(first)), "tio_resample3d");
   return outputs;
+}
+
+// resample3d_adjoint(Tensor grad(B,C,*out_shape) f32, int[3] in_shape, mapping, cp, spacings, affine_first, Tensor? fill(C), passthrough)
+//   -> Tensor (B, C, *in_shape) f32: the TRANSPOSE of the trilinear resample3d of one image (TIO_LINEAR_ADJOINT): every output
+//   voxel adds grad * w_t to its in-bounds taps; voxels that took the fill value carry no gradient; gated-out elements pass
+//   their gradient through.  The backward of resample3d (torchio_amd/torch_ops.py registers it with the dispatcher).
+at::Tensor resample3d_adjoint(const at::Tensor& grad, at::IntArrayRef in_shape, const at::Tensor& mapping,
+                              const c10::optional<at::Tensor>& control_points, at::ArrayRef<double> in_spacing,
+                              at::ArrayRef<double> out_spacing, bool affine_first, const c10::optional<at::Tensor>& fill,
+                              const c10::optional<at::Tensor>& passthrough) {
+  check_volume(grad, "resample3d_adjoint");
+  TORCH_CHECK(in_shape.size() == 3 && in_spacing.size() == 3 && out_spacing.size() == 3, "resample3d_adjoint: shapes and spacings have 3 entries");
+  const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(grad.device());
+  const at::Device device = grad.device();
+  std::vector<at::Tensor> keep;
+  const at::Tensor g = grad.to(at::kFloat).contiguous();  // (a handle of its own: `keep` reallocates as it grows)
+  at::Tensor accumulator = at::zeros({g.size(0), g.size(1), in_shape[0], in_shape[1], in_shape[2]}, g.options());
+  tio_resample_geom geom{};
+  geom.batch = static_cast<int32_t>(g.size(0));
+  for (int d = 0; d < 3; d++) {
+    geom.in_shape[d] = static_cast<int32_t>(in_shape[d]);
+    geom.out_shape[d] = static_cast<int32_t>(g.size(2 + d));
+    geom.in_spacing[d] = static_cast<float>(in_spacing[d]);
+    geom.out_spacing[d] = static_cast<float>(out_spacing[d]);
+  }
+  geom.affine_first = affine_first ? 1 : 0;
+  TORCH_CHECK(mapping.device() == device && mapping.dim() == 3 && mapping.size(1) == 3 && mapping.size(2) == 4 &&
+                  (mapping.size(0) == 1 || mapping.size(0) == geom.batch),
+              "resample3d_adjoint: mapping must be (B|1, 3, 4) on the data's device");
+  keep.push_back(mapping.to(at::kFloat).contiguous());
+  geom.mapping_dev = keep.back().data_ptr<float>();
+  geom.mapping_batched = mapping.size(0) > 1 ? 1 : 0;
+  if (control_points.has_value() && control_points->defined()) {
+    const at::Tensor& cp = *control_points;
+    TORCH_CHECK(cp.device() == device && cp.dim() == 5 && cp.size(4) == 3 && (cp.size(0) == 1 || cp.size(0) == geom.batch),
+                "resample3d_adjoint: control points must be (B|1, ni, nj, nk, 3) on the data's device");
+    keep.push_back(cp.to(at::kFloat).contiguous());
+    geom.control_points_dev = keep.back().data_ptr<float>();
+    geom.cp_batched = cp.size(0) > 1 ? 1 : 0;
+    for (int d = 0; d < 3; d++) geom.cp_shape[d] = static_cast<int32_t>(cp.size(1 + d));
+  }
+  geom.passthrough_dev = opt_flags(passthrough, keep, device, geom.batch, "resample3d_adjoint");
+  geom.precision = TIO_PRECISION_EXACT;
+  tio_resample_image d{};
+  d.in = accumulator.data_ptr();          // written: dL/d(input)
+  d.out = const_cast<float*>(g.data_ptr<float>());  // read: the incoming gradient
+  d.channels = static_cast<int32_t>(g.size(1));
+  d.dtype = TIO_F32;
+  d.interp = TIO_LINEAR_ADJOINT;
+  if (fill.has_value() && fill->defined()) TORCH_CHECK(fill->numel() == g.size(1), "resample3d_adjoint: a fill tensor holds one value per channel");
+  d.fill_dev = opt_f32(fill, keep, device, "resample3d_adjoint");
+  check_status(tio_resample3d(&geom, 1, &d, current_stream(grad)), "tio_resample3d (adjoint)");
+  return accumulator;
 }
 
 // separable_conv3d(Tensor x, Tensor taps(1|B,3,stride), int[3] radius, Tensor? skip(B)) -> Tensor
@@ -268,6 +321,8 @@ at::Tensor bspline_prefilter(const at::Tensor& x, int64_t order) {
 TORCH_LIBRARY(tio_hip, m) {
   m.def("resample3d(Tensor[] images, int[] modes, Tensor mapping, Tensor? control_points, float[] in_spacing, float[] out_spacing, "
         "int[] out_shape, bool affine_first, Tensor?[] fill, Tensor? passthrough=None, int precision=0) -> Tensor[]");
+  m.def("resample3d_adjoint(Tensor grad, int[] in_shape, Tensor mapping, Tensor? control_points, float[] in_spacing, float[] out_spacing, "
+        "bool affine_first, Tensor? fill=None, Tensor? passthrough=None) -> Tensor");
   m.def("separable_conv3d(Tensor x, Tensor taps, int[] radius, Tensor? skip=None) -> Tensor");
   m.def("bias_field_apply(Tensor x, Tensor coarse, bool divide=False, Tensor? skip=None) -> Tensor");
   m.def("add_noise(Tensor x, Tensor mean, Tensor std, bool rician=False, Tensor? base=None, Tensor? base2=None, int philox_seed=0, "
@@ -279,6 +334,7 @@ TORCH_LIBRARY(tio_hip, m) {
 
 TORCH_LIBRARY_IMPL(tio_hip, CUDA, m) {
   m.impl("resample3d", resample3d);
+  m.impl("resample3d_adjoint", resample3d_adjoint);
   m.impl("separable_conv3d", separable_conv3d);
   m.impl("bias_field_apply", bias_field_apply);
   m.impl("add_noise", add_noise);
