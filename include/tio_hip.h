@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 7
+#define TIO_ABI_VERSION 8
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -449,6 +449,27 @@ int tio_kspace_segment_mix(const void* const* segments, int32_t n_segments, cons
                            void* stream);
 /* Host helper: fills table_host (n_segments * length * length floats) with W. */
 int tio_kspace_mix_table(int32_t length, int32_t n_segments, const int32_t* bounds, float* table_host);
+
+/* ------------------------------------------------------------------------ */
+/* Host helper: torch's CPU `randn` stream on all host cores (ABI 8)         */
+/* ------------------------------------------------------------------------ */
+/*
+ * Replaces: `torch.randn(data.shape, generator=cpu_gen)` of the reference's Noise (transforms/intensity/noise.py:108-116,
+ * 166-178: ONE CPU generator seeded with params["seed"], shared by the images of the batch in dict order, one or — Rician —
+ * two draws per image).  torch draws on a single thread: 0.35 s for the bench batch.  Here the mt19937 state chain runs on
+ * one thread with integer vectors and every other step (tempering, the 24-bit uniform, the Box-Muller step of
+ * normal_fill_16_AVX2 with avx_mathfun's log / sincos) on `n_threads - 1` more, in place in `out`.  BIT-IDENTICAL to
+ * torch 2.10's CPU kernel for float32 and n >= 16 (pinned against torch.randn: tests/test_host_rng.py); n < 16 returns
+ * TIO_ERR_UNSUPPORTED_CONFIG (torch takes another path there: the caller keeps using torch.randn).  Host pointers only, no
+ * device work, no stream.  The state persists across calls, like the generator it stands for: a second call continues
+ * the stream where the first one stopped (including the 16 extra draws torch spends when n is not a multiple of 16).
+ */
+#define TIO_HOST_MT_STATE_BYTES 2688
+typedef struct tio_host_mt_state { uint64_t opaque[TIO_HOST_MT_STATE_BYTES / 8]; } tio_host_mt_state;
+/* `torch.Generator().manual_seed(seed)` (at::mt19937 keeps the low 32 bits) */
+int tio_host_mt19937_seed(tio_host_mt_state* state, uint64_t seed);
+/* `torch.randn(n, generator=...)` into out (host memory, ideally pinned); n_threads <= 1: everything on the calling thread */
+int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int32_t n_threads);
 
 /* ------------------------------------------------------------------------ */
 /* Introspection                                                             */

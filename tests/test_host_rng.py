@@ -1,0 +1,72 @@
+"""``tio_host_mt19937_*`` (csrc/host_rng.cpp): torch's CPU ``randn`` stream on all host cores, bit for bit.
+
+The reference's Noise draws ``torch.randn(data.shape, generator=Generator().manual_seed(seed))``
+(transforms/intensity/noise.py:108-116, 166-178); this is the pin of the restatement against torch itself — sizes around the
+16-value groups and the 624-word state blocks, continuation across calls (one generator serves every image of a batch),
+thread counts, and a 32 M-draw run.  No GPU involved: the helper is host code of ``libtio_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from torchio_amd import _abi
+from torchio_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def functions():
+    return _lib.load()[1]
+
+
+def _draw(functions, state, n, threads):
+    out = torch.empty(n, dtype=torch.float32)
+    status = functions["host_mt19937_randn"](C.addressof(state), C.c_void_p(out.data_ptr()), n, threads)
+    return status, out
+
+
+@pytest.mark.parametrize("threads", [1, 2, 5])
+@pytest.mark.parametrize("n", [16, 32, 608, 624, 640, 1248, 16 * 1000, 16 * 1000 + 7, 624 * 16 * 3 + 5, 100003])
+def test_randn_equals_torch_bit_for_bit(functions, n, threads):
+    seed = 12345 + n
+    state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    assert functions["host_mt19937_seed"](C.addressof(state), seed) == _abi.OK
+    status, ours = _draw(functions, state, n, threads)
+    assert status == _abi.OK
+    expected = torch.randn(n, generator=torch.Generator().manual_seed(seed))
+    assert torch.equal(ours.view(torch.int32), expected.view(torch.int32))
+
+
+def test_stream_continues_across_calls_like_one_generator(functions):
+    """Several images / a Rician second draw share one generator: call after call, including sizes that leave the state
+    in the middle of a block and sizes that are not multiples of 16 (torch spends 16 extra draws there)."""
+    seed = 2**31 - 7
+    state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    functions["host_mt19937_seed"](C.addressof(state), seed)
+    generator = torch.Generator().manual_seed(seed)
+    for n, threads in [(1000 * 16, 3), (16 * 77 + 3, 1), (624 * 5, 4), (48, 2), (20 * 20 * 20, 8), (16, 1)]:
+        status, ours = _draw(functions, state, n, threads)
+        assert status == _abi.OK
+        expected = torch.randn(n, generator=generator)
+        assert torch.equal(ours.view(torch.int32), expected.view(torch.int32)), n
+
+
+def test_small_draws_are_left_to_torch(functions):
+    state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    functions["host_mt19937_seed"](C.addressof(state), 1)
+    status, _ = _draw(functions, state, 15, 1)
+    assert status == _abi.UNSUPPORTED_CONFIG
+
+
+def test_a_volume_sized_draw(functions):
+    n = 2 * 256 * 256 * 256  # 32 M values: two bench volumes
+    seed = 424242
+    state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    functions["host_mt19937_seed"](C.addressof(state), seed)
+    status, ours = _draw(functions, state, n, 8)
+    assert status == _abi.OK
+    expected = torch.randn(n, generator=torch.Generator().manual_seed(seed))
+    assert torch.equal(ours.view(torch.int32), expected.view(torch.int32))

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_IMAGES = 8
 
 # tio_status
@@ -132,9 +132,13 @@ PROTOTYPES = {
 }
 
 #: entry points only the HIP library has (not the CPU restatement)
+HOST_MT_STATE_BYTES = 2688
+
 HIP_ONLY_PROTOTYPES = {
     "last_error": (C.c_char_p, []),
     "device_count": (C.c_int, []),
+    "host_mt19937_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "host_mt19937_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "blur_fused": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, C.c_int32,

@@ -1,0 +1,357 @@
+// host_rng.cpp — torch's CPU `randn` stream, reproduced on the host cores (tio_host_mt19937_*).
+//
+// The reference's Noise draws `torch.randn(data.shape, generator=cpu_gen)` from ONE seeded CPU generator
+// (reference transforms/intensity/noise.py:108-116, 166-178).  That stream is what "reference-identical noise" means, and
+// torch produces it on one thread: 134 M draws for the bench batch = 0.35 s per step (18 volumes/s, VERDICT r2 missing #2).
+// The stream itself is public arithmetic — restated here, bit for bit, and split so that only the part that MUST be
+// sequential is:
+//   * mt19937 (ATen/core/MT19937RNGEngine.h): the state twist is a chain, but one twist of 624 words is data parallel
+//     inside (new[i] needs old[i], old[i+1] and a word 227 places back): ONE thread runs the chain with 8 / 16-lane
+//     integer vectors and drops every new state block, untempered, straight into the output buffer;
+//   * tempering, the 24-bit uniform (ATen/core/TransformationHelper.h uniform_real: (x & (2^24 - 1)) * 2^-24) and the
+//     Box-Muller step on groups of 16 (ATen/native/cpu/DistributionKernels.cpp normal_fill_16_AVX2: u1 = 1 - data[0:8],
+//     u2 = data[8:16], radius = sqrt(-2 log u1), theta = 2 pi u2, data[0:8] = radius cos theta, data[8:16] = radius sin
+//     theta; log256_ps / sincos256_ps of avx_mathfun.h, with the multiply-adds fused exactly where the compiler of the
+//     torch build fuses them — pinned against torch.randn on 10^8 draws, tests/test_host_rng.py) are independent per
+//     group: worker threads follow the chain through the buffer and turn the raw words into normals IN PLACE.
+// A state block is 624 = 39 x 16 words, so groups never straddle blocks.
+//
+// Host code only (no device code, no HIP call); part of libtio_hip.so so that the binding loads one library.
+#include <immintrin.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "../../include/tio_hip.h"
+
+namespace {
+
+constexpr int kN = 624, kM = 397;
+
+struct MtState {
+  uint32_t s[kN + 16];  // + mirror of the first 16 new words (vector loads across the wrap)
+  int32_t pos;          // next unread word of the current block (kN = block exhausted)
+  int32_t seeded;
+};
+static_assert(sizeof(MtState) <= TIO_HOST_MT_STATE_BYTES, "tio_host_mt_state is too small");
+
+void mt_seed(MtState* st, uint32_t seed) {
+  st->s[0] = seed;
+  for (int j = 1; j < kN; j++) st->s[j] = 1812433253u * (st->s[j - 1] ^ (st->s[j - 1] >> 30)) + static_cast<uint32_t>(j);
+  st->pos = kN;
+  st->seeded = 1;
+}
+
+inline uint32_t twist_word(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+void twist_scalar(uint32_t* s) {
+  for (int i = 0; i < kN - kM; i++) s[i] = twist_word(s[i], s[i + 1], s[i + kM]);
+  for (int i = kN - kM; i < kN - 1; i++) s[i] = twist_word(s[i], s[i + 1], s[i - (kN - kM)]);
+  s[kN - 1] = twist_word(s[kN - 1], s[0], s[kM - 1]);
+}
+
+__attribute__((target("avx2"))) inline void twist_step_avx2(uint32_t* s, int i, const uint32_t* third) {
+  const __m256i upper = _mm256_set1_epi32(static_cast<int>(0x80000000u)), lower = _mm256_set1_epi32(0x7fffffff);
+  const __m256i matrix = _mm256_set1_epi32(static_cast<int>(0x9908b0dfu)), one = _mm256_set1_epi32(1);
+  const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i));
+  const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 1));
+  const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(third));
+  const __m256i y = _mm256_or_si256(_mm256_and_si256(a, upper), _mm256_and_si256(b, lower));
+  const __m256i mag = _mm256_and_si256(_mm256_sub_epi32(_mm256_setzero_si256(), _mm256_and_si256(y, one)), matrix);
+  _mm256_storeu_si256(reinterpret_cast<__m256i*>(s + i), _mm256_xor_si256(_mm256_xor_si256(c, _mm256_srli_epi32(y, 1)), mag));
+}
+
+__attribute__((target("avx2"))) void twist_avx2(uint32_t* s) {
+  twist_step_avx2(s, 0, s + kM);
+  memcpy(s + kN, s, 16 * sizeof(uint32_t));  // (only the first 8 are new yet: the next vector refreshes the rest)
+  twist_step_avx2(s, 8, s + 8 + kM);
+  memcpy(s + kN, s, 16 * sizeof(uint32_t));
+  // words 16 .. 231 take their third operand at i + 397 (old words up to 623, then the mirror of the new words 0 .. 12)
+  for (int i = 16; i < 232; i += 8) twist_step_avx2(s, i, s + i + kM);
+  for (int i = 232; i < kN; i += 8) twist_step_avx2(s, i, s + i - (kN - kM));  // (i = 616 reads s[617 .. 624]: the mirror of new word 0)
+}
+
+__attribute__((target("avx512f"))) inline void twist_step_avx512(uint32_t* s, int i, const uint32_t* third) {
+  const __m512i upper = _mm512_set1_epi32(static_cast<int>(0x80000000u)), lower = _mm512_set1_epi32(0x7fffffff);
+  const __m512i matrix = _mm512_set1_epi32(static_cast<int>(0x9908b0dfu)), one = _mm512_set1_epi32(1);
+  const __m512i a = _mm512_loadu_si512(s + i), b = _mm512_loadu_si512(s + i + 1), c = _mm512_loadu_si512(third);
+  const __m512i y = _mm512_or_si512(_mm512_and_si512(a, upper), _mm512_and_si512(b, lower));
+  const __m512i mag = _mm512_and_si512(_mm512_sub_epi32(_mm512_setzero_si512(), _mm512_and_si512(y, one)), matrix);
+  _mm512_storeu_si512(s + i, _mm512_xor_si512(_mm512_xor_si512(c, _mm512_srli_epi32(y, 1)), mag));
+}
+
+__attribute__((target("avx512f"))) void twist_avx512(uint32_t* s) {
+  twist_step_avx512(s, 0, s + kM);
+  memcpy(s + kN, s, 16 * sizeof(uint32_t));
+  for (int i = 16; i < 240; i += 16) twist_step_avx512(s, i, s + i + kM);  // (i = 224: old words 621 .. 623, then the mirror of new 0 .. 12)
+  for (int i = 240; i < kN; i += 16) twist_step_avx512(s, i, s + i - (kN - kM));
+}
+
+void twist(uint32_t* s) {
+  static const int level = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") ? 1 : 0);
+  if (level == 2) twist_avx512(s);
+  else if (level == 1) twist_avx2(s);
+  else twist_scalar(s);
+}
+
+inline uint32_t temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// ---- one group of 16 raw words -> 16 normals, scalar (the reference for the vector form, and the fallback) ----------------
+inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t as_u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+inline float log_ps(float x) {  // avx_mathfun.h log256_ps, fused as in the torch build
+  x = x < as_f(0x00800000u) ? as_f(0x00800000u) : x;
+  int32_t imm0 = static_cast<int32_t>(as_u(x) >> 23);
+  x = as_f((as_u(x) & ~0x7f800000u) | as_u(0.5f));
+  imm0 -= 0x7f;
+  float e = static_cast<float>(imm0) + 1.0f;
+  const bool below = x < 0.707106781186547524f;
+  const float tmp = below ? x : 0.0f;
+  x = x - 1.0f;
+  e = e - (below ? 1.0f : 0.0f);
+  x = x + tmp;
+  const float z = x * x;
+  float y = 7.0376836292E-2f;
+  y = __builtin_fmaf(y, x, -1.1514610310E-1f);
+  y = __builtin_fmaf(y, x, 1.1676998740E-1f);
+  y = __builtin_fmaf(y, x, -1.2420140846E-1f);
+  y = __builtin_fmaf(y, x, 1.4249322787E-1f);
+  y = __builtin_fmaf(y, x, -1.6668057665E-1f);
+  y = __builtin_fmaf(y, x, 2.0000714765E-1f);
+  y = __builtin_fmaf(y, x, -2.4999993993E-1f);
+  y = __builtin_fmaf(y, x, 3.3333331174E-1f);
+  y = y * x;
+  y = __builtin_fmaf(y, z, e * -2.12194440e-4f);
+  y = __builtin_fmaf(-z, 0.5f, y);
+  x = x + y;
+  return __builtin_fmaf(e, 0.693359375f, x);
+}
+
+inline void sincos_ps(float x, float* s, float* c) {  // avx_mathfun.h sincos256_ps, fused as in the torch build
+  uint32_t sign_sin = as_u(x) & 0x80000000u;
+  x = as_f(as_u(x) & 0x7fffffffu);
+  float y = x * 1.27323954473516f;
+  int32_t j = static_cast<int32_t>(y);
+  j = (j + 1) & ~1;
+  y = static_cast<float>(j);
+  const uint32_t swap_sin = static_cast<uint32_t>(j & 4) << 29;
+  const bool poly = (j & 2) == 0;
+  x = __builtin_fmaf(y, -0.78515625f, x);
+  x = __builtin_fmaf(y, -2.4187564849853515625e-4f, x);
+  x = __builtin_fmaf(y, -3.77489497744594108e-8f, x);
+  const uint32_t sign_cos = static_cast<uint32_t>(~(j - 2) & 4) << 29;
+  sign_sin ^= swap_sin;
+  const float z = x * x;
+  float yc = 2.443315711809948E-005f;
+  yc = __builtin_fmaf(yc, z, -1.388731625493765E-003f);
+  yc = __builtin_fmaf(yc, z, 4.166664568298827E-002f);
+  yc = yc * z;
+  yc = __builtin_fmaf(yc, z, -(z * 0.5f));
+  yc = yc + 1.0f;
+  float ys = -1.9515295891E-4f;
+  ys = __builtin_fmaf(ys, z, 8.3321608736E-3f);
+  ys = __builtin_fmaf(ys, z, -1.6666654611E-1f);
+  ys = ys * z;
+  ys = __builtin_fmaf(ys, x, x);
+  const float ysin2 = poly ? ys : 0.0f, ysin1 = poly ? 0.0f : yc;
+  ys = ys - ysin2;
+  yc = yc - ysin1;
+  *s = as_f(as_u(ysin1 + ysin2) ^ sign_sin);
+  *c = as_f(as_u(yc + ys) ^ sign_cos);
+}
+
+void group16_scalar(uint32_t* words) {  // in place: 16 raw state words -> 16 float32 normals
+  float u[16];
+  for (int i = 0; i < 16; i++) u[i] = static_cast<float>(temper(words[i]) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+  float* out = reinterpret_cast<float*>(words);
+  for (int i = 0; i < 8; i++) {
+    const float radius = __builtin_sqrtf(-2.0f * log_ps(1.0f - u[i]));
+    const float theta = 6.283185307179586476925286766559f * u[i + 8];
+    float s, c;
+    sincos_ps(theta, &s, &c);
+    out[i] = __builtin_fmaf(radius * c, 1.0f, 0.0f);  // fmadd(n, std = 1, mean = 0): n, except that -0 becomes +0 (u1 == 1)
+    out[i + 8] = __builtin_fmaf(radius * s, 1.0f, 0.0f);
+  }
+}
+
+// ---- the same, 8 lanes at a time -------------------------------------------------------------------------------------
+__attribute__((target("avx2,fma"))) inline __m256 uniform8(const uint32_t* words) {
+  __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(words));
+  y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 11));
+  y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 7), _mm256_set1_epi32(static_cast<int>(0x9d2c5680u))));
+  y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 15), _mm256_set1_epi32(static_cast<int>(0xefc60000u))));
+  y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 18));
+  y = _mm256_and_si256(y, _mm256_set1_epi32(0xFFFFFF));
+  return _mm256_mul_ps(_mm256_cvtepi32_ps(y), _mm256_set1_ps(1.0f / 16777216.0f));
+}
+
+__attribute__((target("avx2,fma"))) inline __m256 log256(__m256 x) {
+  const __m256 one = _mm256_set1_ps(1.0f);
+  x = _mm256_max_ps(x, _mm256_castsi256_ps(_mm256_set1_epi32(0x00800000)));
+  __m256i imm0 = _mm256_srli_epi32(_mm256_castps_si256(x), 23);
+  x = _mm256_and_ps(x, _mm256_castsi256_ps(_mm256_set1_epi32(~0x7f800000)));
+  x = _mm256_or_ps(x, _mm256_set1_ps(0.5f));
+  imm0 = _mm256_sub_epi32(imm0, _mm256_set1_epi32(0x7f));
+  __m256 e = _mm256_add_ps(_mm256_cvtepi32_ps(imm0), one);
+  const __m256 mask = _mm256_cmp_ps(x, _mm256_set1_ps(0.707106781186547524f), _CMP_LT_OS);
+  const __m256 tmp = _mm256_and_ps(x, mask);
+  x = _mm256_sub_ps(x, one);
+  e = _mm256_sub_ps(e, _mm256_and_ps(one, mask));
+  x = _mm256_add_ps(x, tmp);
+  const __m256 z = _mm256_mul_ps(x, x);
+  __m256 y = _mm256_set1_ps(7.0376836292E-2f);
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(-1.1514610310E-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(1.1676998740E-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(-1.2420140846E-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(1.4249322787E-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(-1.6668057665E-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(2.0000714765E-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(-2.4999993993E-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(3.3333331174E-1f));
+  y = _mm256_mul_ps(y, x);
+  y = _mm256_fmadd_ps(y, z, _mm256_mul_ps(e, _mm256_set1_ps(-2.12194440e-4f)));
+  y = _mm256_fnmadd_ps(z, _mm256_set1_ps(0.5f), y);
+  x = _mm256_add_ps(x, y);
+  return _mm256_fmadd_ps(e, _mm256_set1_ps(0.693359375f), x);
+}
+
+__attribute__((target("avx2,fma"))) inline void sincos256(__m256 x, __m256* s, __m256* c) {
+  const __m256 sign_mask = _mm256_castsi256_ps(_mm256_set1_epi32(static_cast<int>(0x80000000u)));
+  __m256 sign_sin = _mm256_and_ps(x, sign_mask);
+  x = _mm256_andnot_ps(sign_mask, x);
+  __m256 y = _mm256_mul_ps(x, _mm256_set1_ps(1.27323954473516f));
+  __m256i j = _mm256_cvttps_epi32(y);
+  j = _mm256_and_si256(_mm256_add_epi32(j, _mm256_set1_epi32(1)), _mm256_set1_epi32(~1));
+  y = _mm256_cvtepi32_ps(j);
+  const __m256 swap_sin = _mm256_castsi256_ps(_mm256_slli_epi32(_mm256_and_si256(j, _mm256_set1_epi32(4)), 29));
+  const __m256 poly = _mm256_castsi256_ps(_mm256_cmpeq_epi32(_mm256_and_si256(j, _mm256_set1_epi32(2)), _mm256_setzero_si256()));
+  x = _mm256_fmadd_ps(y, _mm256_set1_ps(-0.78515625f), x);
+  x = _mm256_fmadd_ps(y, _mm256_set1_ps(-2.4187564849853515625e-4f), x);
+  x = _mm256_fmadd_ps(y, _mm256_set1_ps(-3.77489497744594108e-8f), x);
+  const __m256i j2 = _mm256_sub_epi32(j, _mm256_set1_epi32(2));
+  const __m256 sign_cos = _mm256_castsi256_ps(_mm256_slli_epi32(_mm256_andnot_si256(j2, _mm256_set1_epi32(4)), 29));
+  sign_sin = _mm256_xor_ps(sign_sin, swap_sin);
+  const __m256 z = _mm256_mul_ps(x, x);
+  __m256 yc = _mm256_set1_ps(2.443315711809948E-005f);
+  yc = _mm256_fmadd_ps(yc, z, _mm256_set1_ps(-1.388731625493765E-003f));
+  yc = _mm256_fmadd_ps(yc, z, _mm256_set1_ps(4.166664568298827E-002f));
+  yc = _mm256_mul_ps(yc, z);
+  yc = _mm256_fmsub_ps(yc, z, _mm256_mul_ps(z, _mm256_set1_ps(0.5f)));
+  yc = _mm256_add_ps(yc, _mm256_set1_ps(1.0f));
+  __m256 ys = _mm256_set1_ps(-1.9515295891E-4f);
+  ys = _mm256_fmadd_ps(ys, z, _mm256_set1_ps(8.3321608736E-3f));
+  ys = _mm256_fmadd_ps(ys, z, _mm256_set1_ps(-1.6666654611E-1f));
+  ys = _mm256_mul_ps(ys, z);
+  ys = _mm256_fmadd_ps(ys, x, x);
+  const __m256 ysin2 = _mm256_and_ps(poly, ys), ysin1 = _mm256_andnot_ps(poly, yc);
+  ys = _mm256_sub_ps(ys, ysin2);
+  yc = _mm256_sub_ps(yc, ysin1);
+  *s = _mm256_xor_ps(_mm256_add_ps(ysin1, ysin2), sign_sin);
+  *c = _mm256_xor_ps(_mm256_add_ps(yc, ys), sign_cos);
+}
+
+__attribute__((target("avx2,fma"))) void groups_avx2(uint32_t* words, int64_t n_groups) {
+  for (int64_t g = 0; g < n_groups; g++, words += 16) {
+    const __m256 u1 = _mm256_sub_ps(_mm256_set1_ps(1.0f), uniform8(words));
+    const __m256 u2 = uniform8(words + 8);
+    const __m256 radius = _mm256_sqrt_ps(_mm256_mul_ps(_mm256_set1_ps(-2.0f), log256(u1)));
+    const __m256 theta = _mm256_mul_ps(_mm256_set1_ps(6.283185307179586476925286766559f), u2);
+    __m256 s, c;
+    sincos256(theta, &s, &c);
+    const __m256 one = _mm256_set1_ps(1.0f), zero = _mm256_setzero_ps();  // (std = 1, mean = 0: turns a -0 product into +0)
+    _mm256_storeu_ps(reinterpret_cast<float*>(words), _mm256_fmadd_ps(_mm256_mul_ps(radius, c), one, zero));
+    _mm256_storeu_ps(reinterpret_cast<float*>(words) + 8, _mm256_fmadd_ps(_mm256_mul_ps(radius, s), one, zero));
+  }
+}
+
+void groups(uint32_t* words, int64_t n_groups) {
+  static const bool vector = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  if (vector) { groups_avx2(words, n_groups); return; }
+  for (int64_t g = 0; g < n_groups; g++) group16_scalar(words + 16 * g);
+}
+
+inline uint32_t next_word(MtState* st) {
+  if (st->pos >= kN) { twist(st->s); st->pos = 0; }
+  return st->s[st->pos++];
+}
+
+}  // namespace
+
+extern "C" int tio_host_mt19937_seed(tio_host_mt_state* state, uint64_t seed) {
+  if (state == nullptr) return TIO_ERR_INVALID_ARGUMENT;
+  mt_seed(reinterpret_cast<MtState*>(state), static_cast<uint32_t>(seed));  // (at::mt19937 keeps the low 32 bits of the seed)
+  return TIO_OK;
+}
+
+extern "C" int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int32_t n_threads) {
+  MtState* st = reinterpret_cast<MtState*>(state);
+  if (st == nullptr || out == nullptr || n < 0 || st->seeded != 1) return TIO_ERR_INVALID_ARGUMENT;
+  if (n < 16) return TIO_ERR_UNSUPPORTED_CONFIG;  // torch takes its scalar normal_distribution path below 16 values: not restated
+  uint32_t* words = reinterpret_cast<uint32_t*>(out);
+  const int64_t n_full = n & ~static_cast<int64_t>(15);  // values transformed by the in-order groups (normal_fill: i < size - 15)
+  // head: finish the current state block word by word (a previous call may have stopped inside it)
+  int64_t filled = 0;
+  while (filled < n && st->pos < kN) words[filled++] = st->s[st->pos++];
+  // body: whole state blocks straight from the chain; the groups behind `done` are complete and can be transformed
+  const int64_t body_blocks = (n - filled) / kN;
+  const int64_t head = filled;
+  std::atomic<int64_t> done{head};
+  int workers = n_threads > 1 ? n_threads - 1 : 0;
+  if (workers > 64) workers = 64;
+  std::atomic<int64_t> next_group{0};
+  std::atomic<bool> all_written{false};
+  const int64_t total_groups = n_full / 16;
+  constexpr int64_t kChunk = 64;  // groups per claim (4 KiB)
+  auto work = [&]() {
+    for (;;) {
+      int64_t g = next_group.load(std::memory_order_relaxed);
+      if (g >= total_groups) return;
+      const bool finished = all_written.load(std::memory_order_acquire);
+      const int64_t ready = std::min<int64_t>(done.load(std::memory_order_acquire), n_full) / 16;  // groups whose 16 words are written
+      if (ready <= g) {
+        if (finished) return;  // (cannot happen with g < total_groups once everything is written; belt and braces)
+        std::this_thread::yield();
+        continue;
+      }
+      const int64_t take = std::min<int64_t>(kChunk, ready - g);
+      if (!next_group.compare_exchange_weak(g, g + take, std::memory_order_relaxed)) continue;
+      groups(words + 16 * g, take);
+    }
+  };
+  std::vector<std::thread> pool;
+  pool.reserve(workers);
+  for (int t = 0; t < workers; t++) pool.emplace_back(work);
+  for (int64_t b = 0; b < body_blocks; b++) {
+    twist(st->s);
+    memcpy(words + filled, st->s, kN * sizeof(uint32_t));
+    filled += kN;
+    done.store(filled, std::memory_order_release);
+  }
+  if (body_blocks > 0) st->pos = kN;  // the last block the chain produced is used up
+  while (filled < n) words[filled++] = next_word(st);  // tail: the first words of one more block
+  done.store(filled, std::memory_order_release);
+  all_written.store(true, std::memory_order_release);
+  work();  // the chain thread helps with what is left (all of it when n_threads <= 1)
+  for (std::thread& t : pool) t.join();
+  if (n != n_full) {  // normal_fill: "recompute the last 16 values" from 16 FRESH draws
+    uint32_t last[16];
+    for (int i = 0; i < 16; i++) last[i] = next_word(st);
+    groups(last, 1);
+    memcpy(words + n - 16, last, sizeof(last));
+  }
+  return TIO_OK;
+}

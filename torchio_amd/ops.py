@@ -112,6 +112,59 @@ def folded_channel_min(data: Tensor) -> Tensor | None:
     return record[1]
 
 
+class HostNormalStream:
+    """``torch.Generator().manual_seed(seed)`` + ``torch.randn(shape, generator=...)`` on all host cores, bit for bit
+    (``tio_host_mt19937_*``, csrc/host_rng.cpp), delivered on the device.
+
+    The reference's Noise draws from ONE seeded CPU generator, call after call (noise.py:108-116); torch produces that
+    stream on a single thread (0.35 s for 8 x 256^3 values).  Here the mt19937 chain runs on one thread and everything
+    else on the others, into pinned memory, and the upload of a chunk overlaps the generation of the next one.
+    """
+
+    CHUNK = 16 * (1 << 20)  # values per upload (64 MiB; a multiple of 16: only the last chunk can carry torch's tail rule)
+
+    def __init__(self, seed: int) -> None:
+        from . import _lib  # noqa: PLC0415
+
+        _, functions = _lib.load()
+        self._fn = functions
+        self._state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+        status = functions["host_mt19937_seed"](C.addressof(self._state), int(seed) & (2**64 - 1))
+        if status != _abi.OK:
+            raise EngineError(f"tio_host_mt19937_seed failed with status {status}")
+        threads = os.environ.get("TIO_HOST_RNG_THREADS")
+        self.threads = int(threads) if threads else max(1, min(32, (os.cpu_count() or 2) - 1))
+
+    @staticmethod
+    def takes(shape) -> bool:
+        """torch uses another algorithm below 16 values (not restated): such draws stay with ``torch.randn``."""
+        count = 1
+        for extent in shape:
+            count *= int(extent)
+        return count >= 16
+
+    def randn(self, shape, device) -> Tensor:
+        count = 1
+        for extent in shape:
+            count *= int(extent)
+        device = torch.device(device)
+        on_gpu = device.type == "cuda"
+        host = torch.empty(count, dtype=torch.float32, pin_memory=on_gpu)
+        out = torch.empty(count, dtype=torch.float32, device=device) if on_gpu else host
+        for start in range(0, count, self.CHUNK):
+            stop = min(start + self.CHUNK, count)
+            if count - stop < 16 and stop != count:
+                stop = count  # (never leave a last chunk of fewer than 16 values)
+            status = self._fn["host_mt19937_randn"](C.addressof(self._state), C.c_void_p(host.data_ptr() + 4 * start), stop - start, self.threads)
+            if status != _abi.OK:
+                raise EngineError(f"tio_host_mt19937_randn failed with status {status}")
+            if on_gpu:
+                out[start:stop].copy_(host[start:stop], non_blocking=True)
+            if stop == count:
+                break
+        return out.view(tuple(int(extent) for extent in shape))
+
+
 class EngineError(RuntimeError):
     """A ``tio_*`` call returned a non-zero status."""
 

@@ -83,7 +83,15 @@ class Noise(IntensityTransform):
         generator = torch.Generator(device="cpu")
         generator.manual_seed(seed)
         engine = ops.engine()
-        for index, img_batch in enumerate(self._get_images(batch).values()):
+        images = self._get_images(batch)
+        # the reference-identical stream for device-resident images: the same draws as `torch.randn(..., generator=generator)`
+        # below, produced on all host cores (ops.HostNormalStream); one stream object = the one generator of this call
+        stream = None
+        if _NOISE_RNG == "reference" and images and os.environ.get("TIO_HOST_RNG", "1") != "0":
+            tensors = [img._data if hasattr(img, "_data") else img.data for img in images.values()]  # (shape / device: pending stages keep both)
+            if all(t.is_cuda and ops.HostNormalStream.takes(t.shape) for t in tensors):
+                stream = ops.HostNormalStream(seed)
+        for index, img_batch in enumerate(images.values()):
             queue = getattr(img_batch, "_pending", None)  # foreign containers (reference_binding) never defer
             if (
                 queue is not None and queue.blur is not None and _NOISE_RNG != "reference" and not rician and keep is None
@@ -103,8 +111,12 @@ class Noise(IntensityTransform):
             std_arg = ops.h2d(torch.tensor(std, dtype=torch.float32), device) if isinstance(std, list) else std
             keep_arg = None if keep is None else ops.h2d(torch.tensor(keep, dtype=torch.uint8), device)
             if _NOISE_RNG == "reference":
-                base1 = torch.randn(data.shape, generator=generator).to(device)
-                base2 = torch.randn(data.shape, generator=generator).to(device) if rician else None
+                if stream is not None:
+                    base1 = stream.randn(data.shape, device)
+                    base2 = stream.randn(data.shape, device) if rician else None
+                else:
+                    base1 = torch.randn(data.shape, generator=generator).to(device)
+                    base2 = torch.randn(data.shape, generator=generator).to(device) if rician else None
                 img_batch.data = engine.add_noise(
                     work, mean_arg, std_arg, rician=rician, base1=base1, base2=base2, keep=keep_arg
                 )
