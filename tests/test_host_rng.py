@@ -29,7 +29,7 @@ def _draw(functions, state, n, threads):
 
 
 @pytest.mark.parametrize("threads", [1, 2, 5])
-@pytest.mark.parametrize("n", [16, 32, 608, 624, 640, 1248, 16 * 1000, 16 * 1000 + 7, 624 * 16 * 3 + 5, 100003])
+@pytest.mark.parametrize("n", [16, 32, 608, 624, 640, 1248, 16 * 1000, 16 * 1000 + 7, 624 * 16 * 3 + 5, 100003, 624 * 300, 624 * 300 + 5, 624 * 517 + 16 * 11])
 def test_randn_equals_torch_bit_for_bit(functions, n, threads):
     seed = 12345 + n
     state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
@@ -47,7 +47,7 @@ def test_stream_continues_across_calls_like_one_generator(functions):
     state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
     functions["host_mt19937_seed"](C.addressof(state), seed)
     generator = torch.Generator().manual_seed(seed)
-    for n, threads in [(1000 * 16, 3), (16 * 77 + 3, 1), (624 * 5, 4), (48, 2), (20 * 20 * 20, 8), (16, 1)]:
+    for n, threads in [(1000 * 16, 3), (624 * 400 + 32, 6), (16 * 77 + 3, 1), (624 * 5, 4), (624 * 333, 5), (48, 2), (20 * 20 * 20, 8), (16, 1)]:
         status, ours = _draw(functions, state, n, threads)
         assert status == _abi.OK
         expected = torch.randn(n, generator=generator)

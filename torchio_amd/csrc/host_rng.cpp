@@ -22,7 +22,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -303,50 +302,55 @@ extern "C" int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int6
   if (n < 16) return TIO_ERR_UNSUPPORTED_CONFIG;  // torch takes its scalar normal_distribution path below 16 values: not restated
   uint32_t* words = reinterpret_cast<uint32_t*>(out);
   const int64_t n_full = n & ~static_cast<int64_t>(15);  // values transformed by the in-order groups (normal_fill: i < size - 15)
-  // head: finish the current state block word by word (a previous call may have stopped inside it)
-  int64_t filled = 0;
-  while (filled < n && st->pos < kN) words[filled++] = st->s[st->pos++];
-  // body: whole state blocks straight from the chain; the groups behind `done` are complete and can be transformed
-  const int64_t body_blocks = (n - filled) / kN;
-  const int64_t head = filled;
-  std::atomic<int64_t> done{head};
-  int workers = n_threads > 1 ? n_threads - 1 : 0;
-  if (workers > 64) workers = 64;
-  std::atomic<int64_t> next_group{0};
-  std::atomic<bool> all_written{false};
-  const int64_t total_groups = n_full / 16;
-  constexpr int64_t kChunk = 64;  // groups per claim (4 KiB)
-  auto work = [&]() {
-    for (;;) {
-      int64_t g = next_group.load(std::memory_order_relaxed);
-      if (g >= total_groups) return;
-      const bool finished = all_written.load(std::memory_order_acquire);
-      const int64_t ready = std::min<int64_t>(done.load(std::memory_order_acquire), n_full) / 16;  // groups whose 16 words are written
-      if (ready <= g) {
-        if (finished) return;  // (cannot happen with g < total_groups once everything is written; belt and braces)
-        std::this_thread::yield();
-        continue;
-      }
-      const int64_t take = std::min<int64_t>(kChunk, ready - g);
-      if (!next_group.compare_exchange_weak(g, g + take, std::memory_order_relaxed)) continue;
-      groups(words + 16 * g, take);
+  constexpr int64_t kUnitBlocks = 128;                  // state blocks per unit of parallel work (80 k values)
+
+  // head: the rest of the current state block (a previous call may have stopped inside it)
+  const int64_t head = std::min<int64_t>(n, kN - st->pos);
+  const bool aligned = (head % 16) == 0;  // groups of 16 then never straddle state blocks (624 = 39 x 16)
+  const int64_t body_words = n - head;
+  const int64_t total_blocks = (body_words + kN - 1) / kN;  // state blocks the body touches (the last one maybe partly)
+  if (!aligned || n_threads <= 1 || total_blocks < 2 * kUnitBlocks) {
+    // the plain road, on this thread: raw words in order, then the groups (also what a misaligned continuation takes)
+    for (int64_t i = 0; i < n; i++) words[i] = next_word(st);
+    groups(words, n_full / 16);
+  } else {
+    for (int64_t i = 0; i < head; i++) words[i] = st->s[st->pos++];
+    // Phase A, the only sequential part: run the chain through the body, keeping a snapshot of the state every
+    // kUnitBlocks blocks (2.5 KB each; everything stays in this core's cache — nothing of the output is touched here)
+    const int64_t n_units = (total_blocks + kUnitBlocks - 1) / kUnitBlocks;
+    std::vector<uint32_t> snapshots(static_cast<size_t>(n_units) * kN);
+    for (int64_t b = 0; b < total_blocks; b++) {
+      if (b % kUnitBlocks == 0) memcpy(&snapshots[static_cast<size_t>(b / kUnitBlocks) * kN], st->s, kN * sizeof(uint32_t));
+      twist(st->s);
     }
-  };
-  std::vector<std::thread> pool;
-  pool.reserve(workers);
-  for (int t = 0; t < workers; t++) pool.emplace_back(work);
-  for (int64_t b = 0; b < body_blocks; b++) {
-    twist(st->s);
-    memcpy(words + filled, st->s, kN * sizeof(uint32_t));
-    filled += kN;
-    done.store(filled, std::memory_order_release);
+    const int64_t tail_words = body_words - (total_blocks - 1) * kN;  // words of the last block that belong to this call (1 .. 624)
+    st->pos = static_cast<int32_t>(tail_words);
+    // Phase B, parallel: every unit replays its kUnitBlocks twists from its snapshot and turns each block into normals
+    // where it lands in the output (complete groups only: a trailing partial group is torch's tail rule, below)
+    int threads = n_threads > 64 ? 64 : n_threads;
+    if (threads > n_units) threads = static_cast<int>(n_units);
+    auto run = [&](int t) {
+      MtState local;
+      for (int64_t u = t; u < n_units; u += threads) {
+        memcpy(local.s, &snapshots[static_cast<size_t>(u) * kN], kN * sizeof(uint32_t));
+        const int64_t b_end = std::min<int64_t>((u + 1) * kUnitBlocks, total_blocks);
+        for (int64_t b = u * kUnitBlocks; b < b_end; b++) {
+          twist(local.s);
+          const int64_t at = head + b * kN;                                   // first output index of this block
+          const int64_t count = std::min<int64_t>(kN, n - at);                // words of it inside this call
+          memcpy(words + at, local.s, static_cast<size_t>(count) * sizeof(uint32_t));
+          const int64_t whole = (std::min<int64_t>(at + count, n_full) - at) / 16;  // complete groups below n_full
+          if (whole > 0) groups(words + at, whole);
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(threads - 1);
+    for (int t = 1; t < threads; t++) pool.emplace_back(run, t);
+    groups(words, head / 16);  // (the head's groups, while the others start)
+    run(0);
+    for (std::thread& t : pool) t.join();
   }
-  if (body_blocks > 0) st->pos = kN;  // the last block the chain produced is used up
-  while (filled < n) words[filled++] = next_word(st);  // tail: the first words of one more block
-  done.store(filled, std::memory_order_release);
-  all_written.store(true, std::memory_order_release);
-  work();  // the chain thread helps with what is left (all of it when n_threads <= 1)
-  for (std::thread& t : pool) t.join();
   if (n != n_full) {  // normal_fill: "recompute the last 16 values" from 16 FRESH draws
     uint32_t last[16];
     for (int i = 0; i < 16; i++) last[i] = next_word(st);
