@@ -140,9 +140,10 @@ def aten_baseline(size: int, batch: int, device, steps: int = 3) -> dict:
 def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int, timer=None, launch_bytes: int = 0) -> dict:
     """A few steps of the same Compose in another (noise rng, resample precision) mode: volumes/s on this GPU, and the
     mean duration of the tio_resample3d launches in that mode (live HIP events, as for the headline's roofline)."""
-    previous = (tio.get_noise_rng(), tio.get_resample_precision())
+    previous = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision())
     tio.set_noise_rng(noise_rng)
     tio.set_resample_precision(precision)
+    tio.set_stencil_precision(precision)
     try:
         torch.manual_seed(seed)
         for _ in range(2):
@@ -161,6 +162,7 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
             timer.active = False
         tio.set_noise_rng(previous[0])
         tio.set_resample_precision(previous[1])
+        tio.set_stencil_precision(previous[2])
     n = steps * batch.batch_size
     result = {"volumes_per_s": n / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps}
     launch_ms = timer.mean_ms() if timer is not None else None
@@ -268,6 +270,7 @@ def main() -> None:
 
     tio.set_noise_rng(args.noise_rng)
     tio.set_resample_precision(args.resample_precision)
+    tio.set_stencil_precision(args.resample_precision)  # the same switch for the Blur's taps: fused multiply-adds in the throughput mode
     engine = ops.engine()
     timer = KernelTimer(engine, "resample3d")
     transform = build_transform()
@@ -349,6 +352,7 @@ def main() -> None:
                 "global_batch": args.batch * args.gpus,
                 "noise_rng": args.noise_rng,
                 "resample_precision": args.resample_precision,
+                "stencil_precision": args.resample_precision,
                 "parallelism": f"batch-split x{args.gpus} (no data-path collective)",
             },
             "distributed": {

@@ -245,7 +245,11 @@ int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, int32_t bat
                    const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],
                    int32_t noise_on, float noise_mean, float noise_std,
                    const float* noise_mean_dev, const float* noise_std_dev,
-                   int32_t noise_batched, uint64_t philox_seed, void* stream);
+                   int32_t noise_batched, uint64_t philox_seed, int32_t fast_math, void* stream);
+/* fast_math (ABI 8): 0 = every tap is `acc = acc + w * v` with two roundings, the reference's accumulation (bit-identical
+ * to tio_separable_conv3d); 1 = fused multiply-adds in the register-window passes (radii <= 8): one rounding per tap,
+ * results within float rounding of the exact ones (~1e-7 relative; the contract for intensities is 1e-4), and a J+K pass
+ * that is bound by vector instructions ~25 % shorter.  The counterpart of tio_resample_geom.precision for the stencil. */
 
 /*
  * BiasField: y = x * exp(trilinear_upsample(coarse))   (or x / ... when divide)

@@ -132,3 +132,24 @@ def test_lazy_fusion_matches_oracle_and_is_invisible(oracle, hip):
     values = queued.t1.data
     assert queued.t1._pending is None and torch.equal(values, finished.t1.data)
     assert not torch.equal(values, before)
+
+
+def test_fast_stencil_stays_within_float_rounding_of_the_exact_one(hip):
+    """``tio.set_stencil_precision("fast")``: fused multiply-adds in the taps of the fused Blur launch — same taps, same order,
+    one rounding per tap instead of two."""
+    subjects = make_subjects(48, 3, seed=17, with_label=False)
+    gpu_batch = tio.SubjectsBatch.from_subjects(subjects).to("cuda")
+    transform = tio.Compose([tio.BiasField(), tio.Blur(std=(0.5, 2)), tio.Noise()])
+    previous = tio.get_stencil_precision()
+    try:
+        tio.set_stencil_precision("exact")
+        _, exact = _run(transform, gpu_batch, 9, lazy=True)
+        tio.set_stencil_precision("fast")
+        with _FusedCalls(hip) as seen:
+            _, fast = _run(transform, gpu_batch, 9, lazy=True)
+    finally:
+        tio.set_stencil_precision(previous)
+    assert seen.with_noise == 1
+    assert not torch.equal(exact, fast)  # it really is another arithmetic ...
+    scale = float(exact.abs().max())
+    assert float((exact - fast).abs().max()) <= 2e-6 * scale  # ... within a few float32 roundings

@@ -23,7 +23,9 @@ from .data import ScalarImage
 from .data import Subject
 from .data import SubjectsBatch
 from .ops import get_resample_precision
+from .ops import get_stencil_precision
 from .ops import set_resample_precision
+from .ops import set_stencil_precision
 from .transforms import Affine
 from .transforms import Anisotropy
 from .transforms import AppliedTransform
@@ -59,5 +61,5 @@ __all__ = [
     "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "Crop", "ElasticDeformation", "Flip",
     "Gamma", "GridSampler", "Image", "ImagesBatch", "ImagesLoader", "IntensityTransform", "LabelMap", "LabelSampler", "Motion", "Noise", "OneOf",
     "Pad", "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
-    "SubjectsBatch", "SubjectsLoader", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "set_noise_rng", "set_resample_precision",
+    "SubjectsBatch", "SubjectsLoader", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "get_stencil_precision", "set_noise_rng", "set_resample_precision", "set_stencil_precision",
 ]

@@ -143,7 +143,7 @@ HIP_ONLY_PROTOTYPES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, C.c_int32,
          _I32x3, C.c_void_p, _I32x3, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64,
-         C.c_void_p],
+         C.c_int32, C.c_void_p],
     ),
 }
 

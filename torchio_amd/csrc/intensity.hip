@@ -97,6 +97,10 @@ struct ConvArgs {
   const float* noise_mean_b;
   const float* noise_std_b;
   uint64_t noise_seed;
+  // tio_blur_fused(fast_math = 1): the taps of the marching kernel accumulate with fused multiply-adds (one rounding per
+  // tap instead of the reference's two: results within float rounding, ~1e-7 relative — the J+K pass is bound by vector
+  // instructions, not by memory, and the taps are two thirds of them)
+  int fma;
 };
 
 template <int SRC_DT, int DST_DT>
@@ -579,13 +583,24 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
       for (int d = 0; d + 1 < kMarchAhead; d++) nxt[d] = nxt[d + 1];
       nxt[kMarchAhead - 1] = TIO_ROW_LOAD(p + R + kMarchAhead);
       float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (a.fma) {  // (block uniform)
 #pragma unroll
-      for (int t = 0; t < W; t++) {
-        const v4f v = win[(u + t) % W];
-        acc.x = __fadd_rn(acc.x, __fmul_rn(tw[t], v.x));
-        acc.y = __fadd_rn(acc.y, __fmul_rn(tw[t], v.y));
-        acc.z = __fadd_rn(acc.z, __fmul_rn(tw[t], v.z));
-        acc.w = __fadd_rn(acc.w, __fmul_rn(tw[t], v.w));
+        for (int t = 0; t < W; t++) {
+          const v4f v = win[(u + t) % W];
+          acc.x = __builtin_fmaf(tw[t], v.x, acc.x);
+          acc.y = __builtin_fmaf(tw[t], v.y, acc.y);
+          acc.z = __builtin_fmaf(tw[t], v.z, acc.z);
+          acc.w = __builtin_fmaf(tw[t], v.w, acc.w);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < W; t++) {
+          const v4f v = win[(u + t) % W];
+          acc.x = __fadd_rn(acc.x, __fmul_rn(tw[t], v.x));
+          acc.y = __fadd_rn(acc.y, __fmul_rn(tw[t], v.y));
+          acc.z = __fadd_rn(acc.z, __fmul_rn(tw[t], v.z));
+          acc.w = __fadd_rn(acc.w, __fmul_rn(tw[t], v.w));
+        }
       }
       if constexpr (FUSE_K) {
         // the register-window K filter of conv_k_v4_kernel on the row this wave just produced
@@ -607,14 +622,27 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
           w[4 * d] = c.x; w[4 * d + 1] = c.y; w[4 * d + 2] = c.z; w[4 * d + 3] = c.w;
         }
         float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.fma) {
 #pragma unroll
-        for (int jj = 0; jj < 17; jj++) {
-          if (jj >= 8 - rk && jj <= 8 + rk) {
-            const float tv = tk[jj - (8 - rk)];
-            out.x = __fadd_rn(out.x, __fmul_rn(tv, w[jj]));
-            out.y = __fadd_rn(out.y, __fmul_rn(tv, w[jj + 1]));
-            out.z = __fadd_rn(out.z, __fmul_rn(tv, w[jj + 2]));
-            out.w = __fadd_rn(out.w, __fmul_rn(tv, w[jj + 3]));
+          for (int jj = 0; jj < 17; jj++) {
+            if (jj >= 8 - rk && jj <= 8 + rk) {
+              const float tv = tk[jj - (8 - rk)];
+              out.x = __builtin_fmaf(tv, w[jj], out.x);
+              out.y = __builtin_fmaf(tv, w[jj + 1], out.y);
+              out.z = __builtin_fmaf(tv, w[jj + 2], out.z);
+              out.w = __builtin_fmaf(tv, w[jj + 3], out.w);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 17; jj++) {
+            if (jj >= 8 - rk && jj <= 8 + rk) {
+              const float tv = tk[jj - (8 - rk)];
+              out.x = __fadd_rn(out.x, __fmul_rn(tv, w[jj]));
+              out.y = __fadd_rn(out.y, __fmul_rn(tv, w[jj + 1]));
+              out.z = __fadd_rn(out.z, __fmul_rn(tv, w[jj + 2]));
+              out.w = __fadd_rn(out.w, __fmul_rn(tv, w[jj + 3]));
+            }
           }
         }
         acc = out;
@@ -775,6 +803,7 @@ struct ConvFuse {  // optional pointwise stages of tio_blur_fused
   const float* noise_mean_b = nullptr;
   const float* noise_std_b = nullptr;
   uint64_t noise_seed = 0;
+  int fma = 0;
   bool any() const { return bias_coarse != nullptr || noise_on != 0; }
 };
 
@@ -859,6 +888,7 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
         if (radius[axis] <= (pre_bias ? 6 : kMarchMaxRadius) && getenv("TIO_CONV_RING") == nullptr) {
           // register-window marching: one strip per wave, enough segments for >= 8 waves per SIMD
           a.bcs = bcs;
+          a.fma = fuse.fma;
           const int64_t strips = lines;
           int want = static_cast<int>((8192 + strips - 1) / strips);
           want = std::max(1, std::min(want, std::max(1, n / 32)));
@@ -1307,7 +1337,7 @@ extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, 
                               const int32_t shape[3], const float* taps_dev, int32_t taps_batched, int32_t tap_stride,
                               const int32_t radius[3], const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],
                               int32_t noise_on, float noise_mean, float noise_std, const float* noise_mean_dev,
-                              const float* noise_std_dev, int32_t noise_batched, uint64_t philox_seed, void* stream) {
+                              const float* noise_std_dev, int32_t noise_batched, uint64_t philox_seed, int32_t fast_math, void* stream) {
   if (batch == 0) return TIO_OK;
   if (x == nullptr || y == nullptr || tmp == nullptr || shape == nullptr || radius == nullptr || taps_dev == nullptr)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: null argument");
@@ -1333,6 +1363,7 @@ extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, 
     for (int d = 0; d < 3; d++) fuse.bias_shape[d] = bias_coarse_shape[d];
   fuse.noise_on = noise_on; fuse.noise_batched = noise_batched; fuse.noise_mean = noise_mean; fuse.noise_std = noise_std;
   fuse.noise_mean_b = noise_mean_dev; fuse.noise_std_b = noise_std_dev; fuse.noise_seed = philox_seed;
+  fuse.fma = fast_math != 0;
   float* tmp0 = static_cast<float*>(tmp);
   float* tmp1 = tmp0 + static_cast<int64_t>(batch) * channels * n;
   const int status = launch_conv<TIO_F32>(x, y, tmp0, tmp1, batch, channels, shape, taps_dev, taps_batched, tap_stride, radius, nullptr,
