@@ -153,3 +153,35 @@ def test_fast_stencil_stays_within_float_rounding_of_the_exact_one(hip):
     assert not torch.equal(exact, fast)  # it really is another arithmetic ...
     scale = float(exact.abs().max())
     assert float((exact - fast).abs().max()) <= 2e-6 * scale  # ... within a few float32 roundings
+
+
+def test_host_resident_subjects_are_staged_through_the_device(hip, oracle):
+    """``tio.Compose(...)(cpu_subject)`` — the reference's everyday call (transform.py:212-254) — works on the HIP engine:
+    the data takes ONE trip through the device and comes back as host tensors with the oracle's values."""
+    import copy
+
+    subjects = make_subjects(24, 2, seed=19)
+    transform = tio.Compose([tio.Affine(degrees=(-8, 8), scales=(0.95, 1.05)), tio.Blur(std=(0.5, 1.0)), tio.Gamma(log_gamma=(-0.2, 0.2))])
+    previous = tio.get_noise_rng()
+    tio.set_noise_rng("reference")
+    try:
+        torch.manual_seed(21)
+        with use_engine(oracle):
+            expected = transform(tio.SubjectsBatch.from_subjects(copy.deepcopy(subjects)))
+        host_batch = tio.SubjectsBatch.from_subjects(copy.deepcopy(subjects))
+        before = host_batch.t1.data.clone()
+        torch.manual_seed(21)
+        actual = transform(host_batch)
+        assert actual.t1.data.device.type == "cpu" and actual.seg.data.device.type == "cpu"
+        assert host_batch.t1.data.device.type == "cpu" and torch.equal(host_batch.t1.data, before)  # the caller's batch: untouched, at home
+        assert torch.equal(actual.seg.data, expected.seg.data)
+        torch.testing.assert_close(actual.t1.data, expected.t1.data, rtol=1e-5, atol=2e-6)
+        # a single Subject goes the same way
+        torch.manual_seed(22)
+        with use_engine(oracle):
+            want = tio.Affine(degrees=(-8, 8))(copy.deepcopy(subjects[0]))
+        torch.manual_seed(22)
+        got = tio.Affine(degrees=(-8, 8))(copy.deepcopy(subjects[0]))
+        assert got.t1.data.device.type == "cpu" and torch.equal(got.seg.data, want.seg.data)
+    finally:
+        tio.set_noise_rng(previous)

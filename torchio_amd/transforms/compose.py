@@ -19,6 +19,8 @@ import torch
 
 from ..data.batch import SubjectsBatch
 from .transform import Transform
+from .transform import _return_home
+from .transform import _stage_on_engine_device
 from .transform import _wrap
 
 
@@ -42,6 +44,12 @@ class Compose(Transform):
 
     def _forward(self, data: Any) -> Any:
         batch, unwrap = _wrap(data)
+        home = _stage_on_engine_device(batch)
+        if home is not None:  # host-resident data: ONE trip through the device for the whole container (transform.py)
+            try:
+                return unwrap(_return_home(self._forward(batch), home))
+            finally:
+                _return_home(batch, home)
         for transform in self.transforms:
             # Children apply without copying: the container copied the input once (compose.py:18-35).  For a child whose
             # envelope is the stock one (no overridden `forward`, no module hooks) that is exactly `_forward(batch)`;
@@ -103,6 +111,12 @@ class OneOf(Transform):
 
     def _forward(self, data: Any) -> Any:
         batch, unwrap = _wrap(data)
+        home = _stage_on_engine_device(batch)
+        if home is not None:  # host-resident data: ONE trip through the device for the whole container (transform.py)
+            try:
+                return unwrap(_return_home(self._forward(batch), home))
+            finally:
+                _return_home(batch, home)
         with _disabled_copy(self.transforms):
             if self.per_instance and batch.batch_size > 1:
                 return unwrap(self._forward_per_element(batch))
@@ -149,6 +163,12 @@ class SomeOf(Transform):
 
     def _forward(self, data: Any) -> Any:
         batch, unwrap = _wrap(data)
+        home = _stage_on_engine_device(batch)
+        if home is not None:  # host-resident data: ONE trip through the device for the whole container (transform.py)
+            try:
+                return unwrap(_return_home(self._forward(batch), home))
+            finally:
+                _return_home(batch, home)
         with _disabled_copy(self.transforms):
             if self.per_instance and batch.batch_size > 1:
                 return unwrap(self._forward_per_element(batch))

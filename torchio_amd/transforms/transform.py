@@ -92,6 +92,12 @@ class Transform(nn.Module):
 
     def _forward(self, data: Any) -> Any:
         batch, unwrap = _wrap(data)
+        home = _stage_on_engine_device(batch)
+        if home is not None:  # host-resident data on the HIP engine: through the device and back (see the helper)
+            try:
+                return unwrap(_return_home(self._forward(batch), home))
+            finally:
+                _return_home(batch, home)
         if not self._per_instance_p_active(batch) and torch.rand(1).item() >= self.p:
             return unwrap(batch)
         params = self.make_params(batch)
@@ -244,6 +250,41 @@ def _init_defaults(cls: type) -> dict[str, Any]:
                 continue
             found.setdefault(name, parameter.default)
     return found
+
+
+# -- host-resident data ----------------------------------------------------------------------------------------------
+def _stage_on_engine_device(batch: SubjectsBatch):
+    """The reference transforms host tensors on the host (transform.py:212-254); this package computes on the GPU only.
+    Host-resident subjects — what a reader hands over — are therefore STAGED: moved to the engine's device for the
+    transform and back afterwards, so that ``tio.Affine()(cpu_subject)`` keeps working and returns host tensors.  Still
+    no CPU compute path: without a GPU the engine raises as before.  (PCIe-bound: DESIGN.md section 5 has the rate.)
+
+    Returns the device to go back to, or ``None`` when nothing has to move (data already on the engine's device, an
+    engine that computes where the data lives — the CPU oracle of the tests —, or no GPU to stage on).
+    """
+    from .. import ops  # noqa: PLC0415
+
+    images = batch.images
+    if not images:
+        return None
+    first = next(iter(images.values()))
+    raw = getattr(first, "_data", None)
+    if raw is None or raw.device.type != "cpu":
+        return None
+    engine = ops._ENGINE
+    if engine is not None and engine.device_type != "cuda":
+        return None
+    if not torch.cuda.is_available():
+        return None
+    home = raw.device
+    batch.to(torch.device("cuda", torch.cuda.current_device()))
+    return home
+
+
+def _return_home(result, home):
+    if isinstance(result, (SubjectsBatch, ImagesBatch)):
+        result.to(home)
+    return result
 
 
 # -- input wrapping (transform.py:488-665): output type always matches input type ---
