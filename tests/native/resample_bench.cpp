@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <random>
 #include <string>
 #include <vector>
@@ -176,6 +177,63 @@ static const Paths kPaths[] = {
     // round 3 A/B: the general planned kernel for a single-channel image too (TIO_PLANNED_LEAN=0)
     {"fast-general", "tile", "0", 1, "planned", "nolean"}};
 
+// --ablate 64: the lean kernel overwrites the first output row of every brick with its block's shader-clock stamps
+// (resample_fast.hpp); medians of the phases, and how many blocks of a CU were alive together
+static void report_stamps(Case& cs, int B, size_t n_out) {
+  Image& im = cs.images[0];
+  if (im.dtype != TIO_F32) return;
+  std::vector<uint32_t> got(static_cast<size_t>(B) * im.channels * n_out);
+  HIP_CHECK(hipMemcpy(got.data(), im.d_out, got.size() * 4, hipMemcpyDeviceToHost));
+  const int Io = cs.out_shape[0], Jo = cs.out_shape[1], Ko = cs.out_shape[2];
+  const char* names[7] = {"entry->descriptor", "->DMA issued (wave 0)", "->column constants", "->own DMA landed", "->all landed (barrier)",
+                          "->sampled (stores issued)", "->stores drained"};
+  const int ti = 16, tk = 16;  // brick shape (resample.hip)
+  std::vector<std::vector<uint32_t>> phase(7);
+  std::vector<uint32_t> life;
+  struct Span { uint64_t t0, t1; };
+  std::map<uint32_t, std::vector<Span>> per_cu;  // (XCC, SE, SH, CU) -> the blocks that ran there
+  size_t found = 0;
+  for (int b = 0; b < B * im.channels; b++)
+    for (int i = 0; i < Io; i += ti)
+      for (int j = 0; j < Jo; j += 16)
+        for (int k = 0; k + 12 <= Ko; k += tk) {
+          const uint32_t* w = &got[static_cast<size_t>(b) * n_out + (static_cast<size_t>(i) * Jo + j) * Ko + k];
+          if (w[0] != 0x53544D50u || w[10] != 0u) continue;  // staged bricks only
+          found++;
+          uint32_t prev = 0;
+          for (int q = 0; q < 7; q++) { phase[q].push_back(w[3 + q] - prev); prev = w[3 + q]; }
+          life.push_back(w[9]);
+          const uint64_t t0 = (static_cast<uint64_t>(w[2]) << 32) | w[1];
+          const uint32_t cu = ((w[12] & 0xF) << 16) | (w[11] & 0xFF00);  // HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
+          per_cu[cu].push_back(Span{t0, t0 + w[9]});
+        }
+  if (!found) { printf("  stamps: none found\n"); return; }
+  auto med = [](std::vector<uint32_t>& v, double f) { std::sort(v.begin(), v.end()); return v[static_cast<size_t>(f * (v.size() - 1))]; };
+  printf("  stamps: %zu staged bricks; life median %u p10 %u p90 %u ticks\n", found, med(life, 0.5), med(life, 0.1), med(life, 0.9));
+  for (int q = 0; q < 7; q++) printf("    %-28s median %6u  p10 %6u  p90 %6u\n", names[q], med(phase[q], 0.5), med(phase[q], 0.1), med(phase[q], 0.9));
+  // residency per CU: share of the CU's busy span with n blocks alive, and the gap between a block's end and the next entry
+  double share[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0.0;
+  std::vector<uint32_t> gaps;
+  for (auto& kv : per_cu) {
+    std::vector<std::pair<uint64_t, int>> ev;
+    for (const Span& sp : kv.second) { ev.push_back({sp.t0, +1}); ev.push_back({sp.t1, -1}); }
+    std::sort(ev.begin(), ev.end());
+    int alive = 0;
+    uint64_t last_end = 0;
+    for (size_t e = 0; e + 1 < ev.size(); e++) {
+      if (ev[e].second < 0) last_end = ev[e].first;
+      else if (last_end != 0) { gaps.push_back(static_cast<uint32_t>(std::min<uint64_t>(ev[e].first - last_end, 1u << 30))); last_end = 0; }
+      alive += ev[e].second;
+      const double dt = static_cast<double>(ev[e + 1].first - ev[e].first);
+      share[std::min(alive, 7)] += dt; total += dt;
+    }
+  }
+  printf("    %zu CUs seen; share of a CU's span with n blocks alive:", per_cu.size());
+  for (int n = 0; n < 6; n++) printf(" %d: %.1f%%", n, 100.0 * share[n] / total);
+  if (!gaps.empty()) printf("\n    end of a block -> next entry on that CU: median %u p10 %u p90 %u ticks", med(gaps, 0.5), med(gaps, 0.1), med(gaps, 0.9));
+  printf("\n");
+}
+
 static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
   if (!g_case_filter.empty() && cs.name.find(g_case_filter) == std::string::npos) return 0;
   const int B = cs.batch;
@@ -292,6 +350,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       ms /= reps;
     }
+    if (p != 0 && getenv("TIO_TILE_ABLATE") && (atoi(getenv("TIO_TILE_ABLATE")) & 64)) report_stamps(cs, B, n_out);
     size_t diff_first = 0, diff_oracle = 0;
     double max_rel = 0.0;
     for (size_t i = 0; i < cs.images.size(); i++) {

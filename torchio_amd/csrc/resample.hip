@@ -885,7 +885,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           for (int e = 0; e < 3; e++) la.dsc[e] = a.rsp[e] * (a.affine_first ? a.half_h[e] / a.dh[e] : 1.0f);
           la.hx = a.size_m1[0]; la.hy = a.size_m1[1]; la.hz = a.size_m1[2];
           la.affine_first = a.affine_first; la.ablate = a.ablate;
-          auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16> : resample_planned_lean_kernel<false, 16, 16, 16>;
+          auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3> : resample_planned_lean_kernel<false, 16, 16, 16, 3>;
           if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       static_cast<int>(lds_p)) != hipSuccess)
             return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);

@@ -833,11 +833,18 @@ __device__ __forceinline__ float lean_gather(const float* __restrict__ chan, int
 // shape.  Tried and dropped (profiles/r03_resample.md): eight waves per 16-plane brick (two threads per column) — no
 // faster for affine launches, much slower for elastic ones; 8-plane bricks with five or six blocks per CU — no faster;
 // 16 x 8 x 32 bricks (longer rows: fewer, fuller cache lines) — boxes outgrow the tile, slower; 16-byte stores through a
-// quad transpose — a quarter of the store instructions, no faster (the transpose costs what the stores saved).
-template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK>
-__global__ __launch_bounds__(256, 3) void resample_planned_lean_kernel(const LeanArgs a) {
-  constexpr int NW = 4;
-  static_assert(TJ * TK == 256 && (TK & (TK - 1)) == 0, "one thread per column of the brick");
+// quad transpose — a quarter of the store instructions, no faster (the transpose costs what the stores saved).  Later in
+// round 3 (profiles/r03_resample.md section 5): wave priorities (s_setprio around the DMA issue or the sampling),
+// nontemporal stores, a wave footprint of 8 x 8 columns (conflict-free LDS reads, 32-byte store segments), the box
+// through registers (global_load_dwordx4 + ds_write_b128) instead of the LDS-DMA, 12- and 14-plane bricks with a fourth
+// block per CU, 512-thread blocks on 16 x 16 x 32 and 8 x 16 x 32 bricks — none faster on the affine launch (the
+// 16 x 16 x 32 bricks gain 6 % on an elastic-only launch and lose 2 x on rotated boxes that outgrow 80 KB).
+// a.ablate (TIO_TILE_ABLATE, tests/native/resample_bench --ablate): 1 no DMA, 2 no sampling, 64 shader-clock stamps
+// written over the brick's first output row (instrumentation), 128 every lane samples one LDS address.
+template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_kernel(const LeanArgs a) {
+  constexpr int NW = TJ * TK / 64;
+  static_assert((TJ * TK) % 64 == 0 && (TK & (TK - 1)) == 0, "one thread per column of the brick");
   constexpr int PLANES = TI;  // output planes per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_tile = smem;
@@ -851,6 +858,7 @@ __global__ __launch_bounds__(256, 3) void resample_planned_lean_kernel(const Lea
     asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K),
                  "s"(a.ablate));
   }
+  const unsigned long long t_entry = (a.ablate & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned brick = xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items));
   const int b = static_cast<int>(fastdiv(brick, a.bpe_magic, a.bricks_per_element));
   // the two scalar loads everything waits for, requested together
@@ -879,11 +887,14 @@ __global__ __launch_bounds__(256, 3) void resample_planned_lean_kernel(const Lea
 
   const int kind = kind_w & 0xFF;
   bx.kind = kind; bx.interior = kind_w >> 8;
+  unsigned long long t_desc = 0ull, t_issued = 0ull;
+  if (a.ablate & 64) { asm volatile("" ::"s"(kind)); t_desc = __builtin_amdgcn_s_memtime(); }
   if (kind == kDescStaged && !(a.ablate & 1)) {  // the road to the first DMA instruction ends here
     StageLanes sl;
     sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
     stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
   }
+  if (a.ablate & 64) t_issued = __builtin_amdgcn_s_memtime();
 
   const int i_count = min(TI, a.Io - i_begin), nv = min(TJ, a.Jo - j_lo), nw = min(TK, a.Ko - k_lo);
   const bool col_active = (tj < nv) & (tk < nw);
@@ -951,8 +962,16 @@ __global__ __launch_bounds__(256, 3) void resample_planned_lean_kernel(const Lea
   float A3[3], B3[3];
   int run0 = u0;
   int run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
+  if (a.ablate & 128) {  // experiment: every lane samples the box origin (same instructions, one LDS address per wave)
+#pragma unroll
+    for (int r = 0; r < 3; r++) { A3[r] = 0.25f; B3[r] = 0.0f; }
+  }
+  unsigned long long t_ready = 0ull, t_own = 0ull, t_landed = 0ull;
+  if (a.ablate & 64) t_ready = __builtin_amdgcn_s_memtime();
   tile_dma_wait();
+  if (a.ablate & 64) t_own = __builtin_amdgcn_s_memtime();
   __syncthreads();
+  if (a.ablate & 64) t_landed = __builtin_amdgcn_s_memtime();
   if (col_active && u0 < u1 && !(a.ablate & 2)) {
     uint32_t kmin = 0xFFFFFFFFu;
     const bool needs_mask = has_fill & !bx.interior;
@@ -962,6 +981,23 @@ __global__ __launch_bounds__(256, 3) void resample_planned_lean_kernel(const Lea
       run0 = run1;
       if (run0 >= u1) break;
       run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
+    }
+  }
+  if (a.ablate & 64) {  // instrumentation: the block's shader-clock stamps over the first row of its own output
+    const unsigned long long t_sampled = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const unsigned long long t_drained = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && nw >= 12 && i_count >= 1) {
+      unsigned* w = reinterpret_cast<unsigned*>(out_chan + static_cast<int64_t>(i_begin) * slab_b) + (j_lo * a.Ko + k_lo);
+      w[0] = 0x53544D50u;
+      w[1] = static_cast<unsigned>(t_entry); w[2] = static_cast<unsigned>(t_entry >> 32);
+      w[3] = static_cast<unsigned>(t_desc - t_entry); w[4] = static_cast<unsigned>(t_issued - t_entry);
+      w[5] = static_cast<unsigned>(t_ready - t_entry); w[6] = static_cast<unsigned>(t_own - t_entry);
+      w[7] = static_cast<unsigned>(t_landed - t_entry); w[8] = static_cast<unsigned>(t_sampled - t_entry);
+      w[9] = static_cast<unsigned>(t_drained - t_entry); w[10] = static_cast<unsigned>(kind);
+      w[11] = static_cast<unsigned>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   // HW_ID
+      w[12] = static_cast<unsigned>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));  // XCC_ID
     }
   }
 }
