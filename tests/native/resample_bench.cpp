@@ -146,6 +146,7 @@ struct Case {
   double max_deg = 10, scale_dev = 0.1, shift = 5, amp = 7.5;
   std::vector<Image> images;
   std::vector<uint8_t> cp_skip, passthrough;
+  bool half_shift = false;  // identity mapping shifted by exactly half a voxel: every nearest index is a tie
 };
 
 static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
@@ -246,6 +247,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     const double gs = getenv("TIO_BENCH_GEOM_SCALE") ? atof(getenv("TIO_BENCH_GEOM_SCALE")) : 1.0;
     if (cs.affine) random_mapping(&mapping[12 * b], cs.in_shape, cs.max_deg * gs, cs.scale_dev * gs, cs.shift);
     else identity_mapping(&mapping[12 * b]);
+    if (cs.half_shift) { mapping[12 * b + 3] = 0.5f; mapping[12 * b + 7] = -0.5f; mapping[12 * b + 11] = 1.5f; }
     if (cs.out_shape[0] != cs.in_shape[0])  // resampling case: scale the mapping to the output grid
       for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) mapping[12 * b + r * 4 + c] *= static_cast<float>(cs.in_shape[c]) / cs.out_shape[c];
@@ -332,10 +334,14 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     if (kPaths[p].kernel) setenv("TIO_FAST_KERNEL", kPaths[p].kernel, 1); else unsetenv("TIO_FAST_KERNEL");
     const std::string mix = kPaths[p].v2 ? kPaths[p].v2 : "";
     setenv("TIO_PLANNED_LEAN", mix == "nolean" ? "0" : "1", 1);
+    setenv("TIO_NEAREST_KERNEL", p == 0 ? "0" : "1", 1);  // the baseline keeps nearest images on the gather kernel's exact chain
     geom.precision = kPaths[p].fast ? TIO_PRECISION_FAST : TIO_PRECISION_EXACT;
-    bool all_f32_linear = true;
-    for (const Image& im : cs.images) all_f32_linear &= im.dtype == TIO_F32 && im.interp == TIO_LINEAR;
-    const bool tolerant = kPaths[p].fast && all_f32_linear;  // other launches stay on the exact kernels
+    // a FAST call samples its float32 trilinear images within 1e-4 when every other image of the call has a kernel of its
+    // own (nearest without a fill rule: resample_nearest.hpp, bit-exact); any other image pins the exact kernels for all
+    bool fast_set = true;
+    for (const Image& im : cs.images)
+      fast_set &= (im.dtype == TIO_F32 && im.interp == TIO_LINEAR) || (im.interp == TIO_NEAREST && !im.with_fill && p != 0);
+    const bool fast_call = kPaths[p].fast && fast_set;
     for (Image& im : cs.images) HIP_CHECK(hipMemset(im.d_out, 0xCD, static_cast<size_t>(B) * im.channels * n_out * dtype_bytes(im.dtype)));
     int st = tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
     if (st != 0) { fprintf(stderr, "%s/%s: tio_resample3d failed %d: %s\n", cs.name.c_str(), kPaths[p].name, st, tio_last_error()); return 1; }
@@ -359,6 +365,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
       std::vector<uint8_t> got(static_cast<size_t>(B) * im.channels * n_out * es);
       HIP_CHECK(hipMemcpy(got.data(), im.d_out, got.size(), hipMemcpyDeviceToHost));
       if (p == 0) first[i] = got;
+      const bool tolerant = fast_call && im.dtype == TIO_F32 && im.interp == TIO_LINEAR;
       if (tolerant) {  // |fast - exact| <= 1e-4 max(1, |exact|); a flipped fill decision (mask within rounding of 0.5) counts apart
         const float* gf = reinterpret_cast<const float*>(got.data());
         const float* ff = reinterpret_cast<const float*>(first[i].data());
@@ -383,7 +390,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     printf("%-34s %-13s", cs.name.c_str(), kPaths[p].name);
     if (time_it) printf(" %8.3f ms  %8.1f GB/s algorithmic (%5.1f%% of 8 TB/s)", ms, algorithmic / (ms * 1e6), algorithmic / (ms * 1e6) / 80.0);
     printf("  mismatch vs gather: %zu", diff_first);
-    if (tolerant) printf("  (max rel %.2e)", max_rel);
+    if (fast_call) printf("  (max rel %.2e)", max_rel);
     if (check_oracle) printf("  vs oracle: %zu", diff_oracle);
     printf("\n");
     fflush(stdout);
@@ -469,6 +476,60 @@ int main(int argc, char** argv) {
         failures += run_case(c, 1, true, false);
       }
     }
+    {  // nearest images without a fill rule: resample_nearest.hpp (every element size; ties; flags; far out; spacing)
+      const int dts[] = {TIO_U8, TIO_I16, TIO_I32, TIO_I64, TIO_F32, TIO_F64};
+      for (int dt : dts) {
+        Case c = make_case(("nearest dtype " + std::to_string(dt)).c_str(), 2, 33, 34, 36, true, true);
+        c.images.push_back(Image{dt == TIO_I16 ? 2 : 1, dt, TIO_NEAREST, false});
+        failures += run_case(c, 1, true, false);
+      }
+      {
+        Case c = make_case("nearest all ties (half-voxel shift)", 1, 40, 48, 64, false, false);
+        c.half_shift = true;
+        c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+        failures += run_case(c, 1, true, false);
+      }
+      {
+        Case c = make_case("nearest ties + elastic", 1, 40, 48, 64, false, true);
+        c.half_shift = true; c.amp = 0.0;
+        c.images.push_back(Image{1, TIO_U8, TIO_NEAREST, false});
+        failures += run_case(c, 1, true, false);
+      }
+      {
+        Case c = make_case("nearest far-out i16", 2, 64, 48, 96, true, true);
+        c.max_deg = 40; c.shift = 30; c.scale_dev = 0.4;
+        c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+        failures += run_case(c, 1, true, false);
+      }
+      {
+        Case c = make_case("nearest mixed sizes + flags", 4, 50, 37, 75, true, true);
+        c.images.push_back(Image{2, TIO_I16, TIO_NEAREST, false});
+        c.images.push_back(Image{1, TIO_U8, TIO_NEAREST, false});
+        c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+        c.images.push_back(Image{1, TIO_I32, TIO_NEAREST, true});  // with a fill rule: stays with the trilinear image
+        c.cp_skip = {0, 1, 0, 0}; c.passthrough = {0, 0, 1, 0};
+        failures += run_case(c, 1, true, false);
+      }
+      {
+        Case c = make_case("nearest downsample x2 aniso", 1, 96, 96, 96, true, true);
+        c.out_shape[0] = c.out_shape[1] = c.out_shape[2] = 48;
+        c.out_spacing[0] = 2.0f; c.out_spacing[1] = 2.5f; c.out_spacing[2] = 1.5f; c.in_spacing[1] = 1.25f;
+        c.affine_first = false; c.max_deg = 5;
+        c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+        failures += run_case(c, 1, true, false);
+      }
+      {
+        Case c = make_case("nearest dense cp 40^3", 1, 64, 64, 64, true, true);
+        c.cp_shape[0] = c.cp_shape[1] = c.cp_shape[2] = 40; c.amp = 1.0;
+        c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+        failures += run_case(c, 1, true, false);
+      }
+      {
+        Case c = make_case("nearest 2-D K=1", 1, 70, 90, 1, true, false);
+        c.images.push_back(Image{1, TIO_U8, TIO_NEAREST, false});
+        failures += run_case(c, 1, true, false);
+      }
+    }
     {  // 2-D input (K == 1)
       Case c = make_case("2-D K=1", 1, 70, 90, 1, true, false);
       c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
@@ -504,6 +565,25 @@ int main(int argc, char** argv) {
     }
     {
       Case c = make_case("subject 2xf32 + i16 labels", 2, size, size, size, true, true);
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
+      c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+      failures += run_case(c, reps, false, true);
+    }
+  }
+  if (cases == "perf" || cases == "all") {
+    {
+      Case c = make_case("labels i16 affine+elastic", batch, size, size, size, true, true);
+      c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+      failures += run_case(c, reps, false, true);
+    }
+    {
+      Case c = make_case("labels u8 affine", batch, size, size, size, true, false);
+      c.images.push_back(Image{1, TIO_U8, TIO_NEAREST, false});
+      failures += run_case(c, reps, false, true);
+    }
+    {  // config 5's shape: one 512^3 subject (when --size 256: twice the edge)
+      Case c = make_case("subject 512^3 2xf32 + i16 labels", 1, 2 * size, 2 * size, 2 * size, true, true);
       c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
       c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
       c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});

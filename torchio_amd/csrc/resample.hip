@@ -72,6 +72,7 @@ struct ResampleArgs {
   int tile_cap;  // floats of LDS available for one staged input brick (tile kernel)
   int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
   int dma_packed;  // planned bricks: DMA instructions cover rows across x-plane boundaries (A/B: TIO_DMA_PACKED=0)
+  float nn_eps;    // resample_nearest.hpp: a FAST coordinate decides a nearest index when eps (S + |x|) away from a half-integer
 };
 
 constexpr int kTileI = 8;          // output slabs walked by one block
@@ -82,6 +83,7 @@ constexpr int kLdsFloatsPerCU = 40960;   // 160 KiB
 constexpr int kPlannedMinBricks = 12288;  // below: one kernel with in-kernel boxes (the plan costs a launch)
 constexpr int kTileMinCap = 6144;       // the per-voxel fallback parks 8 planes x 3 coordinates x 256 threads there
 constexpr int kTileBlocksPerCU = 3;       // resident blocks the default LDS budget is sized for
+constexpr float kNearestEps = 2e-6f;      // resample_nearest.hpp: decision margin per unit of (S + |x|); DESIGN.md section 4.1b
 
 // IEEE-754 correctly rounded n / d from r = RN(1/d): q0 = RN(n r), two Markstein
 // refinements (each: exact remainder by FMA, correction by FMA).  Checked
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 
 #include "resample_tile.hpp"
 #include "resample_fast.hpp"
+#include "resample_nearest.hpp"
 
 // Device scratch for the brick plan of a planned launch (resample_fast.hpp): one buffer per (device, stream), grown on
 // demand and kept.  A planned launch is a PAIR of kernels on the caller's stream — plan_bricks_kernel writes the buffer,
@@ -650,6 +653,11 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   // coordinates); everything else shares one launch of the brick / gather kernel
   ResampleArgs pv = a;
   ResampleArgs spl = a;  // B-spline images (TIO_QUADRATIC / TIO_CUBIC): their own launch of the gather kernel as well
+  // nearest images without a fill rule (label maps): their own kernel (resample_nearest.hpp), bit-identical to the exact
+  // chain whatever the precision mode of the call; TIO_NEAREST_KERNEL=0 keeps them with the other images (A/B)
+  ResampleArgs nn = a;
+  nn.n_images = 0;
+  const bool nn_enabled = !(getenv("TIO_NEAREST_KERNEL") != nullptr && atoi(getenv("TIO_NEAREST_KERNEL")) == 0);
   a.n_images = 0;
   pv.n_images = 0;
   pv.any_linear = 1;
@@ -682,6 +690,10 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       pv.img[pv.n_images++] = ImgArgs{s.in, s.out, nullptr, 1, s.dtype, s.interp, s.labels_dev, s.n_labels, s.pad_label, nullptr, nullptr};
       continue;
     }
+    if (nn_enabled && s.interp == TIO_NEAREST && s.fill_dev == nullptr && s.out_min_dev == nullptr) {
+      nn.img[nn.n_images++] = ImgArgs{s.in, s.out, nullptr, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, nullptr, nullptr};
+      continue;
+    }
     a.img[a.n_images++] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, s.out_min_dev, nullptr};
     // the in-bounds weight mask needs the trilinear weights even for nearest data (spatial.py:1722-1727)
     if (s.interp == TIO_LINEAR || s.interp == TIO_LINEAR_ADJOINT || s.fill_dev != nullptr) a.any_linear = 1;
@@ -694,6 +706,28 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_cp = a.cp != nullptr ? a.ni * a.nj * a.nk * 3 : 0;
 
+  if (nn.n_images > 0) {
+    nn.tiles_k = (nn.Ko + 15) / 16; nn.tiles_j = (nn.Jo + 15) / 16; nn.tiles_i = (nn.Io + 15) / 16;
+    nn.magic_k = nn.tiles_k > 1 ? 0xFFFFFFFFu / nn.tiles_k + 1u : 0u;
+    nn.magic_j = nn.tiles_j > 1 ? 0xFFFFFFFFu / nn.tiles_j + 1u : 0u;
+    nn.magic_i = nn.tiles_i > 1 ? 0xFFFFFFFFu / nn.tiles_i + 1u : 0u;
+    const int64_t blocks = static_cast<int64_t>(nn.B) * nn.tiles_i * nn.tiles_j * nn.tiles_k;
+    if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
+    nn.nn_eps = kNearestEps;
+    if (const char* env = getenv("TIO_NEAREST_EPS")) nn.nn_eps = static_cast<float>(atof(env));  // (calibration runs only)
+    const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+    for (int es = 1; es <= 8; es *= 2) {  // one launch per element size present
+      bool present = false;
+      for (int i = 0; i < nn.n_images; i++) present = present || dtype_size(nn.img[i].dtype) == es;
+      if (!present) continue;
+#define TIO_NN_LAUNCH(ES)                                                                                    \
+  if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES>), grid, block, 0, s, nn);     \
+  else hipLaunchKernelGGL((resample_nearest_kernel<false, ES>), grid, block, 0, s, nn);
+      if (es == 1) { TIO_NN_LAUNCH(1) } else if (es == 2) { TIO_NN_LAUNCH(2) } else if (es == 4) { TIO_NN_LAUNCH(4) } else { TIO_NN_LAUNCH(8) }
+#undef TIO_NN_LAUNCH
+    }
+    if (a.n_images == 0 && pv.n_images == 0 && spl.n_images == 0) return check_launch("tio_resample3d");
+  }
   if (pv.n_images > 0) {
     pv.tiles_k = (pv.Ko + kLanes - 1) / kLanes;
     pv.tiles_j = (pv.Jo + kRowsPerBlock - 1) / kRowsPerBlock;
