@@ -146,11 +146,15 @@ typedef struct tio_resample_geom {
    * x = ((g + 1) / 2) (S_own - 1).  All zeros = in_shape (the usual case: every image shares it). */
   int32_t norm_shape[3];
   /* tio_precision.  TIO_PRECISION_EXACT (0, the default): the reference's float32 operation
-   * sequence, bit for bit.  TIO_PRECISION_FAST: launches whose images are all float32 and
-   * trilinear may skip the normalise / un-normalise round trip of the coordinates and
-   * interpolate with nested fma lerps — same interpolant, different rounding: within ~1e-5
-   * absolute of the exact result on unit-range data (the north_star bar for intensities is
-   * 1e-4 relative); any launch with a nearest / label image stays exact.              */
+   * sequence, bit for bit.  TIO_PRECISION_FAST: the float32 trilinear images of the call may skip
+   * the normalise / un-normalise round trip of the coordinates and interpolate with nested fma
+   * lerps — same interpolant, different rounding: within ~1e-5 absolute of the exact result on
+   * unit-range data (the north_star bar for intensities is 1e-4 relative).  Nearest-neighbour
+   * images WITHOUT a fill rule (label maps) are bit-identical to the reference in either mode
+   * and do not hold the float images back (their own kernel: the index of a voxel only
+   * depends on its coordinate's rounding, and coordinates within rounding error of a
+   * half-integer are re-evaluated with the exact chain); any other image in the call — a
+   * nearest image with a fill rule, TIO_LABEL_PV, another dtype — keeps the whole call exact. */
   int32_t precision;
 } tio_resample_geom;
 

@@ -367,13 +367,18 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
       if (p == 0) first[i] = got;
       const bool tolerant = fast_call && im.dtype == TIO_F32 && im.interp == TIO_LINEAR;
       if (tolerant) {  // |fast - exact| <= 1e-4 max(1, |exact|); a flipped fill decision (mask within rounding of 0.5) counts apart
+        // (this harness samples WHITE NOISE of range 4: a coordinate difference d is a value difference of up to ~4 d, and
+        // the FAST and the exact coordinates — both ~1e-7 S from the true one — differ by up to ~4e-5 at S = 512: the
+        // bar scales with the edge beyond 256)
+        const int s_max = std::max(cs.in_shape[0], std::max(cs.in_shape[1], cs.in_shape[2]));
+        const double tol = 1e-4 * std::max(1.0, s_max / 256.0 * 2.0 - 1.0);
         const float* gf = reinterpret_cast<const float*>(got.data());
         const float* ff = reinterpret_cast<const float*>(first[i].data());
         size_t flips = 0;
         for (size_t e = 0; e < got.size() / 4; e++) {
           const double ref = ff[e], val = gf[e];
           const double rel = fabs(val - ref) / fmax(1.0, fabs(ref));
-          if (!(rel <= 1e-4)) {
+          if (!(rel <= tol)) {
             const bool fill_flip = im.with_fill && (ff[e] == im.fill[(e / n_out) % im.channels] || gf[e] == im.fill[(e / n_out) % im.channels]);
             if (fill_flip) flips++; else diff_first++;
           } else if (rel > max_rel) max_rel = rel;

@@ -72,7 +72,6 @@ struct ResampleArgs {
   int tile_cap;  // floats of LDS available for one staged input brick (tile kernel)
   int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
   int dma_packed;  // planned bricks: DMA instructions cover rows across x-plane boundaries (A/B: TIO_DMA_PACKED=0)
-  float nn_eps;    // resample_nearest.hpp: a FAST coordinate decides a nearest index when eps (S + |x|) away from a half-integer
 };
 
 constexpr int kTileI = 8;          // output slabs walked by one block
@@ -83,7 +82,6 @@ constexpr int kLdsFloatsPerCU = 40960;   // 160 KiB
 constexpr int kPlannedMinBricks = 12288;  // below: one kernel with in-kernel boxes (the plan costs a launch)
 constexpr int kTileMinCap = 6144;       // the per-voxel fallback parks 8 planes x 3 coordinates x 256 threads there
 constexpr int kTileBlocksPerCU = 3;       // resident blocks the default LDS budget is sized for
-constexpr float kNearestEps = 2e-6f;      // resample_nearest.hpp: decision margin per unit of (S + |x|); DESIGN.md section 4.1b
 
 // IEEE-754 correctly rounded n / d from r = RN(1/d): q0 = RN(n r), two Markstein
 // refinements (each: exact remainder by FMA, correction by FMA).  Checked
@@ -655,9 +653,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   ResampleArgs spl = a;  // B-spline images (TIO_QUADRATIC / TIO_CUBIC): their own launch of the gather kernel as well
   // nearest images without a fill rule (label maps): their own kernel (resample_nearest.hpp), bit-identical to the exact
   // chain whatever the precision mode of the call; TIO_NEAREST_KERNEL=0 keeps them with the other images (A/B)
-  ResampleArgs nn = a;
-  nn.n_images = 0;
-  const bool nn_enabled = !(getenv("TIO_NEAREST_KERNEL") != nullptr && atoi(getenv("TIO_NEAREST_KERNEL")) == 0);
+  NearestArgs nn{};
+  const bool nn_enabled = !(getenv("TIO_NEAREST_KERNEL") != nullptr && atoi(getenv("TIO_NEAREST_KERNEL")) == 0) &&
+                          static_cast<int64_t>(a.I) * a.J <= (1LL << 24) && a.K <= (1 << 24);
   a.n_images = 0;
   pv.n_images = 0;
   pv.any_linear = 1;
@@ -691,7 +689,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       continue;
     }
     if (nn_enabled && s.interp == TIO_NEAREST && s.fill_dev == nullptr && s.out_min_dev == nullptr) {
-      nn.img[nn.n_images++] = ImgArgs{s.in, s.out, nullptr, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, nullptr, nullptr};
+      nn.img[nn.n_images++] = NearestImg{s.in, s.out, s.channels, dtype_size(s.dtype)};
       continue;
     }
     a.img[a.n_images++] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, s.out_min_dev, nullptr};
@@ -707,22 +705,38 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   const int n_cp = a.cp != nullptr ? a.ni * a.nj * a.nk * 3 : 0;
 
   if (nn.n_images > 0) {
-    nn.tiles_k = (nn.Ko + 15) / 16; nn.tiles_j = (nn.Jo + 15) / 16; nn.tiles_i = (nn.Io + 15) / 16;
+    nn.B = a.B; nn.I = a.I; nn.J = a.J; nn.K = a.K; nn.Io = a.Io; nn.Jo = a.Jo; nn.Ko = a.Ko; nn.affine_first = a.affine_first;
+    nn.mapping = a.mapping; nn.cp = a.cp; nn.cp_skip = a.cp_skip; nn.passthrough = a.passthrough;
+    nn.mapping_batched = a.mapping_batched; nn.cp_batched = a.cp_batched; nn.ni = a.ni; nn.nj = a.nj; nn.nk = a.nk;
+    nn.unit_spacing = a.unit_spacing;
+    nn.scale_i = a.scale_i; nn.scale_j = a.scale_j; nn.scale_k = a.scale_k;
+    for (int d = 0; d < 3; d++) {
+      nn.sp[d] = a.sp[d]; nn.rsp[d] = a.rsp[d]; nn.den[d] = a.den[d]; nn.rden[d] = a.rden[d]; nn.size_m1[d] = a.size_m1[d];
+      nn.ratio[d] = a.half_h[d] / a.dh[d];
+    }
+    const bool nn_rows = nn.Ko >= 48;  // bricks of 16 x 4 x 64 (a wave = one output row) unless the volume is narrower than that
+    const int nn_tj = nn_rows ? 4 : 16, nn_tk = nn_rows ? 64 : 16;
+    nn.tiles_k = (nn.Ko + nn_tk - 1) / nn_tk; nn.tiles_j = (nn.Jo + nn_tj - 1) / nn_tj; nn.tiles_i = (nn.Io + 15) / 16;
     nn.magic_k = nn.tiles_k > 1 ? 0xFFFFFFFFu / nn.tiles_k + 1u : 0u;
     nn.magic_j = nn.tiles_j > 1 ? 0xFFFFFFFFu / nn.tiles_j + 1u : 0u;
     nn.magic_i = nn.tiles_i > 1 ? 0xFFFFFFFFu / nn.tiles_i + 1u : 0u;
     const int64_t blocks = static_cast<int64_t>(nn.B) * nn.tiles_i * nn.tiles_j * nn.tiles_k;
     if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
-    nn.nn_eps = kNearestEps;
-    if (const char* env = getenv("TIO_NEAREST_EPS")) nn.nn_eps = static_cast<float>(atof(env));  // (calibration runs only)
+    nn.eps = kNearestEps;
+    if (const char* env = getenv("TIO_NEAREST_EPS")) nn.eps = static_cast<float>(atof(env));  // (calibration runs only)
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
     for (int es = 1; es <= 8; es *= 2) {  // one launch per element size present
       bool present = false;
-      for (int i = 0; i < nn.n_images; i++) present = present || dtype_size(nn.img[i].dtype) == es;
+      for (int i = 0; i < nn.n_images; i++) present = present || nn.img[i].es == es;
       if (!present) continue;
-#define TIO_NN_LAUNCH(ES)                                                                                    \
-  if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES>), grid, block, 0, s, nn);     \
-  else hipLaunchKernelGGL((resample_nearest_kernel<false, ES>), grid, block, 0, s, nn);
+#define TIO_NN_LAUNCH(ES)                                                                                               \
+  if (nn_rows) {                                                                                                        \
+    if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES, 4, 64>), grid, block, 0, s, nn);        \
+    else hipLaunchKernelGGL((resample_nearest_kernel<false, ES, 4, 64>), grid, block, 0, s, nn);                        \
+  } else {                                                                                                              \
+    if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES, 16, 16>), grid, block, 0, s, nn);       \
+    else hipLaunchKernelGGL((resample_nearest_kernel<false, ES, 16, 16>), grid, block, 0, s, nn);                       \
+  }
       if (es == 1) { TIO_NN_LAUNCH(1) } else if (es == 2) { TIO_NN_LAUNCH(2) } else if (es == 4) { TIO_NN_LAUNCH(4) } else { TIO_NN_LAUNCH(8) }
 #undef TIO_NN_LAUNCH
     }

@@ -1,6 +1,6 @@
 // Nearest-neighbour images without a fill rule (label maps, masks): their own kernel, bit-identical to the exact
-// coordinate chain at a fraction of its cost.  Included by resample.hip after ResampleArgs, the exact-chain helpers
-// (exact_div, normalise_roundtrip, cp_trilerp3) and resample_fast.hpp.
+// coordinate chain at a fraction of its cost.  Included by resample.hip after the exact-chain helpers (exact_div,
+// normalise_roundtrip, cp_trilerp3) and resample_fast.hpp.
 //
 // Reference: `_sample_batch_grid_sample(..., mode="nearest")` -> F.grid_sample(padding_mode="zeros", align_corners=True)
 // (transforms/spatial/spatial.py:1695-1731): the value of the input voxel at nearbyint(coordinate) per axis, zero
@@ -8,9 +8,11 @@
 // reference's chain (affine_grid-style matmul, field upsampling, normalise / un-normalise: ~115 vector instructions per
 // voxel with control points) matters only where a coordinate lies within rounding error of a half-integer.  The kernel
 //   1. evaluates the FAST coordinate line of the column (resample_fast.hpp: one fma per axis and plane),
-//   2. takes the voxel as decided when every axis is at least eps = nn_eps * (S + |x|) away from the next
-//      half-integer (the in-bounds test flips at -0.5 and S - 0.5: half-integers too) — the FAST and the exact
-//      coordinate differ by far less (bound and measurement: DESIGN.md section 4.1b),
+//   2. takes the voxel as decided when on every axis |x - rint(x)| <= 1/2 - margin, margin = kNearestEps (row + S + |x|)
+//      with row = sum |m_rc| S_out,c + |m_r3| (every partial sum of the reference's matmul is below it) — the rounding, and
+//      the in-bounds test (it flips at -1/2 and S - 1/2: half-integers too), are then the same for any coordinate within
+//      `margin` of x; the FAST and the exact coordinate differ by less than a tenth of it (bound and measurement:
+//      DESIGN.md section 4.1b),
 //   3. re-evaluates the few undecided voxels of the column with the exact chain (exact_voxel_coords below: the
 //      operation sequence of resample_kernel, which tests/ pin against the oracle and the reference's golden vectors).
 // One load per voxel straight from global memory (no LDS: a nearest image has no taps to share), element size 1 / 2 / 4 / 8
@@ -19,9 +21,36 @@
 
 namespace tio {
 
+constexpr float kNearestEps = 1e-6f;  // decision margin per unit of magnitude (~16 float32 ulps)
+
+struct NearestImg {
+  const void* in;
+  void* out;
+  int channels, es;  // es: bytes per element
+};
+
+// what the kernel needs of a launch (ResampleArgs carries 1 KiB of image descriptors for the other kernels)
+struct NearestArgs {
+  int B, I, J, K, Io, Jo, Ko, affine_first;
+  const float* mapping;
+  const float* cp;
+  const uint8_t* cp_skip;
+  const uint8_t* passthrough;
+  int mapping_batched, cp_batched, ni, nj, nk, unit_spacing;
+  float sp[3], rsp[3];
+  float scale_i, scale_j, scale_k;
+  float den[3], rden[3], size_m1[3];
+  float ratio[3];  // (S - 1) / max(S_norm - 1, 1) per axis: the FAST line works in voxels of the image's own grid
+  int tiles_k, tiles_j, tiles_i;
+  unsigned magic_k, magic_j, magic_i;
+  float eps;       // kNearestEps (TIO_NEAREST_EPS: calibration runs)
+  int n_images;
+  NearestImg img[TIO_MAX_IMAGES];
+};
+
 // The exact coordinate chain of ONE voxel — the sequence of resample_kernel (resample.hip), operation for operation.
-template <bool ELASTIC_POSSIBLE>
-__device__ __forceinline__ void exact_voxel_coords(const ResampleArgs& a, const float (&m)[12], bool elastic, const float* __restrict__ cp,
+template <bool ELASTIC_POSSIBLE, typename Args>
+__device__ __forceinline__ void exact_voxel_coords(const Args& a, const float (&m)[12], bool elastic, const float* __restrict__ cp,
                                                    const Lerp1D& lj, const Lerp1D& lk, int io, float cj, float ck, float& x, float& y,
                                                    float& z) {
   const float ci = static_cast<float>(io);
@@ -69,6 +98,9 @@ template <> struct NearestBits<2> { typedef uint16_t type; };
 template <> struct NearestBits<4> { typedef uint32_t type; };
 template <> struct NearestBits<8> { typedef uint64_t type; };
 
+template <int ES> struct NearestCarrier { typedef uint32_t type; };  // what a loaded element travels in (a whole register)
+template <> struct NearestCarrier<8> { typedef uint64_t type; };
+
 // nearbyint per axis (round half to even: v_rndne_f32), zero padding: offset of the source voxel, or -1
 __device__ __forceinline__ int nearest_offset(float x, float y, float z, float hx, float hy, float hz, int J, int K) {
   const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
@@ -76,18 +108,28 @@ __device__ __forceinline__ int nearest_offset(float x, float y, float z, float h
   return ok ? (static_cast<int>(xn) * J + static_cast<int>(yn)) * K + static_cast<int>(zn) : -1;
 }
 
-// |frac(x) - 1/2| >= eps (S + |x|): the rounding of x, and its in-bounds test, cannot differ for a coordinate within
-// that distance of x.  NaN and coordinates beyond float32's integer range come out undecided / trivially decided.
-__device__ __forceinline__ bool nearest_decided(float x, float size, float eps) {
-  const float d = fabsf((x - floorf(x)) - 0.5f);
-  return d >= eps * (size + fabsf(x));
+// (a * b + c on 24-bit operands: one full-rate instruction; written out because the compiler turns __mul24(a, b) + c
+// with a scalar b into the quarter-rate v_mad_u64_u32)
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
-// One block per 16 x 16 x 16 brick of the output, one column of 16 planes per thread.
-template <bool ELASTIC_POSSIBLE, int ES>
-__global__ __launch_bounds__(256) void resample_nearest_kernel(const ResampleArgs a) {
+// One block per 16 x TJ x TK brick of the output (TJ * TK = 256), one column of 16 planes per thread: 16 x 4 x 64 — a wave
+// is one output row of 64 voxels: its loads touch one or two cache lines and its stores are contiguous — or 16 x 16 x 16
+// for volumes narrower than that.  The host only launches it for I * J <= 2^24 and K <= 2^24 (24-bit multiply-adds).
+template <bool ELASTIC_POSSIBLE, int ES, int TJ, int TK>
+__global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs a) {
   typedef typename NearestBits<ES>::type bits_t;
-  constexpr int TI = 16, TJ = 16, TK = 16;
+  static_assert(TJ * TK == 256 && (TK & (TK - 1)) == 0, "one thread per column of the brick");
+  constexpr int TI = 16, G = 4;
+  {  // the arguments everything below starts from, requested together (left alone the compiler fetches each one right
+     // before its first use: a dozen dependent round trips through the scalar cache)
+    const float* mp = a.mapping; const uint8_t* pp = a.passthrough; const float* cpp = a.cp;
+    asm volatile("" ::"s"(a.tiles_k), "s"(a.tiles_j), "s"(a.tiles_i), "s"(a.magic_k), "s"(a.magic_j), "s"(a.magic_i), "s"(mp), "s"(pp), "s"(cpp),
+                 "s"(a.mapping_batched), "s"(a.Io), "s"(a.Jo), "s"(a.Ko), "s"(a.I), "s"(a.J), "s"(a.K), "s"(a.eps), "s"(a.n_images));
+  }
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned t1 = fastdiv(tile, a.magic_k, a.tiles_k);
   const int kt = tile - t1 * a.tiles_k;
@@ -113,8 +155,8 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const ResampleArg
   if (a.passthrough != nullptr && a.passthrough[b] != 0) {  // gated-out element: bit-exact copy (spatial.py:1101-1106)
     if (col_active) {
       for (int im = 0; im < a.n_images; im++) {
-        const ImgArgs& g = a.img[im];
-        if (dtype_size(g.dtype) != ES) continue;
+        const NearestImg& g = a.img[im];
+        if (g.es != ES) continue;
         for (int c = 0; c < g.channels; c++) {
           const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
           const bits_t* src = static_cast<const bits_t*>(g.in) + bc * n_out + col;
@@ -134,28 +176,28 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const ResampleArg
     for (int q = 0; q < 12; q++) m[q] = mp[q];
   }
   FastFrameG f;
-  bool weird = false;
 #pragma unroll
-  for (int q = 0; q < 12; q++) {
-    weird |= (__float_as_uint(m[q]) & 0x7FFFFFFFu) > 0x7149F2CAu;  // |m| > 1e30, Inf or NaN: every voxel goes the exact way
-    f.m[q] = m[q] * (a.half_h[q >> 2] / a.dh[q >> 2]);
-  }
+  for (int q = 0; q < 12; q++) f.m[q] = m[q] * a.ratio[q >> 2];
   f.affine_first = a.affine_first != 0;
   f.ni = a.ni; f.nj = a.nj; f.nk = a.nk; f.sci = a.scale_i; f.scj = a.scale_j; f.sck = a.scale_k;
   f.elastic = false; f.cp = nullptr;
 #pragma unroll
-  for (int e = 0; e < 3; e++) f.dsc[e] = a.rsp[e] * (f.affine_first ? a.half_h[e] / a.dh[e] : 1.0f);
+  for (int e = 0; e < 3; e++) f.dsc[e] = a.rsp[e] * (f.affine_first ? a.ratio[e] : 1.0f);
   if constexpr (ELASTIC_POSSIBLE) {
     f.elastic = !(a.cp_skip != nullptr && a.cp_skip[b] != 0);
     f.cp = f.elastic ? a.cp + (a.cp_batched ? static_cast<int64_t>(b) * (a.ni * a.nj * a.nk * 3) : 0) : nullptr;
   }
   pipe_brick_frame(f, j_lo, k_lo);
-  float C3[3], col3[3];
+  float col3[3], lim0[3];
   const float fv = static_cast<float>(jv), fw = static_cast<float>(kw);
+  const float eps = a.eps;
 #pragma unroll
   for (int r = 0; r < 3; r++) {
-    C3[r] = static_cast<float>(static_cast<double>(f.m[4 * r]) * i_begin + f.c[r]);
     col3[r] = __builtin_fmaf(f.m[4 * r + 1], fv, f.m[4 * r + 2] * fw);
+    // 1/2 - eps (row + S): |x - rint(x)| <= lim0 - eps |x| decides the axis (block uniform part)
+    const float row = fabsf(m[4 * r]) * static_cast<float>(a.Io) + fabsf(m[4 * r + 1]) * static_cast<float>(a.Jo) +
+                      fabsf(m[4 * r + 2]) * static_cast<float>(a.Ko) + fabsf(m[4 * r + 3]);
+    lim0[r] = 0.5f - eps * (row + a.size_m1[r] + 1.0f);  // (a NaN / Inf / huge mapping: NaN or negative — nothing is decided)
   }
   Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
   if constexpr (ELASTIC_POSSIBLE) {
@@ -165,57 +207,92 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const ResampleArg
     }
   }
   const float hx = a.size_m1[0], hy = a.size_m1[1], hz = a.size_m1[2];
-  const float eps = weird ? 1.0f : a.nn_eps;  // (1: nothing is ever decided by the FAST line)
+  const unsigned uhx = static_cast<unsigned>(a.I - 1), uhy = static_cast<unsigned>(a.J - 1), uhz = static_cast<unsigned>(a.K - 1);
 
-  // ---- 1 + 2: the FAST line, plane by plane; undecided planes are remembered ---------------------------------------
+  const float cj = static_cast<float>(jo), ck = static_cast<float>(ko);
+  ColumnPlanes planes;
+  planes.cell = -2;
+#pragma unroll
+  for (int e = 0; e < 3; e++) { planes.P0[e] = 0.0f; planes.P1[e] = 0.0f; }
+  float C3[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) C3[r] = static_cast<float>(static_cast<double>(f.m[4 * r]) * i_begin + f.c[r]);
+
+  // ---- 1 + 2: the FAST line, four planes at a time; undecided planes are remembered -------------------------------------
+  // A line holds inside one control cell.  It is fetched at the first plane of a group of four; planes of the group
+  // beyond the cell's end are left to the exact chain (a cell boundary every ~S / (n - 1) planes: a percent or two).
   int offs[TI];
   unsigned undecided = 0u;
   {
-    ColumnPlanes planes;
-    planes.cell = -2;
-#pragma unroll
-    for (int e = 0; e < 3; e++) { planes.P0[e] = 0.0f; planes.P1[e] = 0.0f; }
-    float A3[3], B3[3];
+    float A3[3] = {0.0f, 0.0f, 0.0f}, B3[3] = {0.0f, 0.0f, 0.0f};
     const int u1 = i_begin + i_count;
-    int run0 = i_begin;
-    int run1 = fast_column_line(f, lj, lk, planes, run0, u1, i_begin, C3, col3, lane, A3, B3);
+    int run0 = i_begin, run1 = i_begin;
 #pragma unroll
-    for (int t = 0; t < TI; t++) {
-      offs[t] = -1;
-      if (t < i_count) {  // (block uniform)
-        if (i_begin + t >= run1) {  // next control cell (wave uniform by construction of the runs)
-          run0 = run1;
+    for (int t0 = 0; t0 < TI; t0 += G) {
+      if (t0 < i_count) {  // (block uniform)
+        if (i_begin + t0 >= run1) {  // (wave uniform: the runs depend on the plane index only)
+          run0 = i_begin + t0;
           run1 = fast_column_line(f, lj, lk, planes, run0, u1, i_begin, C3, col3, lane, A3, B3);
         }
-        const float s = static_cast<float>(i_begin + t - run0);
-        const float x = __builtin_fmaf(s, B3[0], A3[0]), y = __builtin_fmaf(s, B3[1], A3[1]), z = __builtin_fmaf(s, B3[2], A3[2]);
-        const bool decided = nearest_decided(x, hx + 1.0f, eps) & nearest_decided(y, hy + 1.0f, eps) & nearest_decided(z, hz + 1.0f, eps);
-        offs[t] = nearest_offset(x, y, z, hx, hy, hz, a.J, a.K);
-        undecided |= decided ? 0u : (1u << t);
+        const float s0 = static_cast<float>(i_begin + t0 - run0);
+        // the group's margin: |x| along a line is largest at one of its ends
+        float lim = 1.0f;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const float xa = __builtin_fmaf(s0, B3[r], A3[r]), xb = __builtin_fmaf(s0 + static_cast<float>(G - 1), B3[r], A3[r]);
+          lim = fminf(lim, __builtin_fmaf(-eps, fmaxf(fabsf(xa), fabsf(xb)), lim0[r]));
+        }
+        if (!(lim >= 0.0f)) lim = -1.0f;  // (NaN geometry: nothing is decided)
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+          const int t = t0 + q;
+          const float s = s0 + static_cast<float>(q);
+          const float x = __builtin_fmaf(s, B3[0], A3[0]), y = __builtin_fmaf(s, B3[1], A3[1]), z = __builtin_fmaf(s, B3[2], A3[2]);
+          const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
+          const bool in_run = i_begin + t < run1;  // (uniform; also false beyond the last plane of a ragged brick)
+          const bool decided = in_run & (fmaxf(fmaxf(fabsf(x - xn), fabsf(y - yn)), fabsf(z - zn)) <= lim);  // NaN: undecided
+          const int ix = static_cast<int>(xn), iy = static_cast<int>(yn), iz = static_cast<int>(zn);
+          const bool ok = (static_cast<unsigned>(ix) <= uhx) & (static_cast<unsigned>(iy) <= uhy) & (static_cast<unsigned>(iz) <= uhz);
+          const int off = mad24(mad24(ix, a.J, iy), a.K, iz);
+          offs[t] = (decided & ok) ? off : -1;
+          undecided |= (decided | (t >= i_count)) ? 0u : (1u << t);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < G; q++) offs[t0 + q] = -1;
       }
     }
   }
   if (!col_active) undecided = 0u;
 
   // ---- the decided voxels: every image and channel of this element size -------------------------------------------------
+  // Sixteen unconditional loads (a voxel without a source reads element 0 and drops it; idle threads shadow a real
+  // column), ONE wait, then the stores.  The wait is written out: the stores sit in per-lane conditionals, and after
+  // such a join the compiler no longer knows what is outstanding — it would put s_waitcnt vmcnt(0) in front of every
+  // store, which also waits for the PREVIOUS store to be acknowledged: sixteen memory round trips per column (measured:
+  // 0.35 ms per 8 x 256^3 launch whatever else the kernel did).
+  typedef typename NearestCarrier<ES>::type carrier_t;
   for (int im = 0; im < a.n_images; im++) {
-    const ImgArgs& g = a.img[im];
-    if (dtype_size(g.dtype) != ES) continue;
+    const NearestImg& g = a.img[im];
+    if (g.es != ES) continue;
     for (int c = 0; c < g.channels; c++) {
       const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
       const bits_t* __restrict__ src = static_cast<const bits_t*>(g.in) + bc * n_in;
       bits_t* __restrict__ dst = static_cast<bits_t*>(g.out) + bc * n_out + col;
-      bits_t v[TI];
+      carrier_t v[TI];
 #pragma unroll
-      for (int t = 0; t < TI; t++) v[t] = (col_active && offs[t] >= 0) ? src[offs[t]] : static_cast<bits_t>(0);
+      for (int t = 0; t < TI; t++) v[t] = static_cast<carrier_t>(src[max(offs[t], 0)]);
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                     "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 #pragma unroll
       for (int t = 0; t < TI; t++)
-        if (col_active && t < i_count && !((undecided >> t) & 1u)) dst[static_cast<int64_t>(t) * slab] = v[t];
+        if (col_active && t < i_count && !((undecided >> t) & 1u))
+          dst[static_cast<int64_t>(t) * slab] = offs[t] >= 0 ? static_cast<bits_t>(v[t]) : static_cast<bits_t>(0);
     }
   }
 
   // ---- 3: the undecided ones through the exact chain ---------------------------------------------------------------------
-  const float cj = static_cast<float>(jo), ck = static_cast<float>(ko);
   while (__builtin_amdgcn_ballot_w64(undecided != 0u) != 0ull) {
     if (undecided != 0u) {
       const int t = __builtin_ctz(undecided);
@@ -224,8 +301,8 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const ResampleArg
       exact_voxel_coords<ELASTIC_POSSIBLE>(a, m, f.elastic, f.cp, lj, lk, i_begin + t, cj, ck, x, y, z);
       const int off = nearest_offset(x, y, z, hx, hy, hz, a.J, a.K);
       for (int im = 0; im < a.n_images; im++) {
-        const ImgArgs& g = a.img[im];
-        if (dtype_size(g.dtype) != ES) continue;
+        const NearestImg& g = a.img[im];
+        if (g.es != ES) continue;
         for (int c = 0; c < g.channels; c++) {
           const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
           const bits_t* src = static_cast<const bits_t*>(g.in) + bc * n_in;

@@ -44,11 +44,13 @@ def set_resample_precision(mode: str) -> None:
     """Process-wide arithmetic of ``tio_resample3d`` for float32 trilinear images.
 
     ``"exact"`` (default) reproduces the reference's float32 operation sequence bit for bit.
-    ``"fast"`` lets launches made only of float32 trilinear images skip the coordinates'
-    normalise / un-normalise round trip and interpolate with nested fma lerps: the same
-    interpolant, results within ~1e-5 of the exact ones on unit-range data (the contract for
-    intensities is 1e-4 relative), ~25 % less kernel time.  Launches with a nearest-neighbour or
-    ``"label"`` image are always exact, so label maps stay bit-identical.
+    ``"fast"`` lets the float32 trilinear images of a call skip the coordinates' normalise /
+    un-normalise round trip and interpolate with nested fma lerps: the same interpolant, results
+    within ~1e-5 of the exact ones on unit-range data (the contract for intensities is 1e-4
+    relative), ~25 % less kernel time.  Label maps resampled with ``"nearest"`` are bit-identical
+    to the reference in either mode (their own kernel, ``csrc/resample_nearest.hpp``); a
+    ``"label"`` (partial-volume) image, or a nearest image with a fill rule, keeps the whole call
+    exact.
     """
     global _RESAMPLE_PRECISION
     if mode not in PRECISION_CODES:
