@@ -223,7 +223,7 @@ def other_configs(batch, size: int, device, timer) -> dict:
             out[f"config5_subject_{big}^3_2xf32+i16,resample={precision}"] = {
                 "subjects_per_s": 1 / seconds, "ms_per_step": 1e3 * seconds, "resample_launch_ms": launch_ms,
                 "step_frac_of_hbm_peak": nbytes / seconds / 1e9 / HBM_PEAK_GBS,
-                "note": "one tio_resample3d call for the three images; the label map (nearest) pins the exact kernels for the whole launch",
+                "note": "one tio_resample3d call for the three images: the float images on the kernels of the precision mode, the label map (nearest, bit-exact in both modes) on its own kernel (csrc/resample_nearest.hpp)",
             }
     finally:
         tio.set_resample_precision(previous)

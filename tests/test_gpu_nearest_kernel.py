@@ -1,0 +1,134 @@
+"""The nearest-neighbour kernel of `tio_resample3d` (csrc/resample_nearest.hpp): label maps without a fill rule.
+
+The kernel decides a voxel's index from the FAST coordinate line unless a coordinate lies within a margin of a
+half-integer, where it evaluates the reference's exact float32 chain.  Its results must be BIT-IDENTICAL to that chain
+everywhere: compared here with the CPU oracle (small cases) and with the previous road of nearest images —
+`TIO_NEAREST_KERNEL=0`: the gather / brick kernels, every voxel through the exact chain — at full size, on label volumes
+of independent random values (a wrong index is a wrong value six times out of seven).
+"""
+from __future__ import annotations
+
+import pytest
+import torch
+
+from test_gpu_ops_parity import _both
+from test_gpu_ops_parity import _control_points
+from test_gpu_ops_parity import _data
+from test_gpu_ops_parity import _mapping
+
+pytestmark = pytest.mark.gpu
+
+
+def _labels(shape, dtype, seed, device="cuda"):
+    g = torch.Generator(device=device).manual_seed(seed)
+    if dtype.is_floating_point:
+        return torch.rand(*shape, generator=g, device=device).to(dtype)
+    return torch.randint(0, 7, shape, generator=g, device=device).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, torch.float32, torch.float64])
+@pytest.mark.parametrize("elastic", [False, True])
+def test_nearest_kernel_matches_the_oracle(oracle, hip, dtype, elastic):
+    batch, shape = 2, (37, 41, 70)  # K >= 48: rows of 64 voxels per wave, ragged on every axis
+    data = _data((batch, 2, *shape), dtype, 3)
+    kwargs = dict(
+        out_shape=shape, mapping=_mapping(batch, 7, scale=0.12, shift=2.5),
+        control_points=_control_points(batch, (6, 5, 7), 8, amplitude=5.0) if elastic else None,
+        in_spacing=(1.0, 1.5, 0.8), out_spacing=(1.0, 1.5, 0.8), affine_first=not elastic, interps=["nearest"], fills=[None],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_every_voxel_a_tie(oracle, hip):
+    """A shift of exactly half a voxel on every axis: every index is a rounding tie, every voxel takes the exact chain."""
+    shape = (33, 40, 64)
+    data = _data((1, 1, *shape), torch.int16, 5)
+    mapping = torch.eye(3, 4).unsqueeze(0).clone()
+    mapping[0, :, 3] = torch.tensor([0.5, -0.5, 1.5])
+    kwargs = dict(out_shape=shape, mapping=mapping, control_points=None, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True,
+                  interps=["nearest"], fills=[None])
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+
+
+def test_non_finite_and_far_away_geometry(oracle, hip):
+    """Element 0: a NaN in the mapping; element 1: the volume a thousand voxels away; element 2: gated out; element 3: plain."""
+    batch, shape = 4, (32, 32, 64)
+    data = _data((batch, 1, *shape), torch.uint8, 11)
+    mapping = _mapping(batch, 13, scale=0.05, shift=1.0)
+    mapping[0, 1, 2] = float("nan")
+    mapping[1, :, 3] += 1000.0
+    kwargs = dict(out_shape=shape, mapping=mapping, control_points=_control_points(batch, (4, 4, 4), 2, amplitude=3.0), in_spacing=(1, 1, 1),
+                  out_spacing=(1, 1, 1), affine_first=True, interps=["nearest"], fills=[None],
+                  passthrough=torch.tensor([0, 0, 1, 0], dtype=torch.uint8), cp_skip=torch.tensor([0, 0, 0, 1], dtype=torch.uint8))
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+    assert torch.equal(gpu[0][2].cpu(), data[2])
+    assert int(gpu[0][1].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_label_maps_no_longer_hold_the_float_images_back(hip, monkeypatch, precision):
+    """One call, two float32 images and two label maps: the labels are bit-identical to the all-exact road in both
+    precision modes; the float images are bit-identical in exact mode and within the FAST tolerance in fast mode (before
+    this kernel a label map in the call kept them on the exact kernels)."""
+    batch, shape = 2, (96, 80, 128)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    t1 = torch.rand(batch, 1, *shape, generator=g, device="cuda")
+    t2 = torch.rand(batch, 1, *shape, generator=g, device="cuda") + 1
+    seg = _labels((batch, 1, *shape), torch.int16, 19)
+    mask = _labels((batch, 2, *shape), torch.uint8, 23)
+    kwargs = dict(
+        out_shape=shape, mapping=_mapping(batch, 29, scale=0.08, shift=3.0).cuda(), control_points=_control_points(batch, (5, 5, 5), 31, amplitude=4.0).cuda(),
+        in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["linear", "linear", "nearest", "nearest"],
+        fills=[torch.tensor([0.0], device="cuda"), torch.tensor([1.0], device="cuda"), None, None],
+    )
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([t1, t2, seg, mask], precision="exact", **kwargs)
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([t1, t2, seg, mask], precision=precision, **kwargs)
+    torch.cuda.synchronize()
+    assert torch.equal(reference[2], got[2]) and torch.equal(reference[3], got[3])
+    for r, o in zip(reference[:2], got[:2]):
+        if precision == "exact":
+            assert torch.equal(r, o)
+        else:
+            assert not torch.equal(r, o)  # the FAST kernels did run
+            beyond = (r.double() - o.double()).abs() > 1e-4
+            assert int(beyond.sum()) <= 16, int(beyond.sum())  # (a fill decision within rounding of 0.5 may flip)
+
+
+@pytest.mark.parametrize("size,elastic", [(256, True), (512, False), (512, True)])
+def test_full_size_label_maps_are_bit_identical_to_the_exact_chain(hip, monkeypatch, size, elastic):
+    """Config 5's label map (512^3 int16) and the bench volume (256^3), every voxel an independent random label."""
+    seg = _labels((1, 1, size, size, size), torch.int16, 41)
+    kwargs = dict(
+        out_shape=(size,) * 3, mapping=_mapping(1, 43, scale=0.06, shift=5.0).cuda(),
+        control_points=_control_points(1, (7, 7, 7), 47, amplitude=7.5).cuda() if elastic else None,
+        in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["nearest"], fills=[None],
+    )
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([seg], **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([seg], **kwargs)[0]
+    torch.cuda.synchronize()
+    assert int((reference != got).sum()) == 0
+    assert int((got != 0).sum()) > 0.5 * got.numel()  # (the volume is in sight)
+
+
+def test_margin_zero_would_not_be_bit_identical(hip, monkeypatch):
+    """The margin is what makes the kernel exact: with TIO_NEAREST_EPS=0 (the FAST line decides every voxel) a 256^3 launch
+    differs from the exact chain in a few hundred voxels — the test above is sensitive to what it claims."""
+    size = 256
+    seg = _labels((2, 1, size, size, size), torch.int16, 53)
+    kwargs = dict(out_shape=(size,) * 3, mapping=_mapping(2, 59, scale=0.06, shift=5.0).cuda(), control_points=None, in_spacing=(1, 1, 1),
+                  out_spacing=(1, 1, 1), affine_first=True, interps=["nearest"], fills=[None])
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([seg], **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    monkeypatch.setenv("TIO_NEAREST_EPS", "0")
+    loose = hip.resample3d([seg], **kwargs)[0]
+    torch.cuda.synchronize()
+    wrong = int((reference != loose).sum())
+    assert 0 < wrong < 1e-4 * seg.numel(), wrong

@@ -237,12 +237,15 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs
         const float s0 = static_cast<float>(i_begin + t0 - run0);
         // the group's margin: |x| along a line is largest at one of its ends
         float lim = 1.0f;
+        bool lim_ok = true;  // (fminf / fmaxf drop a NaN operand: the axes are checked one by one)
 #pragma unroll
         for (int r = 0; r < 3; r++) {
           const float xa = __builtin_fmaf(s0, B3[r], A3[r]), xb = __builtin_fmaf(s0 + static_cast<float>(G - 1), B3[r], A3[r]);
-          lim = fminf(lim, __builtin_fmaf(-eps, fmaxf(fabsf(xa), fabsf(xb)), lim0[r]));
+          const float l = __builtin_fmaf(-eps, fmaxf(fabsf(xa), fabsf(xb)), lim0[r]);
+          lim_ok &= l >= 0.0f;  // NaN / Inf in the mapping or the line, coordinates far beyond float32's integers: false
+          lim = fminf(lim, l);
         }
-        if (!(lim >= 0.0f)) lim = -1.0f;  // (NaN geometry: nothing is decided)
+        if (!lim_ok) lim = -1.0f;  // nothing of this group is decided by the FAST line
 #pragma unroll
         for (int q = 0; q < G; q++) {
           const int t = t0 + q;
