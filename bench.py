@@ -412,6 +412,7 @@ def main() -> None:
             ],
             "noise=philox,resample=exact": ["tests/test_gpu_lazy_fusion.py", "tests/test_gpu_ops_parity.py (philox add_noise vs oracle philox)", "tests/test_gpu_golden.py (resampling: bit-exact)"],
             "noise=reference,resample=exact (library default)": [
+                "tests/test_gpu_device_rng.py (the device-drawn stream == torch.randn(generator=cpu) bit for bit: 134 M draws, tails, continuations)",
                 "tests/test_gpu_full_size.py::test_config3_compose_256_batch2_matches_oracle (labels bit-exact, intensities <= 1e-5)",
                 "tests/test_gpu_golden.py (85 transform + 25 feeding-side golden cases generated from the unmodified reference)",
             ],

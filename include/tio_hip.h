@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 8
+#define TIO_ABI_VERSION 9
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -478,6 +478,28 @@ typedef struct tio_host_mt_state { uint64_t opaque[TIO_HOST_MT_STATE_BYTES / 8];
 int tio_host_mt19937_seed(tio_host_mt_state* state, uint64_t seed);
 /* `torch.randn(n, generator=...)` into out (host memory, ideally pinned); n_threads <= 1: everything on the calling thread */
 int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int32_t n_threads);
+
+/*
+ * The same stream with the draws produced ON THE DEVICE (ABI 9): the host keeps the one part that is a chain — the
+ * mt19937 state twists — and hands the device a PLAN: a snapshot of the state every 128 blocks (2.5 KB per 79 872 draws:
+ * 4 MB for 8 x 256^3) plus the rest of the current block and torch's 16 tail draws.  tio_mt19937_randn_device replays the
+ * twists from the snapshots (one workgroup per snapshot, the state in LDS) and applies tempering, the 24-bit uniform and
+ * normal_fill_16_AVX2's Box-Muller step with avx_mathfun's log / sincos — the float32 operation sequence of the host
+ * restatement, every multiply-add fused where torch's build fuses it: BIT-IDENTICAL to torch.randn(n, generator=cpu_gen)
+ * (tests/test_gpu_device_rng.py).  No 4-bytes-per-draw upload, no worker threads: 6.5 ms of one host core per 134 M draws.
+ *
+ *   words = tio_host_mt19937_plan_words(n);                 capacity (uint32 words) a plan of n draws can need
+ *   tio_host_mt19937_plan(state, n, plan_host, words, &used);   advances `state` exactly like tio_host_mt19937_randn(state, ., n, .)
+ *   copy plan_host[0 : used] to plan_dev (the caller's copy, on `stream`)
+ *   tio_mt19937_randn_device(plan_host, plan_dev, out_dev, stream);
+ *
+ * tio_host_mt19937_plan returns TIO_ERR_UNSUPPORTED_CONFIG — and leaves the state untouched — when n < 16 or when the
+ * stream stands inside a group of 16 (a previous draw count that was not a multiple of 16 AND did not end a block: torch's
+ * groups then straddle state blocks); the caller falls back to tio_host_mt19937_randn.
+ */
+int64_t tio_host_mt19937_plan_words(int64_t n);
+int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int64_t* used_words);
+int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Introspection                                                             */

@@ -1,0 +1,79 @@
+"""`torch.randn(n, generator=cpu_gen)` drawn ON THE DEVICE (csrc/mt19937.hip) from the host's plan of the mt19937 state
+chain (csrc/host_rng.cpp: tio_host_mt19937_plan).  Bit-identical to torch's CPU stream — the reference's Noise draws from
+exactly that (transforms/intensity/noise.py:108-116) — for every count, continuation and tail the transform can produce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_stream(seed, counts):
+    generator = torch.Generator().manual_seed(seed)
+    return [torch.randn(count, generator=generator) for count in counts]
+
+
+@pytest.mark.parametrize("seed", [0, 1234567, 2**31 - 1])
+@pytest.mark.parametrize(
+    "counts",
+    [
+        [1 << 20],                        # whole groups, whole units
+        [(1 << 20) + 16 * 39 * 3 + 32],   # ends inside a state block, on a group boundary
+        [1_500_003],                      # not a multiple of 16: torch's tail rule (16 fresh draws)
+        [1 << 20, 1 << 21, 1 << 20],      # one generator, three images (the second call starts inside a block)
+        [1_200_000 + 7, 1 << 20],         # after a tail the stream stands inside a group: the second draw takes the host road
+        [64 * 64 * 64, 1 << 22],          # a small draw first (host road), then a large one
+    ],
+)
+def test_device_draws_equal_torch_randn(hip, seed, counts):
+    from torchio_amd import ops
+
+    stream = ops.HostNormalStream(seed)
+    got = [stream.randn((count,), "cuda") for count in counts]
+    torch.cuda.synchronize()
+    for expected, result in zip(_torch_stream(seed, counts), got):
+        assert torch.equal(expected.view(torch.int32), result.cpu().view(torch.int32))  # bit for bit (signed zeros included)
+
+
+def test_bench_batch_of_draws_equals_torch_randn(hip):
+    """8 x 256^3: 134 M draws, 1 681 snapshots."""
+    from torchio_amd import ops
+
+    shape = (8, 1, 256, 256, 256)
+    result = ops.HostNormalStream(99).randn(shape, "cuda")
+    expected = torch.randn(shape, generator=torch.Generator().manual_seed(99))
+    assert torch.equal(expected.view(torch.int32), result.cpu().view(torch.int32))
+
+
+def test_device_and_host_roads_agree_and_leave_the_same_state(hip, monkeypatch):
+    from torchio_amd import ops
+
+    counts = [3_000_000, 1_000_000 + 9, 2_000_000]
+    device_stream = ops.HostNormalStream(5)
+    on_device = [device_stream.randn((count,), "cuda").cpu() for count in counts]
+    monkeypatch.setenv("TIO_DEVICE_RNG", "0")
+    host_stream = ops.HostNormalStream(5)
+    on_host = [host_stream.randn((count,), "cuda").cpu() for count in counts]
+    for a, b in zip(on_device, on_host):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert bytes(device_stream._state) == bytes(host_stream._state)
+
+
+def test_plan_refuses_what_it_cannot_express_and_leaves_the_state_alone(hip):
+    from torchio_amd import _abi
+    from torchio_amd import ops
+
+    stream = ops.HostNormalStream(3)
+    stream.randn((1_000_000 + 5,), "cpu")  # a tail: the stream now stands inside a group of 16
+    before = bytes(stream._state)
+    words = int(stream._fn["host_mt19937_plan_words"](1 << 20))
+    plan = torch.empty(words, dtype=torch.int32)
+    used = C.c_int64(0)
+    status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 1 << 20, C.c_void_p(plan.data_ptr()), words, C.byref(used))
+    assert status == _abi.ERR_UNSUPPORTED_CONFIG and bytes(stream._state) == before
+    status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 8, C.c_void_p(plan.data_ptr()), words, C.byref(used))
+    assert status == _abi.ERR_UNSUPPORTED_CONFIG and bytes(stream._state) == before

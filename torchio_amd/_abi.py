@@ -8,11 +8,12 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_IMAGES = 8
 
 # tio_status
 OK = 0
+ERR_UNSUPPORTED_CONFIG = -5  # valid arguments, but this form is not available for them (tio_status)
 UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing was launched
 
 # tio_dtype (values fixed by include/tio_hip.h)
@@ -139,6 +140,9 @@ HIP_ONLY_PROTOTYPES = {
     "device_count": (C.c_int, []),
     "host_mt19937_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "host_mt19937_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "host_mt19937_plan_words": (C.c_int64, [C.c_int64]),
+    "host_mt19937_plan": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "mt19937_randn_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "blur_fused": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, C.c_int32,

@@ -296,6 +296,56 @@ extern "C" int tio_host_mt19937_seed(tio_host_mt_state* state, uint64_t seed) {
   return TIO_OK;
 }
 
+// ---- the plan of a device-side draw (tio_mt19937_randn_device, mt19937.hip) ----------------------------------------------
+// words: [0] magic  [1] head  [2,3] total_blocks  [4] n_units  [5] has_tail  [6,7] n  [8..15] 0
+//        [16 .. 16 + 624) the rest of the current state block (raw words; `head` of them count)
+//        [640 .. 656) torch's tail rule: the last 16 values, final (float bits)
+//        [656 ..) one state snapshot per unit of kPlanUnitBlocks blocks
+constexpr int64_t kPlanUnitBlocks = 128;
+constexpr int64_t kPlanHeader = 16, kPlanTail = kPlanHeader + kN, kPlanSnapshots = kPlanTail + 16;
+constexpr uint32_t kPlanMagic = 0x4D54504Cu;
+
+extern "C" int64_t tio_host_mt19937_plan_words(int64_t n) {
+  if (n < 0) return 0;
+  const int64_t blocks = (n + kN - 1) / kN + 1;
+  return kPlanSnapshots + ((blocks + kPlanUnitBlocks - 1) / kPlanUnitBlocks) * kN;
+}
+
+extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan, int64_t capacity_words, int64_t* used_words) {
+  MtState* st = reinterpret_cast<MtState*>(state);
+  if (st == nullptr || plan == nullptr || used_words == nullptr || n < 0 || st->seeded != 1) return TIO_ERR_INVALID_ARGUMENT;
+  if (n < 16) return TIO_ERR_UNSUPPORTED_CONFIG;
+  const int64_t head = std::min<int64_t>(n, kN - st->pos);
+  if (head % 16 != 0) return TIO_ERR_UNSUPPORTED_CONFIG;  // groups would straddle state blocks: the host road (state untouched)
+  const int64_t body_words = n - head;
+  const int64_t total_blocks = (body_words + kN - 1) / kN;
+  const int64_t n_units = (total_blocks + kPlanUnitBlocks - 1) / kPlanUnitBlocks;
+  const int64_t used = kPlanSnapshots + n_units * kN;
+  if (capacity_words < used) return TIO_ERR_INVALID_ARGUMENT;
+  memset(plan, 0, static_cast<size_t>(kPlanSnapshots) * sizeof(uint32_t));
+  plan[0] = kPlanMagic;
+  plan[1] = static_cast<uint32_t>(head);
+  plan[2] = static_cast<uint32_t>(total_blocks); plan[3] = static_cast<uint32_t>(static_cast<uint64_t>(total_blocks) >> 32);
+  plan[4] = static_cast<uint32_t>(n_units);
+  plan[5] = (n % 16) != 0 ? 1u : 0u;
+  plan[6] = static_cast<uint32_t>(n); plan[7] = static_cast<uint32_t>(static_cast<uint64_t>(n) >> 32);
+  memcpy(plan + kPlanHeader, st->s + st->pos, static_cast<size_t>(head) * sizeof(uint32_t));
+  st->pos += static_cast<int32_t>(head);
+  for (int64_t b = 0; b < total_blocks; b++) {  // the chain: the only sequential part of the stream
+    if (b % kPlanUnitBlocks == 0) memcpy(plan + kPlanSnapshots + (b / kPlanUnitBlocks) * kN, st->s, kN * sizeof(uint32_t));
+    twist(st->s);
+  }
+  if (total_blocks > 0) st->pos = static_cast<int32_t>(body_words - (total_blocks - 1) * kN);
+  if (n % 16 != 0) {  // normal_fill: "recompute the last 16 values" from 16 FRESH draws
+    uint32_t last[16];
+    for (int i = 0; i < 16; i++) last[i] = next_word(st);
+    groups(last, 1);
+    memcpy(plan + kPlanTail, last, sizeof(last));
+  }
+  *used_words = used;
+  return TIO_OK;
+}
+
 extern "C" int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int32_t n_threads) {
   MtState* st = reinterpret_cast<MtState*>(state);
   if (st == nullptr || out == nullptr || n < 0 || st->seeded != 1) return TIO_ERR_INVALID_ARGUMENT;

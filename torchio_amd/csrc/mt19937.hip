@@ -1,0 +1,185 @@
+// mt19937.hip — torch's CPU `randn` stream, drawn on the device from a host-made plan (tio_mt19937_randn_device).
+//
+// Reference: `torch.randn(data.shape, generator=cpu_gen)` of Noise (transforms/intensity/noise.py:108-116, 166-178).  The
+// stream is at::mt19937 -> 24-bit uniforms -> normal_fill_16_AVX2 (ATen/native/cpu/DistributionKernels.cpp) with
+// avx_mathfun.h's log256_ps / sincos256_ps.  host_rng.cpp restates it for the host cores and is pinned against
+// torch.randn; this file is the same float32 operation sequence for the device — every multiply-add below is fused exactly
+// where host_rng.cpp (i.e. the compiler of the torch build) fuses it, and nothing else is (-ffp-contract=off) — so the
+// two produce the same bits (tests/test_gpu_device_rng.py compares them, and torch.randn itself).
+//
+// The only sequential part of the stream, the chain of state twists, stays on ONE host core (tio_host_mt19937_plan):
+// it leaves a snapshot of the 624-word state every 128 blocks.  Here one workgroup per snapshot replays its 128 twists
+// with the state in LDS — a twist is three data-parallel segments (new[i] needs old[i], old[i + 1] and the word 227
+// places back, which is new from the second segment on) — and turns each block into 624 normals where it lands in the
+// output.  HBM traffic: 4 bytes written per draw; the plan is 2.5 KB per 79 872 draws.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tio_hip.h"
+#include "common.hpp"
+
+namespace tio {
+namespace {
+
+constexpr int kN = 624, kM = 397;
+constexpr int64_t kPlanUnitBlocks = 128;
+constexpr int64_t kPlanHeader = 16, kPlanTail = kPlanHeader + kN, kPlanSnapshots = kPlanTail + 16;
+constexpr uint32_t kPlanMagic = 0x4D54504Cu;
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ uint32_t twist_word(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ uint32_t temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// avx_mathfun.h log256_ps as host_rng.cpp's log_ps states it
+__device__ __forceinline__ float log_ps(float x) {
+  x = x < __uint_as_float(0x00800000u) ? __uint_as_float(0x00800000u) : x;
+  int32_t imm0 = static_cast<int32_t>(__float_as_uint(x) >> 23);
+  x = __uint_as_float((__float_as_uint(x) & ~0x7f800000u) | __float_as_uint(0.5f));
+  imm0 -= 0x7f;
+  float e = __fadd_rn(static_cast<float>(imm0), 1.0f);
+  const bool below = x < 0.707106781186547524f;
+  const float tmp = below ? x : 0.0f;
+  x = __fsub_rn(x, 1.0f);
+  e = __fsub_rn(e, below ? 1.0f : 0.0f);
+  x = __fadd_rn(x, tmp);
+  const float z = __fmul_rn(x, x);
+  float y = 7.0376836292E-2f;
+  y = __builtin_fmaf(y, x, -1.1514610310E-1f);
+  y = __builtin_fmaf(y, x, 1.1676998740E-1f);
+  y = __builtin_fmaf(y, x, -1.2420140846E-1f);
+  y = __builtin_fmaf(y, x, 1.4249322787E-1f);
+  y = __builtin_fmaf(y, x, -1.6668057665E-1f);
+  y = __builtin_fmaf(y, x, 2.0000714765E-1f);
+  y = __builtin_fmaf(y, x, -2.4999993993E-1f);
+  y = __builtin_fmaf(y, x, 3.3333331174E-1f);
+  y = __fmul_rn(y, x);
+  y = __builtin_fmaf(y, z, __fmul_rn(e, -2.12194440e-4f));
+  y = __builtin_fmaf(-z, 0.5f, y);
+  x = __fadd_rn(x, y);
+  return __builtin_fmaf(e, 0.693359375f, x);
+}
+
+// avx_mathfun.h sincos256_ps as host_rng.cpp's sincos_ps states it
+__device__ __forceinline__ void sincos_ps(float x, float& s, float& c) {
+  uint32_t sign_sin = __float_as_uint(x) & 0x80000000u;
+  x = __uint_as_float(__float_as_uint(x) & 0x7fffffffu);
+  float y = __fmul_rn(x, 1.27323954473516f);
+  int32_t j = static_cast<int32_t>(y);  // (truncation, like _mm256_cvttps_epi32; y >= 0 and far below 2^31)
+  j = (j + 1) & ~1;
+  y = static_cast<float>(j);
+  const uint32_t swap_sin = static_cast<uint32_t>(j & 4) << 29;
+  const bool poly = (j & 2) == 0;
+  x = __builtin_fmaf(y, -0.78515625f, x);
+  x = __builtin_fmaf(y, -2.4187564849853515625e-4f, x);
+  x = __builtin_fmaf(y, -3.77489497744594108e-8f, x);
+  const uint32_t sign_cos = static_cast<uint32_t>(~(j - 2) & 4) << 29;
+  sign_sin ^= swap_sin;
+  const float z = __fmul_rn(x, x);
+  float yc = 2.443315711809948E-005f;
+  yc = __builtin_fmaf(yc, z, -1.388731625493765E-003f);
+  yc = __builtin_fmaf(yc, z, 4.166664568298827E-002f);
+  yc = __fmul_rn(yc, z);
+  yc = __builtin_fmaf(yc, z, -__fmul_rn(z, 0.5f));
+  yc = __fadd_rn(yc, 1.0f);
+  float ys = -1.9515295891E-4f;
+  ys = __builtin_fmaf(ys, z, 8.3321608736E-3f);
+  ys = __builtin_fmaf(ys, z, -1.6666654611E-1f);
+  ys = __fmul_rn(ys, z);
+  ys = __builtin_fmaf(ys, x, x);
+  const float ysin2 = poly ? ys : 0.0f, ysin1 = poly ? 0.0f : yc;
+  ys = __fsub_rn(ys, ysin2);
+  yc = __fsub_rn(yc, ysin1);
+  s = __uint_as_float(__float_as_uint(__fadd_rn(ysin1, ysin2)) ^ sign_sin);
+  c = __uint_as_float(__float_as_uint(__fadd_rn(yc, ys)) ^ sign_cos);
+}
+
+// lanes i and i + 8 of one group of 16 raw words -> the two normals normal_fill_16_AVX2 leaves there
+__device__ __forceinline__ void normal_pair(uint32_t w1, uint32_t w2, float& at_i, float& at_i8) {
+  const float u1 = __fsub_rn(1.0f, __fmul_rn(static_cast<float>(temper(w1) & 0xFFFFFFu), 1.0f / 16777216.0f));
+  const float u2 = __fmul_rn(static_cast<float>(temper(w2) & 0xFFFFFFu), 1.0f / 16777216.0f);
+  const float radius = __builtin_sqrtf(__fmul_rn(-2.0f, log_ps(u1)));  // (correctly rounded: __fsqrt_rn is the NATIVE square root in this toolchain)
+  const float theta = __fmul_rn(6.283185307179586476925286766559f, u2);
+  float s, c;
+  sincos_ps(theta, s, c);
+  at_i = __builtin_fmaf(__fmul_rn(radius, c), 1.0f, 0.0f);  // fmadd(n, std = 1, mean = 0): n, except that -0 becomes +0
+  at_i8 = __builtin_fmaf(__fmul_rn(radius, s), 1.0f, 0.0f);
+}
+
+// `groups` complete groups of 16 raw words (LDS or global) -> normals at out[0 .. 16 groups)
+template <typename Words>
+__device__ __forceinline__ void emit_groups(Words words, int groups, float* __restrict__ out, int tid) {
+  for (int p = tid; p < groups * 8; p += kThreads) {
+    const int at = (p >> 3) * 16 + (p & 7);
+    float a, b;
+    normal_pair(words[at], words[at + 8], a, b);
+    out[at] = a;
+    out[at + 8] = b;
+  }
+}
+
+// Block 0: the rest of the state block the stream stood in.  Block u + 1: unit u — kPlanUnitBlocks twists from its snapshot.
+__global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out) {
+  __shared__ uint32_t s_state[2][kN];
+  const int tid = threadIdx.x;
+  const int64_t head = plan[1];
+  const int64_t total_blocks = static_cast<int64_t>(plan[2]) | (static_cast<int64_t>(plan[3]) << 32);
+  const int64_t n = static_cast<int64_t>(plan[6]) | (static_cast<int64_t>(plan[7]) << 32);
+  const int64_t n_full = n & ~static_cast<int64_t>(15);  // normal_fill transforms i < size - 15; the tail is the caller's copy
+  if (blockIdx.x == 0) {
+    emit_groups(plan + kPlanHeader, static_cast<int>(head / 16), out, tid);
+    return;
+  }
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) - 1;
+  const uint32_t* snapshot = plan + kPlanSnapshots + unit * kN;
+  for (int i = tid; i < kN; i += kThreads) s_state[0][i] = snapshot[i];
+  __syncthreads();
+  const int64_t b_end = min((unit + 1) * kPlanUnitBlocks, total_blocks);
+  int cur = 0;
+  for (int64_t b = unit * kPlanUnitBlocks; b < b_end; b++) {
+    const uint32_t* o = s_state[cur];
+    uint32_t* w = s_state[cur ^ 1];
+    // new[0 .. 227): old operands only
+    if (tid < kN - kM) w[tid] = twist_word(o[tid], o[tid + 1], o[tid + kM]);
+    __syncthreads();
+    // new[227 .. 454): the third operand is new[i - 227] of the first segment
+    if (tid < kN - kM) w[tid + (kN - kM)] = twist_word(o[tid + (kN - kM)], o[tid + (kN - kM) + 1], w[tid]);
+    __syncthreads();
+    // new[454 .. 623): third operand from the second segment; new[623] wraps to new[0]
+    if (tid < kN - 1 - 2 * (kN - kM)) w[tid + 2 * (kN - kM)] = twist_word(o[tid + 2 * (kN - kM)], o[tid + 2 * (kN - kM) + 1], w[tid + (kN - kM)]);
+    if (tid == kThreads - 1) w[kN - 1] = twist_word(o[kN - 1], w[0], w[kM - 1]);
+    __syncthreads();
+    const int64_t at = head + b * kN;                 // first output index of this block
+    const int64_t count = min(static_cast<int64_t>(kN), n - at);
+    const int whole = static_cast<int>((min(at + count, n_full) - at) / 16);
+    if (whole > 0) emit_groups(w, whole, out + at, tid);
+    cur ^= 1;  // (no barrier here: the next twist only READS the buffer these groups read, and writes the other one)
+  }
+}
+
+}  // namespace
+}  // namespace tio
+
+extern "C" int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream) {
+  using namespace tio;
+  if (plan_host == nullptr || plan_dev == nullptr || out_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_randn_device: null pointer");
+  if (plan_host[0] != kPlanMagic) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_randn_device: not a plan of tio_host_mt19937_plan");
+  const int64_t n_units = plan_host[4];
+  const int64_t n = static_cast<int64_t>(plan_host[6]) | (static_cast<int64_t>(plan_host[7]) << 32);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mt19937_randn_kernel, dim3(static_cast<unsigned>(n_units + 1)), dim3(kThreads), 0, s, plan_dev, out_dev);
+  if (plan_host[5] != 0u) {  // torch's tail rule: the last 16 values come from 16 fresh draws (made by the plan)
+    if (hipMemcpyAsync(out_dev + n - 16, plan_dev + kPlanTail, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return fail(TIO_ERR_LAUNCH, "tio_mt19937_randn_device: cannot place the tail draws");
+  }
+  return check_launch("tio_mt19937_randn_device");
+}

@@ -85,7 +85,8 @@ class Noise(IntensityTransform):
         engine = ops.engine()
         images = self._get_images(batch)
         # the reference-identical stream for device-resident images: the same draws as `torch.randn(..., generator=generator)`
-        # below, produced on all host cores (ops.HostNormalStream); one stream object = the one generator of this call
+        # below — made on the device from the host's plan of the state chain, or on all host cores (ops.HostNormalStream);
+        # one stream object = the one generator of this call
         stream = None
         if _NOISE_RNG == "reference" and images and os.environ.get("TIO_HOST_RNG", "1") != "0":
             tensors = [img._data if hasattr(img, "_data") else img.data for img in images.values()]  # (shape / device: pending stages keep both)
