@@ -74,6 +74,6 @@ def test_plan_refuses_what_it_cannot_express_and_leaves_the_state_alone(hip):
     plan = torch.empty(words, dtype=torch.int32)
     used = C.c_int64(0)
     status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 1 << 20, C.c_void_p(plan.data_ptr()), words, C.byref(used))
-    assert status == _abi.ERR_UNSUPPORTED_CONFIG and bytes(stream._state) == before
+    assert status == _abi.UNSUPPORTED_CONFIG and bytes(stream._state) == before
     status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 8, C.c_void_p(plan.data_ptr()), words, C.byref(used))
-    assert status == _abi.ERR_UNSUPPORTED_CONFIG and bytes(stream._state) == before
+    assert status == _abi.UNSUPPORTED_CONFIG and bytes(stream._state) == before

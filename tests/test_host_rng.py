@@ -70,3 +70,46 @@ def test_a_volume_sized_draw(functions):
     assert status == _abi.OK
     expected = torch.randn(n, generator=torch.Generator().manual_seed(seed))
     assert torch.equal(ours.view(torch.int32), expected.view(torch.int32))
+
+
+def _plan(functions, state, n):
+    words = int(functions["host_mt19937_plan_words"](n))
+    plan = torch.empty(max(words, 1), dtype=torch.int32)
+    used = C.c_int64(0)
+    status = functions["host_mt19937_plan"](C.addressof(state), n, C.c_void_p(plan.data_ptr()), words, C.byref(used))
+    return status, plan, used.value, words
+
+
+@pytest.mark.parametrize("n", [16, 624, 640, 16 * 39 * 128, 100_000, 1_000_003, 5_000_000])
+def test_plan_of_a_device_draw_advances_the_state_like_the_host_draw(functions, n):
+    """tio_host_mt19937_plan (the host half of the device-side stream, csrc/mt19937.hip): same state afterwards as
+    tio_host_mt19937_randn, a snapshot per 128 blocks, the tail draws final in the plan."""
+    drawn = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    planned = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    for state in (drawn, planned):
+        functions["host_mt19937_seed"](C.addressof(state), 77)
+    status, values = _draw(functions, drawn, n, 4)
+    assert status == _abi.OK
+    status, plan, used, words = _plan(functions, planned, n)
+    assert status == _abi.OK and used <= words
+    assert bytes(drawn) == bytes(planned)
+    blocks = -(-n // 624)  # (a fresh generator: no words left in the current block)
+    assert plan[0].item() == 0x4D54504C and plan[1].item() == 0 and plan[4].item() == -(-blocks // 128)
+    assert used == 656 + plan[4].item() * 624
+    if n % 16:
+        assert torch.equal(plan[640:656], values[-16:].view(torch.int32))
+    # the stream continues identically after either call
+    _, after_draw = _draw(functions, drawn, 4096, 1)
+    _, after_plan = _draw(functions, planned, 4096, 1)
+    assert torch.equal(after_draw.view(torch.int32), after_plan.view(torch.int32))
+
+
+def test_plan_refuses_a_stream_inside_a_group(functions):
+    state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    functions["host_mt19937_seed"](C.addressof(state), 5)
+    _draw(functions, state, 1000 * 16 + 5, 1)  # a tail: 16 extra draws, the stream now stands inside a group of 16
+    before = bytes(state)
+    status, _, _, _ = _plan(functions, state, 1 << 20)
+    assert status == _abi.UNSUPPORTED_CONFIG and bytes(state) == before
+    status, _, _, _ = _plan(functions, state, 8)
+    assert status == _abi.UNSUPPORTED_CONFIG and bytes(state) == before

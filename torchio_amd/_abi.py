@@ -13,7 +13,6 @@ MAX_IMAGES = 8
 
 # tio_status
 OK = 0
-ERR_UNSUPPORTED_CONFIG = -5  # valid arguments, but this form is not available for them (tio_status)
 UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing was launched
 
 # tio_dtype (values fixed by include/tio_hip.h)

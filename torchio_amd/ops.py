@@ -202,7 +202,7 @@ class HostNormalStream:
         plan_host = self._plan_staging(words)
         used = C.c_int64(0)
         status = self._fn["host_mt19937_plan"](C.addressof(self._state), count, C.c_void_p(plan_host.data_ptr()), words, C.byref(used))
-        if status == _abi.ERR_UNSUPPORTED_CONFIG:
+        if status == _abi.UNSUPPORTED_CONFIG:
             return None
         if status != _abi.OK:
             raise EngineError(f"tio_host_mt19937_plan failed with status {status}")
