@@ -77,13 +77,15 @@ __attribute__((target("avx2"))) void twist_avx2(uint32_t* s) {
   for (int i = 232; i < kN; i += 8) twist_step_avx2(s, i, s + i - (kN - kM));  // (i = 616 reads s[617 .. 624]: the mirror of new word 0)
 }
 
+// (the chain is what bounds the device-side stream — 215 k twists per 134 M draws on ONE core — so the step is written
+// for the fewest operations: a bit select and a three-way xor are one vpternlogd each, the conditional xor with the
+// matrix constant is a masked xor on the low bit of y)
 __attribute__((target("avx512f"))) inline void twist_step_avx512(uint32_t* s, int i, const uint32_t* third) {
-  const __m512i upper = _mm512_set1_epi32(static_cast<int>(0x80000000u)), lower = _mm512_set1_epi32(0x7fffffff);
-  const __m512i matrix = _mm512_set1_epi32(static_cast<int>(0x9908b0dfu)), one = _mm512_set1_epi32(1);
+  const __m512i lower = _mm512_set1_epi32(0x7fffffff), matrix = _mm512_set1_epi32(static_cast<int>(0x9908b0dfu)), one = _mm512_set1_epi32(1);
   const __m512i a = _mm512_loadu_si512(s + i), b = _mm512_loadu_si512(s + i + 1), c = _mm512_loadu_si512(third);
-  const __m512i y = _mm512_or_si512(_mm512_and_si512(a, upper), _mm512_and_si512(b, lower));
-  const __m512i mag = _mm512_and_si512(_mm512_sub_epi32(_mm512_setzero_si512(), _mm512_and_si512(y, one)), matrix);
-  _mm512_storeu_si512(s + i, _mm512_xor_si512(_mm512_xor_si512(c, _mm512_srli_epi32(y, 1)), mag));
+  const __m512i y = _mm512_ternarylogic_epi32(lower, b, a, 0xCA);  // lower ? b : a, bit by bit
+  const __m512i r = _mm512_xor_si512(c, _mm512_srli_epi32(y, 1));
+  _mm512_storeu_si512(s + i, _mm512_mask_xor_epi32(r, _mm512_test_epi32_mask(y, one), r, matrix));
 }
 
 __attribute__((target("avx512f"))) void twist_avx512(uint32_t* s) {
@@ -93,11 +95,47 @@ __attribute__((target("avx512f"))) void twist_avx512(uint32_t* s) {
   for (int i = 240; i < kN; i += 16) twist_step_avx512(s, i, s + i - (kN - kM));
 }
 
+// The same twist for a 64-byte aligned state, without a single split load: old[i + 1 ..] and the third operand (397 places
+// on = 384 + 13) are assembled from aligned vectors with valignd.  The third operands form ONE sliding sequence — old
+// words 384 .. 623, then the NEW words 0, 16, ... — so every step loads two aligned vectors (the next `a`, the next
+// third) and keeps the previous ones in registers.
+__attribute__((target("avx512f"))) void twist_avx512_aligned(uint32_t* s) {
+  const __m512i lower = _mm512_set1_epi32(0x7fffffff), matrix = _mm512_set1_epi32(static_cast<int>(0x9908b0dfu)), one = _mm512_set1_epi32(1);
+  __m512i a = _mm512_load_si512(s);            // old words i .. i + 15
+  __m512i c_lo = _mm512_load_si512(s + 384);   // third-operand window: its low vector
+  __m512i new0 = _mm512_setzero_si512();       // new words 0 .. 15 (stand in for "old" words 624 ..)
+  for (int i = 0; i < kN; i += 16) {
+    const __m512i a_next = i + 16 < kN ? _mm512_load_si512(s + i + 16) : new0;  // (i = 608: word 624 is new word 0)
+    __m512i c_hi;
+    if (i < 224) c_hi = _mm512_load_si512(s + i + 400);           // old words
+    else if (i == 224) c_hi = new0;                               // old 608 .. 623 | new 0 .. 15
+    else c_hi = _mm512_load_si512(s + i - 224);                   // new words (stored by an earlier step)
+    const __m512i b = _mm512_alignr_epi32(a_next, a, 1);
+    const __m512i c = _mm512_alignr_epi32(c_hi, c_lo, 13);
+    const __m512i y = _mm512_ternarylogic_epi32(lower, b, a, 0xCA);
+    const __m512i r = _mm512_xor_si512(c, _mm512_srli_epi32(y, 1));
+    const __m512i w = _mm512_mask_xor_epi32(r, _mm512_test_epi32_mask(y, one), r, matrix);
+    _mm512_store_si512(s + i, w);
+    if (i == 0) new0 = w;
+    a = a_next;
+    c_lo = c_hi;
+  }
+  _mm512_store_si512(s + kN, new0);  // (the mirror the unaligned forms rely on: kept consistent)
+}
+
 void twist(uint32_t* s) {
   static const int level = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") ? 1 : 0);
   if (level == 2) twist_avx512(s);
   else if (level == 1) twist_avx2(s);
   else twist_scalar(s);
+}
+
+struct alignas(64) AlignedState { uint32_t s[kN + 16]; };
+
+void twist_aligned(uint32_t* s) {  // s: 64-byte aligned, kN + 16 words
+  static const bool wide = __builtin_cpu_supports("avx512f");
+  if (wide) twist_avx512_aligned(s);
+  else twist(s);
 }
 
 inline uint32_t temper(uint32_t y) {
@@ -331,9 +369,14 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
   plan[6] = static_cast<uint32_t>(n); plan[7] = static_cast<uint32_t>(static_cast<uint64_t>(n) >> 32);
   memcpy(plan + kPlanHeader, st->s + st->pos, static_cast<size_t>(head) * sizeof(uint32_t));
   st->pos += static_cast<int32_t>(head);
-  for (int64_t b = 0; b < total_blocks; b++) {  // the chain: the only sequential part of the stream
-    if (b % kPlanUnitBlocks == 0) memcpy(plan + kPlanSnapshots + (b / kPlanUnitBlocks) * kN, st->s, kN * sizeof(uint32_t));
-    twist(st->s);
+  {  // the chain: the only sequential part of the stream (on an aligned copy of the state: no split vector loads)
+    AlignedState work;
+    memcpy(work.s, st->s, sizeof(work.s));
+    for (int64_t b = 0; b < total_blocks; b++) {
+      if (b % kPlanUnitBlocks == 0) memcpy(plan + kPlanSnapshots + (b / kPlanUnitBlocks) * kN, work.s, kN * sizeof(uint32_t));
+      twist_aligned(work.s);
+    }
+    memcpy(st->s, work.s, sizeof(work.s));
   }
   if (total_blocks > 0) st->pos = static_cast<int32_t>(body_words - (total_blocks - 1) * kN);
   if (n % 16 != 0) {  // normal_fill: "recompute the last 16 values" from 16 FRESH draws
@@ -369,9 +412,14 @@ extern "C" int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int6
     // kUnitBlocks blocks (2.5 KB each; everything stays in this core's cache — nothing of the output is touched here)
     const int64_t n_units = (total_blocks + kUnitBlocks - 1) / kUnitBlocks;
     std::vector<uint32_t> snapshots(static_cast<size_t>(n_units) * kN);
-    for (int64_t b = 0; b < total_blocks; b++) {
-      if (b % kUnitBlocks == 0) memcpy(&snapshots[static_cast<size_t>(b / kUnitBlocks) * kN], st->s, kN * sizeof(uint32_t));
-      twist(st->s);
+    {
+      AlignedState work;
+      memcpy(work.s, st->s, sizeof(work.s));
+      for (int64_t b = 0; b < total_blocks; b++) {
+        if (b % kUnitBlocks == 0) memcpy(&snapshots[static_cast<size_t>(b / kUnitBlocks) * kN], work.s, kN * sizeof(uint32_t));
+        twist_aligned(work.s);
+      }
+      memcpy(st->s, work.s, sizeof(work.s));
     }
     const int64_t tail_words = body_words - (total_blocks - 1) * kN;  // words of the last block that belong to this call (1 .. 624)
     st->pos = static_cast<int32_t>(tail_words);
