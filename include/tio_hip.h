@@ -489,16 +489,22 @@ int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int3
  * (tests/test_gpu_device_rng.py).  No 4-bytes-per-draw upload, no worker threads: 6.5 ms of one host core per 134 M draws.
  *
  *   words = tio_host_mt19937_plan_words(n);                 capacity (uint32 words) a plan of n draws can need
- *   tio_host_mt19937_plan(state, n, plan_host, words, &used);   advances `state` exactly like tio_host_mt19937_randn(state, ., n, .)
+ *   tio_host_mt19937_plan(state, n, plan_host, words, &used, n_threads);   advances `state` exactly like tio_host_mt19937_randn(state, ., n, .)
  *   copy plan_host[0 : used] to plan_dev (the caller's copy, on `stream`)
  *   tio_mt19937_randn_device(plan_host, plan_dev, out_dev, stream);
  *
  * tio_host_mt19937_plan returns TIO_ERR_UNSUPPORTED_CONFIG — and leaves the state untouched — when n < 16 or when the
  * stream stands inside a group of 16 (a previous draw count that was not a multiple of 16 AND did not end a block: torch's
  * groups then straddle state blocks); the caller falls back to tio_host_mt19937_randn.
+ * n_threads > 1 cuts long chains into segments: mt19937 is linear over GF(2), so a thread can JUMP to the start of its
+ * segment (g(f) applied to the state, g = x^J mod the characteristic polynomial — computed and verified at first use,
+ * csrc/host_rng_jump.cpp) and chain from there: 134 M draws are planned in ~1.5 ms on 8 threads instead of 5 - 6.5 ms on one.
+ * The snapshot at the start of a jumped segment may differ from the chained one in the 31 low bits of its first word —
+ * bits that are not part of the generator's state (the recurrence never reads them).
  */
 int64_t tio_host_mt19937_plan_words(int64_t n);
-int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int64_t* used_words);
+int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int64_t* used_words,
+                          int32_t n_threads);
 int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------ */

@@ -27,6 +27,7 @@ def _torch_stream(seed, counts):
         [1 << 20, 1 << 21, 1 << 20],      # one generator, three images (the second call starts inside a block)
         [1_200_000 + 7, 1 << 20],         # after a tail the stream stands inside a group: the second draw takes the host road
         [64 * 64 * 64, 1 << 22],          # a small draw first (host road), then a large one
+        [6_000_000 + 16, 12_000_000 + 5], # long chains: the host jumps ahead to the segments of its plan (host_rng_jump.cpp)
     ],
 )
 def test_device_draws_equal_torch_randn(hip, seed, counts):
@@ -73,7 +74,7 @@ def test_plan_refuses_what_it_cannot_express_and_leaves_the_state_alone(hip):
     words = int(stream._fn["host_mt19937_plan_words"](1 << 20))
     plan = torch.empty(words, dtype=torch.int32)
     used = C.c_int64(0)
-    status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 1 << 20, C.c_void_p(plan.data_ptr()), words, C.byref(used))
+    status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 1 << 20, C.c_void_p(plan.data_ptr()), words, C.byref(used), 1)
     assert status == _abi.UNSUPPORTED_CONFIG and bytes(stream._state) == before
-    status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 8, C.c_void_p(plan.data_ptr()), words, C.byref(used))
+    status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 8, C.c_void_p(plan.data_ptr()), words, C.byref(used), 1)
     assert status == _abi.UNSUPPORTED_CONFIG and bytes(stream._state) == before

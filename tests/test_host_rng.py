@@ -72,11 +72,11 @@ def test_a_volume_sized_draw(functions):
     assert torch.equal(ours.view(torch.int32), expected.view(torch.int32))
 
 
-def _plan(functions, state, n):
+def _plan(functions, state, n, threads=1):
     words = int(functions["host_mt19937_plan_words"](n))
     plan = torch.empty(max(words, 1), dtype=torch.int32)
     used = C.c_int64(0)
-    status = functions["host_mt19937_plan"](C.addressof(state), n, C.c_void_p(plan.data_ptr()), words, C.byref(used))
+    status = functions["host_mt19937_plan"](C.addressof(state), n, C.c_void_p(plan.data_ptr()), words, C.byref(used), threads)
     return status, plan, used.value, words
 
 
@@ -113,3 +113,29 @@ def test_plan_refuses_a_stream_inside_a_group(functions):
     assert status == _abi.UNSUPPORTED_CONFIG and bytes(state) == before
     status, _, _, _ = _plan(functions, state, 8)
     assert status == _abi.UNSUPPORTED_CONFIG and bytes(state) == before
+
+
+@pytest.mark.parametrize("n,threads", [(2 * 4096 * 624, 2), (6_000_000 + 7, 3), (20_000_000, 8), (20_000_000 + 624 * 3 + 48, 16)])
+def test_plan_with_jump_ahead_equals_the_serial_plan(functions, n, threads):
+    """Long chains are cut into segments whose starts are reached by jumping (csrc/host_rng_jump.cpp: g(f) applied to the
+    state, g = x^J mod the computed characteristic polynomial).  Same generator state afterwards, same plan — except the
+    31 low bits of the first word of a jumped segment's first snapshot, which are not part of mt19937's state — and the
+    stream continues identically."""
+    serial = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    jumped = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    for state in (serial, jumped):
+        functions["host_mt19937_seed"](C.addressof(state), 31337)
+        _draw(functions, state, 624 * 7 + 160, 1)  # (start inside a block, on a group boundary)
+    status, plan_serial, used_serial, _ = _plan(functions, serial, n, 1)
+    assert status == _abi.OK
+    status, plan_jumped, used_jumped, _ = _plan(functions, jumped, n, threads)
+    assert status == _abi.OK and used_serial == used_jumped
+    assert bytes(serial) == bytes(jumped)
+    different = (plan_serial[:used_serial] != plan_jumped[:used_jumped]).nonzero().flatten()
+    assert different.numel() < threads  # at most one word per jumped segment ...
+    assert all((int(i) - 656) % 624 == 0 and (int(i) - 656) // 624 % 32 == 0 for i in different)  # ... the first of a snapshot at a segment start
+    xor = plan_serial[different] ^ plan_jumped[different]
+    assert bool((xor >= 0).all())  # ... and never its top bit (int32: a set top bit would be negative)
+    _, after_serial = _draw(functions, serial, 10_000, 1)
+    _, after_jumped = _draw(functions, jumped, 10_000, 1)
+    assert torch.equal(after_serial.view(torch.int32), after_jumped.view(torch.int32))

@@ -140,7 +140,7 @@ HIP_ONLY_PROTOTYPES = {
     "host_mt19937_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "host_mt19937_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "host_mt19937_plan_words": (C.c_int64, [C.c_int64]),
-    "host_mt19937_plan": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "host_mt19937_plan": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int32]),
     "mt19937_randn_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "blur_fused": (
         C.c_int,

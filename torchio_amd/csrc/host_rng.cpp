@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/tio_hip.h"
+#include "host_rng_jump.hpp"
 
 namespace {
 
@@ -349,7 +350,8 @@ extern "C" int64_t tio_host_mt19937_plan_words(int64_t n) {
   return kPlanSnapshots + ((blocks + kPlanUnitBlocks - 1) / kPlanUnitBlocks) * kN;
 }
 
-extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan, int64_t capacity_words, int64_t* used_words) {
+extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan, int64_t capacity_words, int64_t* used_words,
+                                     int32_t n_threads) {
   MtState* st = reinterpret_cast<MtState*>(state);
   if (st == nullptr || plan == nullptr || used_words == nullptr || n < 0 || st->seeded != 1) return TIO_ERR_INVALID_ARGUMENT;
   if (n < 16) return TIO_ERR_UNSUPPORTED_CONFIG;
@@ -369,14 +371,40 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
   plan[6] = static_cast<uint32_t>(n); plan[7] = static_cast<uint32_t>(static_cast<uint64_t>(n) >> 32);
   memcpy(plan + kPlanHeader, st->s + st->pos, static_cast<size_t>(head) * sizeof(uint32_t));
   st->pos += static_cast<int32_t>(head);
-  {  // the chain: the only sequential part of the stream (on an aligned copy of the state: no split vector loads)
+  // The chain (on aligned copies of the state: no split vector loads).  Long chains are cut into segments of a power of
+  // two of blocks: thread t JUMPS to the start of segment t (host_rng_jump.cpp: ~0.3 ms whatever the distance) and chains
+  // from there; the last segment leaves the generator's new state.
+  constexpr int64_t kMinSegmentBlocks = 4096;  // 2.5 M draws: below, a jump costs more than the chain it saves
+  int64_t segment = total_blocks;
+  int n_segments = 1;
+  if (n_threads > 1 && total_blocks >= 2 * kMinSegmentBlocks && tio_host_rng::jump_available()) {
+    const int64_t wanted = std::max<int64_t>((total_blocks + n_threads - 1) / n_threads, kMinSegmentBlocks);
+    segment = kMinSegmentBlocks;
+    while (segment < wanted) segment *= 2;  // (few distinct lengths: their polynomials are cached)
+    n_segments = static_cast<int>((total_blocks + segment - 1) / segment);
+  }
+  const std::vector<std::vector<uint64_t>>* ahead = n_segments > 1 ? tio_host_rng::jump_polynomials(segment, n_segments - 1) : nullptr;
+  if (ahead == nullptr) { segment = total_blocks; n_segments = 1; }
+  auto chain = [&](int t) {
     AlignedState work;
-    memcpy(work.s, st->s, sizeof(work.s));
-    for (int64_t b = 0; b < total_blocks; b++) {
+    if (t == 0) memcpy(work.s, st->s, kN * sizeof(uint32_t));
+    else tio_host_rng::jump_state(st->s, (*ahead)[static_cast<size_t>(t) - 1], work.s);
+    memcpy(work.s + kN, work.s, 16 * sizeof(uint32_t));
+    const int64_t b_end = std::min<int64_t>((t + 1) * segment, total_blocks);
+    for (int64_t b = t * segment; b < b_end; b++) {
       if (b % kPlanUnitBlocks == 0) memcpy(plan + kPlanSnapshots + (b / kPlanUnitBlocks) * kN, work.s, kN * sizeof(uint32_t));
       twist_aligned(work.s);
     }
-    memcpy(st->s, work.s, sizeof(work.s));
+    return work;
+  };
+  if (total_blocks > 0) {
+    std::vector<std::thread> pool;
+    AlignedState last;
+    for (int t = 1; t < n_segments; t++)
+      pool.emplace_back([&, t] { const AlignedState done = chain(t); if (t == n_segments - 1) last = done; });
+    const AlignedState first = chain(0);
+    for (std::thread& th : pool) th.join();
+    memcpy(st->s, n_segments == 1 ? first.s : last.s, sizeof(first.s));  // (st->s is read by the jumps: written last)
   }
   if (total_blocks > 0) st->pos = static_cast<int32_t>(body_words - (total_blocks - 1) * kN);
   if (n % 16 != 0) {  // normal_fill: "recompute the last 16 values" from 16 FRESH draws

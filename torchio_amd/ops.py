@@ -201,7 +201,7 @@ class HostNormalStream:
         words = int(self._fn["host_mt19937_plan_words"](count))
         plan_host = self._plan_staging(words)
         used = C.c_int64(0)
-        status = self._fn["host_mt19937_plan"](C.addressof(self._state), count, C.c_void_p(plan_host.data_ptr()), words, C.byref(used))
+        status = self._fn["host_mt19937_plan"](C.addressof(self._state), count, C.c_void_p(plan_host.data_ptr()), words, C.byref(used), self.threads)
         if status == _abi.UNSUPPORTED_CONFIG:
             return None
         if status != _abi.OK:
