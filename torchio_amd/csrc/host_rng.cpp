@@ -21,7 +21,12 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -129,6 +134,62 @@ void twist(uint32_t* s) {
   if (level == 2) twist_avx512(s);
   else if (level == 1) twist_avx2(s);
   else twist_scalar(s);
+}
+
+// A few long-lived worker threads for the parallel parts (creating and joining 15 threads per call is ~0.3 ms of a 1.2-ms
+// plan).  One job at a time (callers are serialised by the mutex); a forked child (DataLoader workers) starts its own.
+class Workers {
+ public:
+  // runs job(t) for t = 0 .. count - 1: t = 0 on the calling thread, the rest on the pool; returns when all are done
+  void run(int count, const std::function<void(int)>& job) {
+    if (count <= 1) { if (count == 1) job(0); return; }
+    std::unique_lock<std::mutex> call(call_mutex_);
+    {
+      std::unique_lock<std::mutex> lock(mutex_);
+      if (owner_ != getpid()) { threads_.clear(); owner_ = getpid(); }  // (after a fork: no workers here; the old objects are leaked)
+      while (static_cast<int>(threads_.size()) < count - 1 && threads_.size() < 63) {
+        const int index = static_cast<int>(threads_.size());
+        threads_.emplace_back(new std::thread([this, index] { loop(index); }));
+      }
+      job_ = &job; count_ = count; pending_ = count - 1; generation_++;
+    }
+    wake_.notify_all();
+    job(0);
+    std::unique_lock<std::mutex> lock(mutex_);
+    done_.wait(lock, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(int index) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(mutex_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (index + 1 < count_) job = job_;
+      }
+      if (job != nullptr) {
+        (*job)(index + 1);
+        std::unique_lock<std::mutex> lock(mutex_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex call_mutex_, mutex_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread*> threads_;  // (never joined: they live as long as the process)
+  const std::function<void(int)>* job_ = nullptr;
+  int count_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+  pid_t owner_ = 0;
+};
+
+Workers& workers() {
+  static Workers* pool = new Workers();  // (leaked on purpose: its threads outlive static destruction)
+  return *pool;
 }
 
 struct alignas(64) AlignedState { uint32_t s[kN + 16]; };
@@ -398,12 +459,12 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
     return work;
   };
   if (total_blocks > 0) {
-    std::vector<std::thread> pool;
-    AlignedState last;
-    for (int t = 1; t < n_segments; t++)
-      pool.emplace_back([&, t] { const AlignedState done = chain(t); if (t == n_segments - 1) last = done; });
-    const AlignedState first = chain(0);
-    for (std::thread& th : pool) th.join();
+    AlignedState first, last;
+    workers().run(n_segments, [&](int t) {
+      const AlignedState done = chain(t);
+      if (t == 0) first = done;
+      if (t == n_segments - 1) last = done;
+    });
     memcpy(st->s, n_segments == 1 ? first.s : last.s, sizeof(first.s));  // (st->s is read by the jumps: written last)
   }
   if (total_blocks > 0) st->pos = static_cast<int32_t>(body_words - (total_blocks - 1) * kN);
@@ -470,12 +531,10 @@ extern "C" int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int6
         }
       }
     };
-    std::vector<std::thread> pool;
-    pool.reserve(threads - 1);
-    for (int t = 1; t < threads; t++) pool.emplace_back(run, t);
-    groups(words, head / 16);  // (the head's groups, while the others start)
-    run(0);
-    for (std::thread& t : pool) t.join();
+    workers().run(threads, [&](int t) {
+      if (t == 0) groups(words, head / 16);  // (the head's groups)
+      run(t);
+    });
   }
   if (n != n_full) {  // normal_fill: "recompute the last 16 values" from 16 FRESH draws
     uint32_t last[16];

@@ -200,6 +200,7 @@ const std::vector<std::vector<uint64_t>>* jump_polynomials(int64_t segment_block
 }
 
 // out[0 .. 624) = the window `g(f)` carries `in` to (Horner over word steps on a linear buffer)
+__attribute__((target_clones("avx512f", "avx2", "default")))  // (the 624-word xor is the whole cost: as wide as the host allows)
 void jump_state(const uint32_t* in, const std::vector<uint64_t>& g, uint32_t* out) {
   const int deg = degree(g);
   std::vector<uint32_t> line(static_cast<size_t>(kN) + (deg > 0 ? deg : 0) + 16, 0u);
