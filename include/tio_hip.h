@@ -506,6 +506,12 @@ int64_t tio_host_mt19937_plan_words(int64_t n);
 int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int64_t* used_words,
                           int32_t n_threads);
 int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream);
+/* Noise.apply_transform for a float32 image in one kernel: out = x + (mean + std z) with z the plan's draws (the three
+ * float32 roundings of noise.py:178, :119, as tio_add_noise) — the draws never exist in memory.  x / out: the image's
+ * B * n_per_element values (the plan's n); mean_dev / std_dev: (B,) per-element parameters or NULL (then the scalars). */
+int tio_mt19937_add_noise_device(const uint32_t* plan_host, const uint32_t* plan_dev, const float* x_dev, float* out_dev,
+                                 int64_t n_per_element, float mean, float std, const float* mean_dev, const float* std_dev,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Introspection                                                             */

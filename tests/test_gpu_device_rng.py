@@ -78,3 +78,61 @@ def test_plan_refuses_what_it_cannot_express_and_leaves_the_state_alone(hip):
     assert status == _abi.UNSUPPORTED_CONFIG and bytes(stream._state) == before
     status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), 8, C.c_void_p(plan.data_ptr()), words, C.byref(used), 1)
     assert status == _abi.UNSUPPORTED_CONFIG and bytes(stream._state) == before
+
+
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("shape", [(2, 1, 96, 96, 96), (3, 2, 64, 80, 70 + 1)])
+def test_draw_and_sum_in_one_kernel_equals_the_two_steps(hip, monkeypatch, batched, shape):
+    """tio_mt19937_add_noise_device == torch.randn on the host + tio_add_noise, bit for bit, and the same stream afterwards."""
+    from torchio_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    data = torch.rand(*shape, generator=g, device="cuda") * 100 - 20
+    mean = torch.tensor([0.5, -1.25, 3.0][: shape[0]], device="cuda") if batched else 0.75
+    std = torch.tensor([0.1, 2.0, 0.5][: shape[0]], device="cuda") if batched else 1.5
+    stream = ops.HostNormalStream(2024)
+    fused = stream.add_noise(data, mean, std)
+    assert fused is not None
+    follow_up = stream.randn((1 << 20,), "cuda").cpu()
+    generator = torch.Generator().manual_seed(2024)
+    base = torch.randn(shape, generator=generator)
+    expected = hip.add_noise(data, mean, std, rician=False, base1=base.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(expected.view(torch.int32), fused.view(torch.int32))
+    assert torch.equal(torch.randn(1 << 20, generator=generator).view(torch.int32), follow_up.view(torch.int32))
+
+
+def test_noise_transform_in_reference_mode_uses_the_fused_kernel_and_matches_torch(hip, monkeypatch):
+    """`tio.Noise` on device-resident float32 images, reference RNG mode: identical to the reference's arithmetic
+    `data + (mean + std * torch.randn(shape, generator=cpu(seed)))`, image after image from one generator."""
+    import torchio_amd as tio
+    from torchio_amd import ops
+
+    calls = []
+    original = ops.HostNormalStream.add_noise
+    monkeypatch.setattr(ops.HostNormalStream, "add_noise", lambda self, *a: calls.append(1) or original(self, *a))
+    previous = tio.get_noise_rng()
+    tio.set_noise_rng("reference")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        t1 = torch.rand(2, 1, 96, 96, 128, generator=g, device="cuda")
+        t2 = torch.rand(2, 1, 96, 96, 128, generator=g, device="cuda") + 5
+        batch = tio.SubjectsBatch({
+            "t1": tio.ImagesBatch(t1, [tio.AffineMatrix(), tio.AffineMatrix()], image_class=tio.ScalarImage),
+            "t2": tio.ImagesBatch(t2, [tio.AffineMatrix(), tio.AffineMatrix()], image_class=tio.ScalarImage),
+        })
+        transform = tio.Noise(mean=0.25, std=(0.5, 0.5))
+        torch.manual_seed(11)
+        out = transform(batch)
+        params = out.applied_transforms[-1].params if hasattr(out, "applied_transforms") else None
+    finally:
+        tio.set_noise_rng(previous)
+    assert len(calls) == 2
+    torch.manual_seed(11)
+    torch.rand(1)  # the p-gate draw of the envelope
+    seed = int(torch.randint(0, 2**31, (1,)).item())
+    generator = torch.Generator().manual_seed(seed)
+    for name, source in (("t1", t1), ("t2", t2)):
+        base = torch.randn(source.shape, generator=generator).cuda()
+        expected = source + (0.25 + 0.5 * base)
+        assert torch.equal(expected, out.images[name].data), name

@@ -115,20 +115,45 @@ __device__ __forceinline__ void normal_pair(uint32_t w1, uint32_t w2, float& at_
   at_i8 = __builtin_fmaf(__fmul_rn(radius, s), 1.0f, 0.0f);
 }
 
-// `groups` complete groups of 16 raw words (LDS or global) -> normals at out[0 .. 16 groups)
-template <typename Words>
-__device__ __forceinline__ void emit_groups(Words words, int groups, float* __restrict__ out, int tid) {
+// What the draws are added to when the kernel is Noise itself (tio_mt19937_add_noise_device): out = x + (mean + std z), the
+// three roundings of tio_add_noise / noise.py:178, :119; mean and std per batch element of n_per_element values, or scalars
+struct NoiseTarget {
+  const float* x;
+  const float* mean_b;
+  const float* std_b;
+  float mean, std;
+  int64_t n_per_element;
+};
+
+__device__ __forceinline__ float noisy(const NoiseTarget& t, int64_t index, float z) {
+  float mu = t.mean, sd = t.std;
+  if (t.mean_b != nullptr || t.std_b != nullptr) {
+    const int64_t b = index / t.n_per_element;
+    if (t.mean_b != nullptr) mu = t.mean_b[b];
+    if (t.std_b != nullptr) sd = t.std_b[b];
+  }
+  return __fadd_rn(t.x[index], __fadd_rn(mu, __fmul_rn(sd, z)));
+}
+
+// `groups` complete groups of 16 raw words (LDS or global) -> normals at out[first .. first + 16 groups)
+template <bool ADD, typename Words>
+__device__ __forceinline__ void emit_groups(Words words, int groups, float* __restrict__ out, int64_t first, const NoiseTarget& target, int tid) {
   for (int p = tid; p < groups * 8; p += kThreads) {
     const int at = (p >> 3) * 16 + (p & 7);
     float a, b;
     normal_pair(words[at], words[at + 8], a, b);
-    out[at] = a;
-    out[at + 8] = b;
+    if constexpr (ADD) {
+      a = noisy(target, first + at, a);
+      b = noisy(target, first + at + 8, b);
+    }
+    out[first + at] = a;
+    out[first + at + 8] = b;
   }
 }
 
 // Block 0: the rest of the state block the stream stood in.  Block u + 1: unit u — kPlanUnitBlocks twists from its snapshot.
-__global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out) {
+template <bool ADD>
+__global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out, const NoiseTarget target) {
   __shared__ uint32_t s_state[2][kN];
   const int tid = threadIdx.x;
   const int64_t head = plan[1];
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
   const int64_t n = static_cast<int64_t>(plan[6]) | (static_cast<int64_t>(plan[7]) << 32);
   const int64_t n_full = n & ~static_cast<int64_t>(15);  // normal_fill transforms i < size - 15; the tail is the caller's copy
   if (blockIdx.x == 0) {
-    emit_groups(plan + kPlanHeader, static_cast<int>(head / 16), out, tid);
+    emit_groups<ADD>(plan + kPlanHeader, static_cast<int>(head / 16), out, 0, target, tid);
     return;
   }
   const int64_t unit = static_cast<int64_t>(blockIdx.x) - 1;
@@ -161,13 +186,36 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
     const int64_t at = head + b * kN;                 // first output index of this block
     const int64_t count = min(static_cast<int64_t>(kN), n - at);
     const int whole = static_cast<int>((min(at + count, n_full) - at) / 16);
-    if (whole > 0) emit_groups(w, whole, out + at, tid);
+    if (whole > 0) emit_groups<ADD>(w, whole, out, at, target, tid);
     cur ^= 1;  // (no barrier here: the next twist only READS the buffer these groups read, and writes the other one)
   }
 }
 
+// torch's tail rule under ADD: the last 16 values of the stream (made by the plan) through the same sum
+__global__ __launch_bounds__(64) void mt19937_tail_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out, const NoiseTarget target, int64_t n) {
+  const int t = threadIdx.x;
+  if (t < 16) out[n - 16 + t] = noisy(target, n - 16 + t, __uint_as_float(plan[kPlanTail + t]));
+}
+
 }  // namespace
 }  // namespace tio
+
+extern "C" int tio_mt19937_add_noise_device(const uint32_t* plan_host, const uint32_t* plan_dev, const float* x_dev, float* out_dev,
+                                            int64_t n_per_element, float mean, float std, const float* mean_dev, const float* std_dev,
+                                            void* stream) {
+  using namespace tio;
+  if (plan_host == nullptr || plan_dev == nullptr || x_dev == nullptr || out_dev == nullptr || n_per_element < 1)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_add_noise_device: bad argument");
+  if (plan_host[0] != kPlanMagic) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_add_noise_device: not a plan of tio_host_mt19937_plan");
+  const int64_t n_units = plan_host[4];
+  const int64_t n = static_cast<int64_t>(plan_host[6]) | (static_cast<int64_t>(plan_host[7]) << 32);
+  if (n % n_per_element != 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_add_noise_device: the plan's %lld draws are not whole elements of %lld", static_cast<long long>(n), static_cast<long long>(n_per_element));
+  const NoiseTarget target{x_dev, mean_dev, std_dev, mean, std, n_per_element};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mt19937_randn_kernel<true>, dim3(static_cast<unsigned>(n_units + 1)), dim3(kThreads), 0, s, plan_dev, out_dev, target);
+  if (plan_host[5] != 0u) hipLaunchKernelGGL(mt19937_tail_kernel, dim3(1), dim3(64), 0, s, plan_dev, out_dev, target, n);
+  return check_launch("tio_mt19937_add_noise_device");
+}
 
 extern "C" int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream) {
   using namespace tio;
@@ -176,7 +224,7 @@ extern "C" int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_
   const int64_t n_units = plan_host[4];
   const int64_t n = static_cast<int64_t>(plan_host[6]) | (static_cast<int64_t>(plan_host[7]) << 32);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(mt19937_randn_kernel, dim3(static_cast<unsigned>(n_units + 1)), dim3(kThreads), 0, s, plan_dev, out_dev);
+  hipLaunchKernelGGL(mt19937_randn_kernel<false>, dim3(static_cast<unsigned>(n_units + 1)), dim3(kThreads), 0, s, plan_dev, out_dev, NoiseTarget{});
   if (plan_host[5] != 0u) {  // torch's tail rule: the last 16 values come from 16 fresh draws (made by the plan)
     if (hipMemcpyAsync(out_dev + n - 16, plan_dev + kPlanTail, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
       return fail(TIO_ERR_LAUNCH, "tio_mt19937_randn_device: cannot place the tail draws");

@@ -194,10 +194,10 @@ class HostNormalStream:
             HostNormalStream._uploaded[id(host)].record()  # the staging buffer is free again once this copy has completed
         return out.view(tuple(int(extent) for extent in shape))
 
-    def _randn_on_device(self, count: int, device) -> Tensor | None:
-        """The draws made on the device from a plan of the host's state chain (``tio_host_mt19937_plan`` +
-        ``tio_mt19937_randn_device``): one host core runs the twists (6.5 ms per 134 M draws), 2.5 KB of state per 79 872
-        draws go up instead of 4 bytes per draw.  ``None`` when the stream stands inside a group of 16 (the host road)."""
+    def _device_plan(self, count: int, device):
+        """The plan of ``count`` draws (``tio_host_mt19937_plan``: the host runs the mt19937 state chain — in parallel, by
+        jump-ahead — and keeps a snapshot every 128 blocks), uploaded: 2.5 KB of state per 79 872 draws instead of 4 bytes
+        per draw.  ``None`` when the stream stands inside a group of 16 (the host road takes over; the state is untouched)."""
         words = int(self._fn["host_mt19937_plan_words"](count))
         plan_host = self._plan_staging(words)
         used = C.c_int64(0)
@@ -206,17 +206,54 @@ class HostNormalStream:
             return None
         if status != _abi.OK:
             raise EngineError(f"tio_host_mt19937_plan failed with status {status}")
+        plan_dev = torch.empty(used.value, dtype=torch.int32, device=device)
+        plan_dev.copy_(plan_host[: used.value], non_blocking=True)
+        HostNormalStream._uploaded[id(plan_host)].record()
+        return plan_host, plan_dev
+
+    def _randn_on_device(self, count: int, device) -> Tensor | None:
+        """The draws made on the device (``tio_mt19937_randn_device``) from the host's plan of the state chain."""
         with torch.cuda.device(device):
-            plan_dev = torch.empty(used.value, dtype=torch.int32, device=device)
-            plan_dev.copy_(plan_host[: used.value], non_blocking=True)
-            HostNormalStream._uploaded[id(plan_host)].record()
+            plan = self._device_plan(count, device)
+            if plan is None:
+                return None
             out = torch.empty(count, dtype=torch.float32, device=device)
             raw_stream = torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
             status = self._fn["mt19937_randn_device"](
-                C.c_void_p(plan_host.data_ptr()), C.c_void_p(plan_dev.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(raw_stream)
+                C.c_void_p(plan[0].data_ptr()), C.c_void_p(plan[1].data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(raw_stream)
             )
         if status != _abi.OK:
             raise EngineError(f"tio_mt19937_randn_device failed with status {status}")
+        return out
+
+    def add_noise(self, data: Tensor, mean, std) -> Tensor | None:
+        """``data + (mean + std * randn(data.shape))`` in ONE kernel (``tio_mt19937_add_noise_device``): the draws of this stream
+        never exist in memory.  *data*: a dense float32 ``(B, ...)`` device tensor; *mean* / *std*: numbers or ``(B,)`` float32
+        device tensors.  ``None`` (nothing drawn) when this form does not apply: the caller draws with :meth:`randn`."""
+        count = data.numel()
+        if (
+            not data.is_cuda or data.dtype != torch.float32 or not data.is_contiguous() or count < self.DEVICE_DRAW_MIN
+            or data.shape[0] < 1 or os.environ.get("TIO_DEVICE_RNG", "1") == "0" or os.environ.get("TIO_FUSED_REFERENCE_NOISE", "1") == "0"
+        ):
+            return None
+        per_element = count // data.shape[0]
+        device = data.device
+        with torch.cuda.device(device):
+            plan = self._device_plan(count, device)
+            if plan is None:
+                return None
+            out = torch.empty_like(data)
+            mean_dev = mean if isinstance(mean, Tensor) else None
+            std_dev = std if isinstance(std, Tensor) else None
+            raw_stream = torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+            status = self._fn["mt19937_add_noise_device"](
+                C.c_void_p(plan[0].data_ptr()), C.c_void_p(plan[1].data_ptr()), C.c_void_p(data.data_ptr()), C.c_void_p(out.data_ptr()), per_element,
+                0.0 if mean_dev is not None else float(mean), 0.0 if std_dev is not None else float(std),
+                C.c_void_p(mean_dev.data_ptr()) if mean_dev is not None else None, C.c_void_p(std_dev.data_ptr()) if std_dev is not None else None,
+                C.c_void_p(raw_stream),
+            )
+        if status != _abi.OK:
+            raise EngineError(f"tio_mt19937_add_noise_device failed with status {status}")
         return out
 
     @classmethod

@@ -112,6 +112,11 @@ class Noise(IntensityTransform):
             std_arg = ops.h2d(torch.tensor(std, dtype=torch.float32), device) if isinstance(std, list) else std
             keep_arg = None if keep is None else ops.h2d(torch.tensor(keep, dtype=torch.uint8), device)
             if _NOISE_RNG == "reference":
+                if stream is not None and not rician and keep_arg is None and work is data:
+                    fused = stream.add_noise(work, mean_arg, std_arg)  # draws and sum in one kernel (large float32 images)
+                    if fused is not None:
+                        img_batch.data = fused
+                        continue
                 if stream is not None:
                     base1 = stream.randn(data.shape, device)
                     base2 = stream.randn(data.shape, device) if rician else None
