@@ -136,3 +136,31 @@ def test_noise_transform_in_reference_mode_uses_the_fused_kernel_and_matches_tor
         base = torch.randn(source.shape, generator=generator).cuda()
         expected = source + (0.25 + 0.5 * base)
         assert torch.equal(expected, out.images[name].data), name
+
+
+def test_concurrent_streams_do_not_share_staging_buffers(hip):
+    """`Queue`'s worker threads each run a Noise: the pinned buffers a draw is staged in are per thread (a shared ring once
+    handed two threads the same buffer — one's raw state words went up as the other's draws)."""
+    import threading
+
+    from torchio_amd import ops
+
+    counts = [40_000, 300_000, 40_000, 2_000_000]  # host road and device road
+    results: dict = {}
+
+    def worker(seed):
+        drawn = []
+        for repeat in range(6):
+            stream = ops.HostNormalStream(seed + repeat)
+            drawn.append([stream.randn((count,), "cuda").cpu() for count in counts])
+        results[seed] = drawn
+
+    threads = [threading.Thread(target=worker, args=(seed,)) for seed in (100, 200, 300, 400)]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join()
+    for seed, drawn in results.items():
+        for repeat, tensors in enumerate(drawn):
+            for expected, got in zip(_torch_stream(seed + repeat, counts), tensors):
+                assert torch.equal(expected.view(torch.int32), got.view(torch.int32)), (seed, repeat)

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from collections.abc import Sequence
 
 import torch
@@ -191,7 +192,7 @@ class HostNormalStream:
             if stop == count:
                 break
         if on_gpu:
-            HostNormalStream._uploaded[id(host)].record()  # the staging buffer is free again once this copy has completed
+            HostNormalStream._rings().uploaded[id(host)].record()  # the staging buffer is free again once this copy has completed
         return out.view(tuple(int(extent) for extent in shape))
 
     def _device_plan(self, count: int, device):
@@ -208,7 +209,7 @@ class HostNormalStream:
             raise EngineError(f"tio_host_mt19937_plan failed with status {status}")
         plan_dev = torch.empty(used.value, dtype=torch.int32, device=device)
         plan_dev.copy_(plan_host[: used.value], non_blocking=True)
-        HostNormalStream._uploaded[id(plan_host)].record()
+        HostNormalStream._rings().uploaded[id(plan_host)].record()
         return plan_host, plan_dev
 
     def _randn_on_device(self, count: int, device) -> Tensor | None:
@@ -256,45 +257,46 @@ class HostNormalStream:
             raise EngineError(f"tio_mt19937_add_noise_device failed with status {status}")
         return out
 
+    # Pinned host buffers (allocating 512 MiB of pinned memory costs ~0.2 s): kept PER THREAD — a buffer is written by the
+    # host and read by an asynchronous upload, and `Queue`'s workers draw concurrently (a ring shared between threads handed
+    # two of them the same buffer: one's raw state words went up as the other's "draws") — and per size, a few per size
+    # used in turn, each guarded by the event of its last upload.
+    _thread_state = threading.local()
+
     @classmethod
-    def _plan_staging(cls, words: int) -> Tensor:
-        """Pinned host buffers for plans (a ring of three per size: a plan is read by the asynchronous upload)."""
-        ring = cls._plans.setdefault(words, [])
+    def _rings(cls):
+        state = cls._thread_state
+        if not hasattr(state, "uploaded"):
+            state.uploaded, state.plans, state.buffers = {}, {}, {}
+        return state
+
+    @classmethod
+    def _ring_buffer(cls, rings: dict, uploaded: dict, size: int, dtype, length: int) -> Tensor:
+        ring = rings.setdefault(size, [])
+        if len(rings) > 4:  # (a few distinct sizes at most: drop the rest)
+            for key in [k for k in rings if k != size]:
+                for tensor in rings.pop(key):
+                    uploaded.pop(id(tensor), None)
         for tensor in ring:
-            if cls._uploaded[id(tensor)].query():
+            if uploaded[id(tensor)].query():
                 return tensor
-        if len(ring) < 3:
-            tensor = torch.empty(words, dtype=torch.int32, pin_memory=True)
+        if len(ring) < length:
+            tensor = torch.empty(size, dtype=dtype, pin_memory=True)
             ring.append(tensor)
-            cls._uploaded[id(tensor)] = torch.cuda.Event()
+            uploaded[id(tensor)] = torch.cuda.Event()
             return tensor
-        cls._uploaded[id(ring[0])].synchronize()
+        uploaded[id(ring[0])].synchronize()
         return ring[0]
 
-    _plans: dict = {}
-
-    # Pinned staging buffers, kept per size (allocating 512 MiB of pinned memory costs ~0.2 s): two per size, used in turn,
-    # each guarded by the event of its last upload
-    _buffers: dict = {}
-    _uploaded: dict = {}
+    @classmethod
+    def _plan_staging(cls, words: int) -> Tensor:
+        state = cls._rings()
+        return cls._ring_buffer(state.plans, state.uploaded, words, torch.int32, 3)
 
     @classmethod
     def _staging(cls, count: int) -> Tensor:
-        ring = cls._buffers.setdefault(count, [])
-        if len(cls._buffers) > 4:  # (a few distinct volume sizes at most: drop the rest)
-            for key in [k for k in cls._buffers if k != count]:
-                for tensor in cls._buffers.pop(key):
-                    cls._uploaded.pop(id(tensor), None)
-        for tensor in ring:
-            if cls._uploaded[id(tensor)].query():
-                return tensor
-        if len(ring) < 2:
-            tensor = torch.empty(count, dtype=torch.float32, pin_memory=True)
-            ring.append(tensor)
-            cls._uploaded[id(tensor)] = torch.cuda.Event()
-            return tensor
-        cls._uploaded[id(ring[0])].synchronize()
-        return ring[0]
+        state = cls._rings()
+        return cls._ring_buffer(state.buffers, state.uploaded, count, torch.float32, 2)
 
 
 class EngineError(RuntimeError):
