@@ -25,7 +25,7 @@ constexpr int kN = 624, kM = 397;
 constexpr int64_t kPlanUnitBlocks = 128;
 constexpr int64_t kPlanHeader = 16, kPlanTail = kPlanHeader + kN, kPlanSnapshots = kPlanTail + 16;
 constexpr uint32_t kPlanMagic = 0x4D54504Cu;
-constexpr int kThreads = 256;
+constexpr int kThreads = 320;  // 312 pairs per state block: five waves, 97.5 % of the lanes busy in the transform
 
 __device__ __forceinline__ uint32_t twist_word(uint32_t a, uint32_t b, uint32_t c) {
   const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
@@ -125,26 +125,45 @@ struct NoiseTarget {
   int64_t n_per_element;
 };
 
-__device__ __forceinline__ float noisy(const NoiseTarget& t, int64_t index, float z) {
-  float mu = t.mean, sd = t.std;
+// mean / std of the (at most two: n_per_element >= 624 is the host's condition) batch elements a run of <= 624 values
+// starting at `first` falls in: one division per run, not per value
+struct NoiseRun {
+  float mean[2], std[2];
+  int64_t boundary;  // first index of the second element
+};
+
+__device__ __forceinline__ NoiseRun noise_run(const NoiseTarget& t, int64_t first, int64_t n) {
+  NoiseRun r;
+  r.mean[0] = r.mean[1] = t.mean; r.std[0] = r.std[1] = t.std;
+  r.boundary = INT64_MAX;
   if (t.mean_b != nullptr || t.std_b != nullptr) {
-    const int64_t b = index / t.n_per_element;
-    if (t.mean_b != nullptr) mu = t.mean_b[b];
-    if (t.std_b != nullptr) sd = t.std_b[b];
+    const int64_t b = first / t.n_per_element;
+    const int64_t b1 = min(b + 1, (n - 1) / t.n_per_element);
+    r.boundary = (b + 1) * t.n_per_element;
+    if (t.mean_b != nullptr) { r.mean[0] = t.mean_b[b]; r.mean[1] = t.mean_b[b1]; }
+    if (t.std_b != nullptr) { r.std[0] = t.std_b[b]; r.std[1] = t.std_b[b1]; }
   }
-  return __fadd_rn(t.x[index], __fadd_rn(mu, __fmul_rn(sd, z)));
+  return r;
+}
+
+__device__ __forceinline__ float noisy(const NoiseTarget& t, const NoiseRun& r, int64_t index, float z) {
+  const bool second = index >= r.boundary;
+  return __fadd_rn(t.x[index], __fadd_rn(second ? r.mean[1] : r.mean[0], __fmul_rn(second ? r.std[1] : r.std[0], z)));
 }
 
 // `groups` complete groups of 16 raw words (LDS or global) -> normals at out[first .. first + 16 groups)
 template <bool ADD, typename Words>
-__device__ __forceinline__ void emit_groups(Words words, int groups, float* __restrict__ out, int64_t first, const NoiseTarget& target, int tid) {
+__device__ __forceinline__ void emit_groups(Words words, int groups, float* __restrict__ out, int64_t first, const NoiseTarget& target, int64_t n,
+                                            int tid) {
+  NoiseRun run;
+  if constexpr (ADD) run = noise_run(target, first, n);
   for (int p = tid; p < groups * 8; p += kThreads) {
     const int at = (p >> 3) * 16 + (p & 7);
     float a, b;
     normal_pair(words[at], words[at + 8], a, b);
     if constexpr (ADD) {
-      a = noisy(target, first + at, a);
-      b = noisy(target, first + at + 8, b);
+      a = noisy(target, run, first + at, a);
+      b = noisy(target, run, first + at + 8, b);
     }
     out[first + at] = a;
     out[first + at + 8] = b;
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
   const int64_t n = static_cast<int64_t>(plan[6]) | (static_cast<int64_t>(plan[7]) << 32);
   const int64_t n_full = n & ~static_cast<int64_t>(15);  // normal_fill transforms i < size - 15; the tail is the caller's copy
   if (blockIdx.x == 0) {
-    emit_groups<ADD>(plan + kPlanHeader, static_cast<int>(head / 16), out, 0, target, tid);
+    emit_groups<ADD>(plan + kPlanHeader, static_cast<int>(head / 16), out, 0, target, n, tid);
     return;
   }
   const int64_t unit = static_cast<int64_t>(blockIdx.x) - 1;
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
     const int64_t at = head + b * kN;                 // first output index of this block
     const int64_t count = min(static_cast<int64_t>(kN), n - at);
     const int whole = static_cast<int>((min(at + count, n_full) - at) / 16);
-    if (whole > 0) emit_groups<ADD>(w, whole, out, at, target, tid);
+    if (whole > 0) emit_groups<ADD>(w, whole, out, at, target, n, tid);
     cur ^= 1;  // (no barrier here: the next twist only READS the buffer these groups read, and writes the other one)
   }
 }
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
 // torch's tail rule under ADD: the last 16 values of the stream (made by the plan) through the same sum
 __global__ __launch_bounds__(64) void mt19937_tail_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out, const NoiseTarget target, int64_t n) {
   const int t = threadIdx.x;
-  if (t < 16) out[n - 16 + t] = noisy(target, n - 16 + t, __uint_as_float(plan[kPlanTail + t]));
+  if (t < 16) out[n - 16 + t] = noisy(target, noise_run(target, n - 16, n), n - 16 + t, __uint_as_float(plan[kPlanTail + t]));
 }
 
 }  // namespace
@@ -209,6 +228,8 @@ extern "C" int tio_mt19937_add_noise_device(const uint32_t* plan_host, const uin
   if (plan_host[0] != kPlanMagic) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_add_noise_device: not a plan of tio_host_mt19937_plan");
   const int64_t n_units = plan_host[4];
   const int64_t n = static_cast<int64_t>(plan_host[6]) | (static_cast<int64_t>(plan_host[7]) << 32);
+  if ((mean_dev != nullptr || std_dev != nullptr) && n_per_element < kN)
+    return fail(TIO_ERR_UNSUPPORTED_CONFIG, "tio_mt19937_add_noise_device: per-element parameters need elements of at least 624 values");
   if (n % n_per_element != 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_add_noise_device: the plan's %lld draws are not whole elements of %lld", static_cast<long long>(n), static_cast<long long>(n_per_element));
   const NoiseTarget target{x_dev, mean_dev, std_dev, mean, std, n_per_element};
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -729,16 +729,14 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       bool present = false;
       for (int i = 0; i < nn.n_images; i++) present = present || nn.img[i].es == es;
       if (!present) continue;
+#define TIO_NN_LAUNCH_SHAPE(ES, TJ, TK)                                                                                 \
+  if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES, TJ, TK, 16>), grid, block, 0, s, nn);     \
+  else hipLaunchKernelGGL((resample_nearest_kernel<false, ES, TJ, TK, 16>), grid, block, 0, s, nn);
 #define TIO_NN_LAUNCH(ES)                                                                                               \
-  if (nn_rows) {                                                                                                        \
-    if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES, 4, 64>), grid, block, 0, s, nn);        \
-    else hipLaunchKernelGGL((resample_nearest_kernel<false, ES, 4, 64>), grid, block, 0, s, nn);                        \
-  } else {                                                                                                              \
-    if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES, 16, 16>), grid, block, 0, s, nn);       \
-    else hipLaunchKernelGGL((resample_nearest_kernel<false, ES, 16, 16>), grid, block, 0, s, nn);                       \
-  }
+  if (nn_rows) { TIO_NN_LAUNCH_SHAPE(ES, 4, 64) } else { TIO_NN_LAUNCH_SHAPE(ES, 16, 16) }
       if (es == 1) { TIO_NN_LAUNCH(1) } else if (es == 2) { TIO_NN_LAUNCH(2) } else if (es == 4) { TIO_NN_LAUNCH(4) } else { TIO_NN_LAUNCH(8) }
 #undef TIO_NN_LAUNCH
+#undef TIO_NN_LAUNCH_SHAPE
     }
     if (a.n_images == 0 && pv.n_images == 0 && spl.n_images == 0) return check_launch("tio_resample3d");
   }

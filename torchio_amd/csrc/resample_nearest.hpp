@@ -119,11 +119,13 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
 // One block per 16 x TJ x TK brick of the output (TJ * TK = 256), one column of 16 planes per thread: 16 x 4 x 64 — a wave
 // is one output row of 64 voxels: its loads touch one or two cache lines and its stores are contiguous — or 16 x 16 x 16
 // for volumes narrower than that.  The host only launches it for I * J <= 2^24 and K <= 2^24 (24-bit multiply-adds).
-template <bool ELASTIC_POSSIBLE, int ES, int TJ, int TK>
+template <bool ELASTIC_POSSIBLE, int ES, int TJ, int TK, int TI>
 __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs a) {
   typedef typename NearestBits<ES>::type bits_t;
-  static_assert(TJ * TK == 256 && (TK & (TK - 1)) == 0, "one thread per column of the brick");
-  constexpr int TI = 16, G = 4;
+  static_assert(TJ * TK == 256 && (TK & (TK - 1)) == 0 && (TI == 16 || TI == 32), "one thread per column of the brick");
+  // (TI = 32 — the prologue spread over twice the voxels — was measured: 128 VGPRs, four waves per SIMD; int16 + elastic
+  //  0.330 -> 0.313 ms, uint8 affine 0.246 -> 0.365 ms: the launch code instantiates 16 only)
+  constexpr int G = 4;
   {  // the arguments everything below starts from, requested together (left alone the compiler fetches each one right
      // before its first use: a dozen dependent round trips through the scalar cache)
     const float* mp = a.mapping; const uint8_t* pp = a.passthrough; const float* cpp = a.cp;
@@ -285,9 +287,12 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs
       carrier_t v[TI];
 #pragma unroll
       for (int t = 0; t < TI; t++) v[t] = static_cast<carrier_t>(src[max(offs[t], 0)]);
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
-                     "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+#pragma unroll
+      for (int t0 = 0; t0 < TI; t0 += 16)  // (one statement per sixteen registers: an asm takes at most thirty operands)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[t0 + 0]), "+v"(v[t0 + 1]), "+v"(v[t0 + 2]), "+v"(v[t0 + 3]), "+v"(v[t0 + 4]), "+v"(v[t0 + 5]), "+v"(v[t0 + 6]),
+                       "+v"(v[t0 + 7]), "+v"(v[t0 + 8]), "+v"(v[t0 + 9]), "+v"(v[t0 + 10]), "+v"(v[t0 + 11]), "+v"(v[t0 + 12]),
+                       "+v"(v[t0 + 13]), "+v"(v[t0 + 14]), "+v"(v[t0 + 15]));
 #pragma unroll
       for (int t = 0; t < TI; t++)
         if (col_active && t < i_count && !((undecided >> t) & 1u))

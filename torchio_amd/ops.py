@@ -238,6 +238,8 @@ class HostNormalStream:
         ):
             return None
         per_element = count // data.shape[0]
+        if (isinstance(mean, Tensor) or isinstance(std, Tensor)) and per_element < 624:
+            return None  # (per-element parameters: the kernel wants elements of at least one state block)
         device = data.device
         with torch.cuda.device(device):
             plan = self._device_plan(count, device)
