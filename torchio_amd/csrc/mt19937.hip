@@ -25,7 +25,8 @@ constexpr int kN = 624, kM = 397;
 constexpr int64_t kPlanUnitBlocks = 128;
 constexpr int64_t kPlanHeader = 16, kPlanTail = kPlanHeader + kN, kPlanSnapshots = kPlanTail + 16;
 constexpr uint32_t kPlanMagic = 0x4D54504Cu;
-constexpr int kThreads = 320;  // 312 pairs per state block: five waves, 97.5 % of the lanes busy in the transform
+constexpr int kThreads = 256;  // (320 — one thread per pair of a state block — was measured: five waves per block no longer fit
+                               //  seven blocks on a CU, the 1 681 blocks of a bench batch need a second round: 0.41 -> 0.57 ms)
 
 __device__ __forceinline__ uint32_t twist_word(uint32_t a, uint32_t b, uint32_t c) {
   const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
@@ -153,10 +154,8 @@ __device__ __forceinline__ float noisy(const NoiseTarget& t, const NoiseRun& r, 
 
 // `groups` complete groups of 16 raw words (LDS or global) -> normals at out[first .. first + 16 groups)
 template <bool ADD, typename Words>
-__device__ __forceinline__ void emit_groups(Words words, int groups, float* __restrict__ out, int64_t first, const NoiseTarget& target, int64_t n,
-                                            int tid) {
-  NoiseRun run;
-  if constexpr (ADD) run = noise_run(target, first, n);
+__device__ __forceinline__ void emit_groups(Words words, int groups, float* __restrict__ out, int64_t first, const NoiseTarget& target,
+                                            const NoiseRun& run, int tid) {
   for (int p = tid; p < groups * 8; p += kThreads) {
     const int at = (p >> 3) * 16 + (p & 7);
     float a, b;
@@ -171,8 +170,10 @@ __device__ __forceinline__ void emit_groups(Words words, int groups, float* __re
 }
 
 // Block 0: the rest of the state block the stream stood in.  Block u + 1: unit u — kPlanUnitBlocks twists from its snapshot.
+// (seven waves per SIMD = seven blocks per CU: the 1 681 blocks of a bench batch then run in ONE round on 256 CUs — at 73
+// registers, one more than that allows, the launch took a second round for its last 145 blocks: 0.41 -> 0.47 ms)
 template <bool ADD>
-__global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out, const NoiseTarget target) {
+__global__ __launch_bounds__(kThreads, 7) void mt19937_randn_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out, const NoiseTarget target) {
   __shared__ uint32_t s_state[2][kN];
   const int tid = threadIdx.x;
   const int64_t head = plan[1];
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
   const int64_t n = static_cast<int64_t>(plan[6]) | (static_cast<int64_t>(plan[7]) << 32);
   const int64_t n_full = n & ~static_cast<int64_t>(15);  // normal_fill transforms i < size - 15; the tail is the caller's copy
   if (blockIdx.x == 0) {
-    emit_groups<ADD>(plan + kPlanHeader, static_cast<int>(head / 16), out, 0, target, n, tid);
+    NoiseRun run{};
+    if constexpr (ADD) run = noise_run(target, 0, n);
+    emit_groups<ADD>(plan + kPlanHeader, static_cast<int>(head / 16), out, 0, target, run, tid);
     return;
   }
   const int64_t unit = static_cast<int64_t>(blockIdx.x) - 1;
@@ -188,6 +191,13 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
   for (int i = tid; i < kN; i += kThreads) s_state[0][i] = snapshot[i];
   __syncthreads();
   const int64_t b_end = min((unit + 1) * kPlanUnitBlocks, total_blocks);
+  // the parameters of the (at most two) batch elements this unit's 79 872 values fall in, fetched ONCE when elements are
+  // at least that long (inside the loop the fetch is a memory round trip per state block)
+  const bool run_per_unit = target.n_per_element >= kPlanUnitBlocks * kN;
+  NoiseRun run{};
+  if constexpr (ADD) {
+    if (run_per_unit) run = noise_run(target, head + unit * kPlanUnitBlocks * kN, n);
+  }
   int cur = 0;
   for (int64_t b = unit * kPlanUnitBlocks; b < b_end; b++) {
     const uint32_t* o = s_state[cur];
@@ -205,7 +215,10 @@ __global__ __launch_bounds__(kThreads) void mt19937_randn_kernel(const uint32_t*
     const int64_t at = head + b * kN;                 // first output index of this block
     const int64_t count = min(static_cast<int64_t>(kN), n - at);
     const int whole = static_cast<int>((min(at + count, n_full) - at) / 16);
-    if (whole > 0) emit_groups<ADD>(w, whole, out, at, target, n, tid);
+    if constexpr (ADD) {
+      if (!run_per_unit) run = noise_run(target, at, n);
+    }
+    if (whole > 0) emit_groups<ADD>(w, whole, out, at, target, run, tid);
     cur ^= 1;  // (no barrier here: the next twist only READS the buffer these groups read, and writes the other one)
   }
 }
