@@ -970,6 +970,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     {
       // Measured (8 x 256^3): affine 0.497 -> 0.478 ms; elastic launches LOSE (0.588 -> 0.610: 27 vertices with their
       // control-point reads per brick cost the planner more than the brick kernel's own reduction), and so do small ones.
+      // (Round 3, with the 32-lanes-per-brick planner: elastic 0.604 -> 0.622 ms, affine + elastic 0.666 -> 0.662: the exact
+      // elastic kernel is bound by its coordinate chain, not by what precedes it — profiles/r03_exp23_native.log.)
       const char* env_plan = getenv("TIO_EXACT_PLAN");
       const bool want = variant == 0 && a.ablate == 0 && a.cp == nullptr && !(env_plan != nullptr && atoi(env_plan) == 0) &&
                         (static_cast<int64_t>(a.B) * ((a.Io + 15) / 16) * ((a.Jo + 15) / 16) * ((a.Ko + 15) / 16) >= kPlannedMinBricks ||
