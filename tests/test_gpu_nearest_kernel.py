@@ -132,3 +132,46 @@ def test_margin_zero_would_not_be_bit_identical(hip, monkeypatch):
     torch.cuda.synchronize()
     wrong = int((reference != loose).sum())
     assert 0 < wrong < 1e-4 * seg.numel(), wrong
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_geometries_against_the_all_exact_road(hip, monkeypatch, seed):
+    """Random shapes (ragged against the 16 x 4 x 64 and 16 x 16 x 16 bricks), dtypes, control grids (some denser than a
+    brick), spacings, both composition orders, per-element or shared parameters, gate and skip flags, different input and
+    output grids: the kernel == the previous road of nearest images, bit for bit."""
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def pick(*options):
+        return options[int(torch.randint(0, len(options), (1,), generator=g))]
+
+    batch = pick(1, 2, 3)
+    k_lo, k_hi = pick((12, 47), (50, 140))  # narrower / wider than the 48 voxels from which a wave is one output row
+    in_shape = tuple(int(torch.randint(lo, hi, (1,), generator=g)) for lo, hi in ((20, 70), (18, 60), (k_lo, k_hi)))
+    out_shape = in_shape if pick(True, True, False) else tuple(max(8, int(s * pick(0.5, 1.5))) for s in in_shape)
+    dtype = pick(torch.uint8, torch.int16, torch.int32, torch.int64, torch.float32)
+    channels = pick(1, 1, 2)
+    data = _labels((batch, channels, *in_shape), dtype, 2000 + seed)
+    shared = pick(False, True)
+    n_param = 1 if shared else batch
+    mapping = _mapping(n_param, 3000 + seed, scale=pick(0.02, 0.1, 0.3), shift=pick(0.0, 3.0, 20.0))
+    if out_shape != in_shape:
+        for axis in range(3):
+            mapping[:, :, axis] *= in_shape[axis] / out_shape[axis]
+    elastic = pick(True, True, False)
+    cp_shape = pick((4, 4, 4), (7, 7, 7), (5, 9, 6), (out_shape[0] // 3 + 2, 5, 5))
+    control_points = _control_points(n_param, cp_shape, 4000 + seed, amplitude=pick(1.0, 6.0)) if elastic else None
+    kwargs = dict(
+        out_shape=out_shape, mapping=mapping.cuda(), control_points=control_points.cuda() if elastic else None,
+        in_spacing=pick((1, 1, 1), (0.8, 1.0, 2.5)), out_spacing=pick((1, 1, 1), (1.5, 0.7, 1.0)), affine_first=pick(True, False),
+        interps=["nearest"], fills=[None],
+    )
+    if out_shape == in_shape and pick(True, False):
+        kwargs["passthrough"] = (torch.rand(batch, generator=g) < 0.4).to(torch.uint8).cuda()
+    if elastic and pick(True, False):
+        kwargs["cp_skip"] = (torch.rand(batch, generator=g) < 0.4).to(torch.uint8).cuda()
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([data], **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([data], **kwargs)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(reference, got), (seed, in_shape, out_shape, dtype, cp_shape if elastic else None)
