@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs
     // 1/2 - eps (row + S): |x - rint(x)| <= lim0 - eps |x| decides the axis (block uniform part)
     const float row = fabsf(m[4 * r]) * static_cast<float>(a.Io) + fabsf(m[4 * r + 1]) * static_cast<float>(a.Jo) +
                       fabsf(m[4 * r + 2]) * static_cast<float>(a.Ko) + fabsf(m[4 * r + 3]);
-    lim0[r] = 0.5f - eps * (row + a.size_m1[r] + 1.0f);  // (a NaN / Inf / huge mapping: NaN or negative — nothing is decided)
+    // (the mapping works in voxels of the NORMALISING grid; on an image `ratio` times finer its roundings count `ratio` times)
+    lim0[r] = 0.5f - eps * (row * fmaxf(1.0f, a.ratio[r]) + a.size_m1[r] + 1.0f);  // (NaN / Inf / huge mapping: NaN or negative — nothing is decided)
   }
   Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
   if constexpr (ELASTIC_POSSIBLE) {
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs
           const float x = __builtin_fmaf(s, B3[0], A3[0]), y = __builtin_fmaf(s, B3[1], A3[1]), z = __builtin_fmaf(s, B3[2], A3[2]);
           const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
           const bool in_run = i_begin + t < run1;  // (uniform; also false beyond the last plane of a ragged brick)
-          const bool decided = in_run & (fmaxf(fmaxf(fabsf(x - xn), fabsf(y - yn)), fabsf(z - zn)) <= lim);  // NaN: undecided
+          // (fmaxf would drop a NaN term — but a NaN coordinate means a NaN line, and then lim is -1: undecided)
+          const bool decided = in_run & (fmaxf(fmaxf(fabsf(x - xn), fabsf(y - yn)), fabsf(z - zn)) <= lim);
           const int ix = static_cast<int>(xn), iy = static_cast<int>(yn), iz = static_cast<int>(zn);
           const bool ok = (static_cast<unsigned>(ix) <= uhx) & (static_cast<unsigned>(iy) <= uhy) & (static_cast<unsigned>(iz) <= uhz);
           const int off = mad24(mad24(ix, a.J, iy), a.K, iz);
