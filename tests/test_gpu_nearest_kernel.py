@@ -175,3 +175,23 @@ def test_random_geometries_against_the_all_exact_road(hip, monkeypatch, seed):
     got = hip.resample3d([data], **kwargs)[0]
     torch.cuda.synchronize()
     assert torch.equal(reference, got), (seed, in_shape, out_shape, dtype, cp_shape if elastic else None)
+
+
+@pytest.mark.parametrize("norm_shape", [(48, 40, 64), (200, 150, 260), (97, 81, 130)])
+def test_label_map_on_another_grid_than_the_normalising_one(hip, monkeypatch, norm_shape):
+    """`Resample` onto a named image of a multi-resolution subject: the grid is normalised with the FIRST image's shape
+    and un-normalised with the label map's own (spatial.py:1136-1191) — coarser, finer and odd ratios."""
+    batch, shape = 2, (96, 80, 128)
+    seg = _labels((batch, 1, *shape), torch.int16, 61)
+    mapping = _mapping(batch, 67, scale=0.05, shift=2.0)
+    for axis in range(3):  # the mapping lives on the normalising grid
+        mapping[:, :, axis] *= norm_shape[axis] / shape[axis]
+    kwargs = dict(out_shape=shape, mapping=mapping.cuda(), control_points=_control_points(batch, (5, 5, 5), 71, amplitude=3.0).cuda(),
+                  in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["nearest"], fills=[None], norm_shape=norm_shape)
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([seg], **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([seg], **kwargs)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(reference, got)
+    assert int((got != 0).sum()) > 0.3 * got.numel()
