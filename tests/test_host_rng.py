@@ -139,3 +139,33 @@ def test_plan_with_jump_ahead_equals_the_serial_plan(functions, n, threads):
     _, after_serial = _draw(functions, serial, 10_000, 1)
     _, after_jumped = _draw(functions, jumped, 10_000, 1)
     assert torch.equal(after_serial.view(torch.int32), after_jumped.view(torch.int32))
+
+
+def test_concurrent_plans_share_the_polynomial_cache_safely(functions):
+    """Several threads planning at once (Queue workers): same segment length, different segment counts — the cache of
+    jump polynomials grows behind the plans that are using it."""
+    import threading
+
+    counts = [2 * 4096 * 624 + 16 * k for k in (0, 5)] + [5 * 4096 * 624, 9 * 4096 * 624 + 160]
+    expected = {}
+    for n in counts:
+        state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+        functions["host_mt19937_seed"](C.addressof(state), n & 0xFFFF)
+        assert _plan(functions, state, n, 1)[0] == _abi.OK
+        expected[n] = bytes(state)
+    failures = []
+
+    def worker(n):
+        for _ in range(3):
+            state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+            functions["host_mt19937_seed"](C.addressof(state), n & 0xFFFF)
+            status = _plan(functions, state, n, 2 + (n // (4096 * 624)))[0]
+            if status != _abi.OK or bytes(state) != expected[n]:
+                failures.append(n)
+
+    threads = [threading.Thread(target=worker, args=(n,)) for n in counts]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join()
+    assert not failures

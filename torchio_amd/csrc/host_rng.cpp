@@ -444,12 +444,13 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
     while (segment < wanted) segment *= 2;  // (few distinct lengths: their polynomials are cached)
     n_segments = static_cast<int>((total_blocks + segment - 1) / segment);
   }
-  const std::vector<std::vector<uint64_t>>* ahead = n_segments > 1 ? tio_host_rng::jump_polynomials(segment, n_segments - 1) : nullptr;
-  if (ahead == nullptr) { segment = total_blocks; n_segments = 1; }
+  std::vector<tio_host_rng::JumpPolynomial> ahead;
+  if (n_segments > 1) ahead = tio_host_rng::jump_polynomials(segment, n_segments - 1);
+  if (static_cast<int>(ahead.size()) != n_segments - 1) { segment = total_blocks; n_segments = 1; }
   auto chain = [&](int t) {
     AlignedState work;
     if (t == 0) memcpy(work.s, st->s, kN * sizeof(uint32_t));
-    else tio_host_rng::jump_state(st->s, (*ahead)[static_cast<size_t>(t) - 1], work.s);
+    else tio_host_rng::jump_state(st->s, *ahead[static_cast<size_t>(t) - 1], work.s);
     memcpy(work.s + kN, work.s, 16 * sizeof(uint32_t));
     const int64_t b_end = std::min<int64_t>((t + 1) * segment, total_blocks);
     for (int64_t b = t * segment; b < b_end; b++) {

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -182,21 +183,21 @@ Poly power_of_x(const Field& f, uint64_t e) {
 }
 
 std::mutex g_cache_mutex;
-std::map<int64_t, std::vector<Poly>> g_cache;  // segment length in blocks -> g for 1, 2, ... segments
+std::map<int64_t, std::vector<JumpPolynomial>> g_cache;  // segment length in blocks -> g for 1, 2, ... segments
 
 }  // namespace
 
 bool jump_available() { return field().ok; }
 
 // the polynomials that carry a state `t * segment_blocks` twists ahead, t = 1 .. count (cached per segment length)
-const std::vector<std::vector<uint64_t>>* jump_polynomials(int64_t segment_blocks, int count) {
+std::vector<JumpPolynomial> jump_polynomials(int64_t segment_blocks, int count) {
   const Field& f = field();
-  if (!f.ok || segment_blocks <= 0 || count <= 0) return nullptr;
+  if (!f.ok || segment_blocks <= 0 || count <= 0) return {};
   std::lock_guard<std::mutex> lock(g_cache_mutex);
-  std::vector<Poly>& list = g_cache[segment_blocks];
-  if (list.empty()) list.push_back(power_of_x(f, static_cast<uint64_t>(segment_blocks) * kN));
-  while (static_cast<int>(list.size()) < count) list.push_back(mulmod(f, list.back(), list[0]));
-  return &list;
+  std::vector<JumpPolynomial>& list = g_cache[segment_blocks];
+  if (list.empty()) list.push_back(std::make_shared<const Poly>(power_of_x(f, static_cast<uint64_t>(segment_blocks) * kN)));
+  while (static_cast<int>(list.size()) < count) list.push_back(std::make_shared<const Poly>(mulmod(f, *list.back(), *list[0])));
+  return std::vector<JumpPolynomial>(list.begin(), list.begin() + count);
 }
 
 // out[0 .. 624) = the window `g(f)` carries `in` to (Horner over word steps on a linear buffer)
