@@ -8,6 +8,7 @@ thread counts, and a 32 M-draw run.  No GPU involved: the helper is host code of
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -169,3 +170,37 @@ def test_concurrent_plans_share_the_polynomial_cache_safely(functions):
     for thread in threads:
         thread.join()
     assert not failures
+
+
+def test_worker_pool_survives_a_fork():
+    """DataLoader workers fork: the child must not inherit the parent's worker threads' synchronisation objects
+    (csrc/host_rng.cpp: one pool per process, re-created behind pthread_atfork).  Run in a subprocess: the child of a
+    fork is not a place for pytest, and torch itself must not be touched in it."""
+    import subprocess
+    import sys
+    import textwrap
+
+    script = textwrap.dedent(
+        """
+        import ctypes as C, os, sys, torch
+        sys.path.insert(0, %r)
+        from torchio_amd import _abi, _lib
+        _, fn = _lib.load()
+        def state(seed):
+            st = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))(); fn["host_mt19937_seed"](C.addressof(st), seed); return st
+        n = 12_000_000
+        words = fn["host_mt19937_plan_words"](n); plan = torch.zeros(words, dtype=torch.int32); used = C.c_int64()
+        def run(st, threads): return fn["host_mt19937_plan"](C.addressof(st), n, C.c_void_p(plan.data_ptr()), words, C.byref(used), threads)
+        serial = state(1); assert run(serial, 1) == 0
+        pooled = state(1); assert run(pooled, 6) == 0 and bytes(pooled) == bytes(serial)   # the pool exists in the parent
+        pid = os.fork()
+        if pid == 0:
+            child = state(1)
+            os._exit(0 if (run(child, 6) == 0 and bytes(child) == bytes(serial)) else 3)
+        _, status = os.waitpid(pid, 0)
+        again = state(1)
+        sys.exit(0 if (os.WEXITSTATUS(status) == 0 and run(again, 6) == 0 and bytes(again) == bytes(serial)) else 4)
+        """
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    result = subprocess.run([sys.executable, "-c", script], timeout=120, capture_output=True, text=True)
+    assert result.returncode == 0, result.stderr[-2000:]

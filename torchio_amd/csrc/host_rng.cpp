@@ -21,7 +21,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#include <unistd.h>
+#include <pthread.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -146,7 +146,6 @@ class Workers {
     std::unique_lock<std::mutex> call(call_mutex_);
     {
       std::unique_lock<std::mutex> lock(mutex_);
-      if (owner_ != getpid()) { threads_.clear(); owner_ = getpid(); }  // (after a fork: no workers here; the old objects are leaked)
       while (static_cast<int>(threads_.size()) < count - 1 && threads_.size() < 63) {
         const int index = static_cast<int>(threads_.size());
         threads_.emplace_back(new std::thread([this, index] { loop(index); }));
@@ -184,12 +183,23 @@ class Workers {
   const std::function<void(int)>* job_ = nullptr;
   int count_ = 0, pending_ = 0;
   uint64_t generation_ = 0;
-  pid_t owner_ = 0;
 };
 
+// One pool per PROCESS: a forked child (DataLoader workers) inherits the parent's object with its mutexes and condition
+// variables in whatever state the parent's threads left them — and none of those threads — so it starts a fresh one
+// (the old object is leaked; measured: reusing it hangs in the first notify).
+Workers* g_workers = nullptr;
+std::mutex g_workers_mutex;
+
 Workers& workers() {
-  static Workers* pool = new Workers();  // (leaked on purpose: its threads outlive static destruction)
-  return *pool;
+  static const int registered = pthread_atfork(nullptr, nullptr, [] {
+    g_workers = nullptr;
+    new (&g_workers_mutex) std::mutex();  // (the parent may have held it at the fork)
+  });
+  (void)registered;
+  std::lock_guard<std::mutex> lock(g_workers_mutex);
+  if (g_workers == nullptr) g_workers = new Workers();  // (leaked on purpose: its threads outlive static destruction)
+  return *g_workers;
 }
 
 struct alignas(64) AlignedState { uint32_t s[kN + 16]; };
