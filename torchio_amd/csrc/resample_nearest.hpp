@@ -222,47 +222,76 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs
   for (int r = 0; r < 3; r++) C3[r] = static_cast<float>(static_cast<double>(f.m[4 * r]) * i_begin + f.c[r]);
 
   // ---- 1 + 2: the FAST line, four planes at a time; undecided planes are remembered -------------------------------------
-  // A line holds inside one control cell.  It is fetched at the first plane of a group of four; planes of the group
-  // beyond the cell's end are left to the exact chain (a cell boundary every ~S / (n - 1) planes: a percent or two).
+  // A line holds inside one control cell, and sixteen planes lie in one cell or two (three with control grids denser than
+  // a brick: the planes of the third are left to the exact chain).  Both lines are fetched up front; a group of four
+  // planes takes the line of its cell, the one group a cell boundary falls into selects plane by plane.  (Leaving the
+  // planes behind a boundary to the exact chain, as the first version did, cost a fifth of the kernel's instructions:
+  // every lane of a wave shares the boundary, 38 % of the bricks have one, and the chain is ten times the FAST line.)
   int offs[TI];
   unsigned undecided = 0u;
   {
-    float A3[3] = {0.0f, 0.0f, 0.0f}, B3[3] = {0.0f, 0.0f, 0.0f};
     const int u1 = i_begin + i_count;
-    int run0 = i_begin, run1 = i_begin;
+    float Aa[3] = {0.0f, 0.0f, 0.0f}, Ba[3] = {0.0f, 0.0f, 0.0f}, Ab[3] = {0.0f, 0.0f, 0.0f}, Bb[3] = {0.0f, 0.0f, 0.0f};
+    const int run_a1 = fast_column_line(f, lj, lk, planes, i_begin, u1, i_begin, C3, col3, lane, Aa, Ba);  // (wave uniform: the runs
+    int run_b1 = run_a1;                                                                                  //  depend on the plane index only)
+    if (run_a1 < u1) run_b1 = fast_column_line(f, lj, lk, planes, run_a1, u1, i_begin, C3, col3, lane, Ab, Bb);
+    // margin of a run of planes [s0, s1] on a line: |x| along a line is largest at one of its ends
+    auto line_margin = [&](const float (&A3)[3], const float (&B3)[3], float s0, float s1, float& lim, bool& lim_ok) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float xa = __builtin_fmaf(s0, B3[r], A3[r]), xb = __builtin_fmaf(s1, B3[r], A3[r]);
+        const float l = __builtin_fmaf(-eps, fmaxf(fabsf(xa), fabsf(xb)), lim0[r]);
+        lim_ok &= l >= 0.0f;  // NaN / Inf in the mapping or the line, coordinates far beyond float32's integers: false
+        lim = fminf(lim, l);  // (fminf / fmaxf drop a NaN operand: that is what lim_ok is for)
+      }
+    };
+    auto decide = [&](int t, float x, float y, float z, bool in_run, float lim) {
+      const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
+      // (fmaxf would drop a NaN term — but a NaN coordinate means a NaN line, and then lim is -1: undecided)
+      const bool decided = in_run & (fmaxf(fmaxf(fabsf(x - xn), fabsf(y - yn)), fabsf(z - zn)) <= lim);
+      const int ix = static_cast<int>(xn), iy = static_cast<int>(yn), iz = static_cast<int>(zn);
+      const bool ok = (static_cast<unsigned>(ix) <= uhx) & (static_cast<unsigned>(iy) <= uhy) & (static_cast<unsigned>(iz) <= uhz);
+      const int off = mad24(mad24(ix, a.J, iy), a.K, iz);
+      offs[t] = (decided & ok) ? off : -1;
+      undecided |= (decided | (t >= i_count)) ? 0u : (1u << t);
+    };
 #pragma unroll
     for (int t0 = 0; t0 < TI; t0 += G) {
       if (t0 < i_count) {  // (block uniform)
-        if (i_begin + t0 >= run1) {  // (wave uniform: the runs depend on the plane index only)
-          run0 = i_begin + t0;
-          run1 = fast_column_line(f, lj, lk, planes, run0, u1, i_begin, C3, col3, lane, A3, B3);
-        }
-        const float s0 = static_cast<float>(i_begin + t0 - run0);
-        // the group's margin: |x| along a line is largest at one of its ends
-        float lim = 1.0f;
-        bool lim_ok = true;  // (fminf / fmaxf drop a NaN operand: the axes are checked one by one)
+        const int p0 = i_begin + t0;
+        const bool straddles = (p0 < run_a1) & (p0 + G > run_a1) & (run_a1 < u1);  // (uniform)
+        if (!straddles) {
+          const bool second = p0 >= run_a1;  // (uniform: the line of this group's cell)
+          float A3[3], B3[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-          const float xa = __builtin_fmaf(s0, B3[r], A3[r]), xb = __builtin_fmaf(s0 + static_cast<float>(G - 1), B3[r], A3[r]);
-          const float l = __builtin_fmaf(-eps, fmaxf(fabsf(xa), fabsf(xb)), lim0[r]);
-          lim_ok &= l >= 0.0f;  // NaN / Inf in the mapping or the line, coordinates far beyond float32's integers: false
-          lim = fminf(lim, l);
-        }
-        if (!lim_ok) lim = -1.0f;  // nothing of this group is decided by the FAST line
+          for (int r = 0; r < 3; r++) { A3[r] = second ? Ab[r] : Aa[r]; B3[r] = second ? Bb[r] : Ba[r]; }
+          const int run0 = second ? run_a1 : i_begin, run_end = second ? run_b1 : run_a1;
+          const float s0 = static_cast<float>(p0 - run0);
+          float lim = 1.0f;
+          bool lim_ok = true;
+          line_margin(A3, B3, s0, s0 + static_cast<float>(G - 1), lim, lim_ok);
+          if (!lim_ok) lim = -1.0f;  // nothing of this group is decided by the FAST line
 #pragma unroll
-        for (int q = 0; q < G; q++) {
-          const int t = t0 + q;
-          const float s = s0 + static_cast<float>(q);
-          const float x = __builtin_fmaf(s, B3[0], A3[0]), y = __builtin_fmaf(s, B3[1], A3[1]), z = __builtin_fmaf(s, B3[2], A3[2]);
-          const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
-          const bool in_run = i_begin + t < run1;  // (uniform; also false beyond the last plane of a ragged brick)
-          // (fmaxf would drop a NaN term — but a NaN coordinate means a NaN line, and then lim is -1: undecided)
-          const bool decided = in_run & (fmaxf(fmaxf(fabsf(x - xn), fabsf(y - yn)), fabsf(z - zn)) <= lim);
-          const int ix = static_cast<int>(xn), iy = static_cast<int>(yn), iz = static_cast<int>(zn);
-          const bool ok = (static_cast<unsigned>(ix) <= uhx) & (static_cast<unsigned>(iy) <= uhy) & (static_cast<unsigned>(iz) <= uhz);
-          const int off = mad24(mad24(ix, a.J, iy), a.K, iz);
-          offs[t] = (decided & ok) ? off : -1;
-          undecided |= (decided | (t >= i_count)) ? 0u : (1u << t);
+          for (int q = 0; q < G; q++) {
+            const float sq = s0 + static_cast<float>(q);
+            decide(t0 + q, __builtin_fmaf(sq, B3[0], A3[0]), __builtin_fmaf(sq, B3[1], A3[1]), __builtin_fmaf(sq, B3[2], A3[2]),
+                   p0 + q < run_end, lim);  // (beyond the run: a third cell, or past the last plane of a ragged brick)
+          }
+        } else {
+          const float sa = static_cast<float>(p0 - i_begin);
+          float lim = 1.0f;
+          bool lim_ok = true;
+          line_margin(Aa, Ba, sa, static_cast<float>(run_a1 - 1 - i_begin), lim, lim_ok);
+          line_margin(Ab, Bb, 0.0f, static_cast<float>(p0 + G - 1 - run_a1), lim, lim_ok);
+          if (!lim_ok) lim = -1.0f;
+#pragma unroll
+          for (int q = 0; q < G; q++) {
+            const bool second = p0 + q >= run_a1;  // (uniform)
+            const float sq = static_cast<float>(second ? p0 + q - run_a1 : p0 + q - i_begin);
+            decide(t0 + q, __builtin_fmaf(sq, second ? Bb[0] : Ba[0], second ? Ab[0] : Aa[0]),
+                   __builtin_fmaf(sq, second ? Bb[1] : Ba[1], second ? Ab[1] : Aa[1]),
+                   __builtin_fmaf(sq, second ? Bb[2] : Ba[2], second ? Ab[2] : Aa[2]), p0 + q < run_b1, lim);
+          }
         }
       } else {
 #pragma unroll
