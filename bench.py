@@ -366,7 +366,7 @@ def main() -> None:
             "host_settling_ms_per_step": settle_log,  # untimed blocks of 20 steps before the warm-up: the host side of a fresh box
             "roofline": {
                 "kernel": (
-                    "tio::resample_planned_kernel (+ tio::plan_bricks_kernel; tio_resample3d: Affine and ElasticDeformation launches, mean)"
+                    "tio::resample_planned_lean_kernel (+ tio::plan_bricks_kernel; tio_resample3d: Affine and ElasticDeformation launches, mean)"
                     if args.resample_precision == "fast"
                     else "tio::resample_tile_kernel (tio_resample3d: Affine and ElasticDeformation launches, mean)"
                 ),
