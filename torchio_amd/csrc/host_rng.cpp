@@ -150,7 +150,9 @@ class Workers {
         const int index = static_cast<int>(threads_.size());
         threads_.emplace_back(new std::thread([this, index] { loop(index); }));
       }
-      job_ = &job; count_ = count; pending_ = count - 1; generation_++;
+      // (more jobs than workers: worker w takes jobs w + 1, w + 1 + W, ...)
+      job_ = &job; count_ = count; stride_ = static_cast<int>(threads_.size());
+      pending_ = std::min(count - 1, stride_); generation_++;
     }
     wake_.notify_all();
     job(0);
@@ -171,7 +173,7 @@ class Workers {
         if (index + 1 < count_) job = job_;
       }
       if (job != nullptr) {
-        (*job)(index + 1);
+        for (int t = index + 1; t < count_; t += stride_) (*job)(t);
         std::unique_lock<std::mutex> lock(mutex_);
         if (--pending_ == 0) done_.notify_all();
       }
@@ -181,7 +183,7 @@ class Workers {
   std::condition_variable wake_, done_;
   std::vector<std::thread*> threads_;  // (never joined: they live as long as the process)
   const std::function<void(int)>* job_ = nullptr;
-  int count_ = 0, pending_ = 0;
+  int count_ = 0, pending_ = 0, stride_ = 1;
   uint64_t generation_ = 0;
 };
 
@@ -448,6 +450,7 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
   constexpr int64_t kMinSegmentBlocks = 4096;  // 2.5 M draws: below, a jump costs more than the chain it saves
   int64_t segment = total_blocks;
   int n_segments = 1;
+  if (n_threads > 64) n_threads = 64;  // (the worker pool's size)
   if (n_threads > 1 && total_blocks >= 2 * kMinSegmentBlocks && tio_host_rng::jump_available()) {
     const int64_t wanted = std::max<int64_t>((total_blocks + n_threads - 1) / n_threads, kMinSegmentBlocks);
     segment = kMinSegmentBlocks;
