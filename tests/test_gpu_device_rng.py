@@ -164,3 +164,78 @@ def test_concurrent_streams_do_not_share_staging_buffers(hip):
         for repeat, tensors in enumerate(drawn):
             for expected, got in zip(_torch_stream(seed + repeat, counts), tensors):
                 assert torch.equal(expected.view(torch.int32), got.view(torch.int32)), (seed, repeat)
+
+
+def _untemper(y: "np.ndarray") -> "np.ndarray":
+    """Inverse of mt19937's tempering on uint32 arrays (a bijection: every 24-bit uniform can be asked for)."""
+    import numpy as np
+
+    y = y.astype(np.uint64)
+    y ^= y >> 18
+    y ^= (y << 15) & 0xEFC60000
+    x = y.copy()
+    for _ in range(5):  # y ^= (y << 7) & mask, undone seven bits at a time
+        x = y ^ ((x << 7) & 0x9D2C5680)
+    y = x & 0xFFFFFFFF
+    x = y.copy()
+    for _ in range(3):
+        x = y ^ (x >> 11)
+    return (x & 0xFFFFFFFF).astype(np.uint32)
+
+
+def test_every_24_bit_uniform_through_both_transforms(hip):
+    """The Box-Muller step depends on a draw only through two 24-bit uniforms: u1 (radius = sqrt(-2 log(1 - u1))) and u2
+    (cos / sin of 2 pi u2).  EVERY value of each — 2^24 radii, 2^24 angles — goes through the host restatement
+    (pinned against torch.randn, tests/test_host_rng.py) and through the device kernel: identical bits.  The raw words
+    are placed in the rest-of-block slot of a generator state (which is emitted without a twist), 624 per call."""
+    import ctypes as C
+
+    import numpy as np
+
+    from torchio_amd import _abi
+    from torchio_amd import _lib
+
+    _, fn = _lib.load()
+    values = np.arange(1 << 24, dtype=np.uint32)
+    high = (np.arange(1 << 24, dtype=np.uint64) * 2654435761 % 256).astype(np.uint32) << 24  # the 8 bits the uniform drops: anything
+    raw = _untemper(values | high)
+    check = raw.astype(np.uint64)
+    check ^= check >> 11
+    check ^= (check << 7) & 0x9D2C5680
+    check ^= (check << 15) & 0xEFC60000
+    check ^= check >> 18
+    assert np.array_equal((check & 0xFFFFFF).astype(np.uint32), values)  # the tempered words carry the uniforms we asked for
+    # groups of 16 words: lanes 0..7 carry u1 = k, lanes 8..15 u2 = a permutation of k (every value of both occurs once)
+    angle = np.roll(raw, 12345)
+    words = np.empty(2 << 24, dtype=np.uint32).reshape(-1, 2, 8)
+    words[:, 0, :] = raw.reshape(-1, 8)
+    words[:, 1, :] = angle.reshape(-1, 8)
+    words = words.reshape(-1)
+    words = np.concatenate([words, words[: (-words.size) % 624]]).reshape(-1, 624)  # whole state blocks (the last one padded with repeats)
+    n_blocks = words.shape[0]
+    state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    view = np.frombuffer(state, dtype=np.uint32)  # MtState: s[624 + 16], pos, seeded (csrc/host_rng.cpp)
+    host = np.empty((n_blocks, 624), dtype=np.float32)
+    device = torch.empty((n_blocks, 624), dtype=torch.float32, device="cuda")
+    plan_words = int(fn["host_mt19937_plan_words"](624))
+    plan_host = torch.empty((n_blocks, plan_words), dtype=torch.int32).pin_memory()
+    used = C.c_int64(0)
+    for block in range(n_blocks):
+        for target in ("host", "plan"):
+            fn["host_mt19937_seed"](C.addressof(state), 1)
+            view[:624] = words[block]
+            view[640] = 0  # pos: the whole block is still to be read
+            if target == "host":
+                assert fn["host_mt19937_randn"](C.addressof(state), C.c_void_p(host[block].ctypes.data), 624, 1) == _abi.OK
+            else:
+                assert fn["host_mt19937_plan"](C.addressof(state), 624, C.c_void_p(plan_host[block].data_ptr()), plan_words, C.byref(used), 1) == _abi.OK
+    plan_dev = plan_host.cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    for block in range(n_blocks):
+        status = fn["mt19937_randn_device"](C.c_void_p(plan_host[block].data_ptr()), C.c_void_p(plan_dev[block].data_ptr()),
+                                            C.c_void_p(device[block].data_ptr()), C.c_void_p(stream))
+        assert status == _abi.OK
+    torch.cuda.synchronize()
+    got = device.cpu().numpy()
+    assert np.array_equal(host.view(np.uint32), got.view(np.uint32))
+    assert n_blocks * 312 >= 1 << 24
