@@ -204,3 +204,55 @@ def test_worker_pool_survives_a_fork():
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     result = subprocess.run([sys.executable, "-c", script], timeout=120, capture_output=True, text=True)
     assert result.returncode == 0, result.stderr[-2000:]
+
+
+def _untemper(y):
+    """Inverse of mt19937's tempering on uint32 arrays (a bijection: every 24-bit uniform can be asked for)."""
+    y = y.astype(np.uint64)
+    y ^= y >> 18
+    y ^= (y << 15) & 0xEFC60000
+    x = y.copy()
+    for _ in range(5):  # y ^= (y << 7) & mask, undone seven bits at a time
+        x = y ^ ((x << 7) & 0x9D2C5680)
+    y = x & 0xFFFFFFFF
+    x = y.copy()
+    for _ in range(3):
+        x = y ^ (x >> 11)
+    return (x & 0xFFFFFFFF).astype(np.uint32)
+
+
+def test_every_24_bit_uniform_against_torch_itself(functions):
+    """The Box-Muller step sees a draw only through two 24-bit uniforms.  EVERY value of each (2^24 radii through
+    log256_ps and the square root, 2^24 angles through sincos256_ps) goes through torch's own kernel — a CPU generator
+    whose state is set to crafted words, read without a twist — and through the restatement: identical bits.  With
+    tests/test_gpu_device_rng.py::test_every_24_bit_uniform_through_both_transforms (host == device on the same words)
+    the device stream is pinned to torch for every input the arithmetic can see, not for a sample of them."""
+    values = np.arange(1 << 24, dtype=np.uint32)
+    high = (np.arange(1 << 24, dtype=np.uint64) * 2654435761 % 256).astype(np.uint32) << 24  # the 8 bits the uniform drops
+    raw = _untemper(values | high)
+    words = np.empty(2 << 24, dtype=np.uint32).reshape(-1, 2, 8)
+    words[:, 0, :] = raw.reshape(-1, 8)                    # lanes 0 .. 7 of a group of 16: u1
+    words[:, 1, :] = np.roll(raw, 12345).reshape(-1, 8)    # lanes 8 .. 15: u2 (a permutation: every value once)
+    words = words.reshape(-1)
+    words = np.concatenate([words, words[: (-words.size) % 608]]).reshape(-1, 608)  # 38 groups of 16 per generator state
+    generator = torch.Generator()
+    template = generator.manual_seed(1).get_state().clone()
+    raw_state = template.numpy().view(np.uint8)
+    # THGeneratorState: uint64 seed; int left; int seeded; uint64 next; uint64 state[624]; ... (left = 624 — the largest
+    # valid value — and next = 0: the next 623 draws read state[0 .. 623) as it stands; 608 of them are used)
+    raw_state[8:12] = np.frombuffer(np.int32(624).tobytes(), dtype=np.uint8)
+    raw_state[16:24] = 0
+    slots = raw_state[24 : 24 + 624 * 8].view(np.uint64)
+    state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+    view = np.frombuffer(state, dtype=np.uint32)  # MtState: s[624 + 16], pos, seeded (csrc/host_rng.cpp)
+    ours = np.empty(608, dtype=np.float32)
+    step = 1 if os.environ.get("TIO_TEST_EXHAUSTIVE", "1") != "0" else 97
+    for block in range(0, words.shape[0], step):
+        slots[:608] = words[block]
+        generator.set_state(template)
+        theirs = torch.randn(608, generator=generator).numpy()
+        functions["host_mt19937_seed"](C.addressof(state), 1)
+        view[:608] = words[block]
+        view[640] = 0
+        assert functions["host_mt19937_randn"](C.addressof(state), C.c_void_p(ours.ctypes.data), 608, 1) == _abi.OK
+        assert np.array_equal(theirs.view(np.uint32), ours.view(np.uint32)), block
