@@ -384,12 +384,13 @@ def main() -> None:
         if args.gpus == 1 and not args.no_mode_matrix:
             # The headline value above is the mode named in config.  The other modes of the same pipeline, so
             # that nobody has to guess what a different switch would have measured:
-            #   noise_rng "reference" = the reference's own stream (seeded CPU mt19937 draws + 64 MiB H2D per
-            #   volume: reference-identical, host bound); "philox" = in-kernel draws, NOT reference-identical;
-            #   resample_precision "exact" = bit-identical coordinates / interpolation; "fast" = within 1e-4.
+            #   noise_rng "reference" = the reference's own stream, bit for bit (torch's CPU mt19937 + Box-Muller: the host
+            #   runs the state chain, the device replays it and draws: csrc/mt19937.hip; the library's default);
+            #   "philox" = in-kernel Philox draws, NOT reference-identical;
+            #   resample_precision "exact" = bit-identical coordinates / interpolation (default); "fast" = within 1e-4.
             out = None
             modes = {}
-            for rng_mode, prec, steps in (("philox", "exact", 10), ("philox", "fast", 10), ("reference", "exact", 3)):
+            for rng_mode, prec, steps in (("philox", "exact", 10), ("philox", "fast", 10), ("reference", "exact", 10), ("reference", "fast", 10)):
                 modes[f"noise={rng_mode},resample={prec}"] = time_mode(
                     transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77, timer=timer, launch_bytes=launch_bytes
                 )
@@ -397,7 +398,7 @@ def main() -> None:
             line["noise_modes"] = {
                 "philox": modes["noise=philox,resample=exact"]["volumes_per_s"],
                 "reference": modes["noise=reference,resample=exact"]["volumes_per_s"],
-                "note": "reference = bit-identical noise stream (host mt19937 draws, host bound); philox = in-kernel draws, a different stream",
+                "note": "reference = bit-identical noise stream (mt19937 state chain on the host, draws on the device); philox = in-kernel draws, a different stream",
             }
         if args.gpus == 1 and not args.no_other_configs:
             out = None
@@ -411,6 +412,7 @@ def main() -> None:
                 "tests/test_gpu_resample_planned.py, tests/test_gpu_full_size.py::test_fast_precision_256_* (FAST resampling vs exact kernel / oracle)",
             ],
             "noise=philox,resample=exact": ["tests/test_gpu_lazy_fusion.py", "tests/test_gpu_ops_parity.py (philox add_noise vs oracle philox)", "tests/test_gpu_golden.py (resampling: bit-exact)"],
+            "noise=reference,resample=fast": ["the two rows around it: the noise stream of the default mode, the resamplers and stencil of the headline mode"],
             "noise=reference,resample=exact (library default)": [
                 "tests/test_gpu_device_rng.py (the device-drawn stream == torch.randn(generator=cpu) bit for bit: 134 M draws, tails, continuations)",
                 "tests/test_gpu_full_size.py::test_config3_compose_256_batch2_matches_oracle (labels bit-exact, intensities <= 1e-5)",
