@@ -156,7 +156,7 @@ class HostNormalStream:
         if status != _abi.OK:
             raise EngineError(f"tio_host_mt19937_seed failed with status {status}")
         threads = os.environ.get("TIO_HOST_RNG_THREADS")
-        self.threads = int(threads) if threads else max(1, min(16, (os.cpu_count() or 2) - 1))
+        self.threads = int(threads) if threads else max(1, min(32, (os.cpu_count() or 2) - 1))
 
     @staticmethod
     def takes(shape) -> bool:
