@@ -508,7 +508,9 @@ int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan_ho
 int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream);
 /* Noise.apply_transform for a float32 image in one kernel: out = x + (mean + std z) with z the plan's draws (the three
  * float32 roundings of noise.py:178, :119, as tio_add_noise) — the draws never exist in memory.  x / out: the image's
- * B * n_per_element values (the plan's n); mean_dev / std_dev: (B,) per-element parameters or NULL (then the scalars). */
+ * B * n_per_element values (the plan's n); mean_dev / std_dev: (B,) per-element parameters or NULL (then the scalars).
+ * out may be x itself only when n is a multiple of 16 (otherwise TIO_ERR_UNSUPPORTED_CONFIG: torch's tail rule draws the
+ * last 16 values a second time, from x). */
 int tio_mt19937_add_noise_device(const uint32_t* plan_host, const uint32_t* plan_dev, const float* x_dev, float* out_dev,
                                  int64_t n_per_element, float mean, float std, const float* mean_dev, const float* std_dev,
                                  void* stream);

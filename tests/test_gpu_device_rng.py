@@ -102,6 +102,52 @@ def test_draw_and_sum_in_one_kernel_equals_the_two_steps(hip, monkeypatch, batch
     assert torch.equal(torch.randn(1 << 20, generator=generator).view(torch.int32), follow_up.view(torch.int32))
 
 
+def test_fused_noise_keeps_the_gradient_and_refuses_what_it_cannot_read(hip):
+    """The reference is differentiable through Noise (tests/test_noise.py:75-80): the fused form passes the gradient on
+    (dy/dx = 1); parameter vectors of another length / dtype / device are left to the general road (`None`)."""
+    from torchio_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    data = torch.rand(2, 1, 96, 96, 128, generator=g, device="cuda")
+    leaf = data.clone().requires_grad_(True)
+    noisy = ops.HostNormalStream(77).add_noise(leaf, 0.5, 2.0)
+    assert noisy is not None and noisy.requires_grad
+    weight = torch.rand(data.shape, generator=g, device="cuda")
+    (noisy * weight).sum().backward()
+    assert torch.equal(leaf.grad, weight)
+    assert torch.equal(noisy.detach(), ops.HostNormalStream(77).add_noise(data, 0.5, 2.0))
+    with torch.no_grad():  # (a tensor that requires grad is just data here)
+        assert not ops.HostNormalStream(77).add_noise(leaf, 0.5, 2.0).requires_grad
+    stream = ops.HostNormalStream(77)
+    state = bytes(stream._state)
+    assert stream.add_noise(data, torch.ones(3, device="cuda"), 1.0) is None          # not one value per element
+    assert stream.add_noise(data, torch.ones(2), 1.0) is None                         # on the host
+    assert stream.add_noise(data, torch.ones(2, device="cuda", dtype=torch.float64), 1.0) is None
+    assert bytes(stream._state) == state, "a refused call draws nothing"
+
+
+def test_in_place_sum_only_where_the_tail_rule_does_not_reread(hip):
+    """out == x through the C ABI: fine for whole groups of 16; with torch's tail rule (the last 16 values drawn again, from x)
+    the call is refused instead of adding noise twice."""
+    from torchio_amd import _abi, ops
+
+    for count, expected in (((1 << 20) + 32, _abi.OK), ((1 << 20) + 5, _abi.UNSUPPORTED_CONFIG)):
+        stream = ops.HostNormalStream(9)
+        data = torch.zeros(count, device="cuda")
+        with torch.cuda.device(data.device):
+            plan_host, plan_dev = stream._device_plan(count, data.device)
+        raw_stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+        status = stream._fn["mt19937_add_noise_device"](
+            C.c_void_p(plan_host.data_ptr()), C.c_void_p(plan_dev.data_ptr()), C.c_void_p(data.data_ptr()), C.c_void_p(data.data_ptr()),
+            count, 0.0, 1.0, None, None, C.c_void_p(raw_stream),
+        )
+        assert status == expected
+        if status == _abi.OK:
+            torch.cuda.synchronize()
+            reference = torch.randn(count, generator=torch.Generator().manual_seed(9))
+            assert torch.equal(data.cpu(), 0.0 + (0.0 + 1.0 * reference))
+
+
 def test_noise_transform_in_reference_mode_uses_the_fused_kernel_and_matches_torch(hip, monkeypatch):
     """`tio.Noise` on device-resident float32 images, reference RNG mode: identical to the reference's arithmetic
     `data + (mean + std * torch.randn(shape, generator=cpu(seed)))`, image after image from one generator."""

@@ -243,6 +243,8 @@ extern "C" int tio_mt19937_add_noise_device(const uint32_t* plan_host, const uin
   const int64_t n = static_cast<int64_t>(plan_host[6]) | (static_cast<int64_t>(plan_host[7]) << 32);
   if ((mean_dev != nullptr || std_dev != nullptr) && n_per_element < kN)
     return fail(TIO_ERR_UNSUPPORTED_CONFIG, "tio_mt19937_add_noise_device: per-element parameters need elements of at least 624 values");
+  if (x_dev == out_dev && plan_host[5] != 0u)  // (the tail rule re-reads x for the last 16 values after the main kernel has written them)
+    return fail(TIO_ERR_UNSUPPORTED_CONFIG, "tio_mt19937_add_noise_device: in place only for draw counts that are multiples of 16");
   if (n % n_per_element != 0) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_add_noise_device: the plan's %lld draws are not whole elements of %lld", static_cast<long long>(n), static_cast<long long>(n_per_element));
   const NoiseTarget target{x_dev, mean_dev, std_dev, mean, std, n_per_element};
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import types
 from collections.abc import Sequence
 
 import torch
@@ -178,6 +179,13 @@ class HostNormalStream:
             out = self._randn_on_device(count, device)
             if out is not None:
                 return out.view(tuple(int(extent) for extent in shape))
+        if on_gpu:  # (the uploads and the event that frees the staging buffer belong to the DATA's device and its current stream)
+            with torch.cuda.device(device):
+                return self._randn_via_host(count, device).view(tuple(int(extent) for extent in shape))
+        return self._randn_via_host(count, device).view(tuple(int(extent) for extent in shape))
+
+    def _randn_via_host(self, count: int, device) -> Tensor:
+        on_gpu = device.type == "cuda"
         host = self._staging(count) if on_gpu else torch.empty(count, dtype=torch.float32)
         out = torch.empty(count, dtype=torch.float32, device=device) if on_gpu else host
         for start in range(0, count, self.CHUNK):
@@ -193,7 +201,7 @@ class HostNormalStream:
                 break
         if on_gpu:
             HostNormalStream._rings().uploaded[id(host)].record()  # the staging buffer is free again once this copy has completed
-        return out.view(tuple(int(extent) for extent in shape))
+        return out
 
     def _device_plan(self, count: int, device):
         """The plan of ``count`` draws (``tio_host_mt19937_plan``: the host runs the mt19937 state chain — in parallel, by
@@ -240,6 +248,15 @@ class HostNormalStream:
         per_element = count // data.shape[0]
         if (isinstance(mean, Tensor) or isinstance(std, Tensor)) and per_element < 624:
             return None  # (per-element parameters: the kernel wants elements of at least one state block)
+        for vector in (mean, std):  # per-element parameters as the kernel reads them: (B,) float32 next to the data
+            if isinstance(vector, Tensor) and (
+                vector.device != data.device or vector.dtype != torch.float32 or vector.numel() != data.shape[0]
+                or not vector.is_contiguous() or vector.requires_grad
+            ):
+                return None
+        if _wants_grad(data):  # additive: dy/dx = 1 (as Engine.add_noise)
+            result = self.add_noise(data.detach(), mean, std)
+            return None if result is None else _AttachBackward.apply(data, result, lambda grad: grad)
         device = data.device
         with torch.cuda.device(device):
             plan = self._device_plan(count, device)
@@ -268,9 +285,13 @@ class HostNormalStream:
     @classmethod
     def _rings(cls):
         state = cls._thread_state
-        if not hasattr(state, "uploaded"):
-            state.uploaded, state.plans, state.buffers = {}, {}, {}
-        return state
+        if not hasattr(state, "per_device"):
+            state.per_device = {}
+        device = torch.cuda.current_device()  # (an event belongs to the device it is first recorded on: one set of rings per device)
+        rings = state.per_device.get(device)
+        if rings is None:
+            rings = state.per_device[device] = types.SimpleNamespace(uploaded={}, plans={}, buffers={})
+        return rings
 
     @classmethod
     def _ring_buffer(cls, rings: dict, uploaded: dict, size: int, dtype, length: int) -> Tensor:
