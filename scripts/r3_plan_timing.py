@@ -22,7 +22,7 @@ words = fn["host_mt19937_plan_words"](n)
 plan = torch.zeros(words, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.zeros(words, dtype=torch.int32)
 used = C.c_int64()
 reference = None
-for threads in (1, 2, 4, 8, 12, 16, 24, 32):
+for threads in (1, 2, 4, 8, 12, 16, 24, 32, 64):
     best = 1e9
     for rep in range(5):
         st = state(7)

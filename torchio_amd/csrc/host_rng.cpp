@@ -24,6 +24,7 @@
 #include <pthread.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -143,48 +144,57 @@ class Workers {
   // runs job(t) for t = 0 .. count - 1: t = 0 on the calling thread, the rest on the pool; returns when all are done
   void run(int count, const std::function<void(int)>& job) {
     if (count <= 1) { if (count == 1) job(0); return; }
-    std::unique_lock<std::mutex> call(call_mutex_);
-    {
-      std::unique_lock<std::mutex> lock(mutex_);
-      while (static_cast<int>(threads_.size()) < count - 1 && threads_.size() < 63) {
-        const int index = static_cast<int>(threads_.size());
-        threads_.emplace_back(new std::thread([this, index] { loop(index); }));
-      }
-      // (more jobs than workers: worker w takes jobs w + 1, w + 1 + W, ...)
-      job_ = &job; count_ = count; stride_ = static_cast<int>(threads_.size());
-      pending_ = std::min(count - 1, stride_); generation_++;
+    std::unique_lock<std::mutex> call(call_mutex_);  // one call at a time
+    while (static_cast<int>(slots_.size()) < count - 1 && slots_.size() < 63) {
+      Slot* slot = new Slot();  // (never freed: its thread lives as long as the process)
+      const int index = static_cast<int>(slots_.size());
+      slots_.push_back(slot);
+      slot->thread = new std::thread([this, slot, index] { loop(slot, index); });
     }
-    wake_.notify_all();
+    // (more jobs than workers: worker w takes jobs w + 1, w + 1 + W, ...)
+    job_ = &job; count_ = count; stride_ = static_cast<int>(slots_.size());
+    const int active = std::min(count - 1, stride_);
+    pending_.store(active);
+    // every worker sleeps on ITS OWN condition variable: the ones this call needs are woken one by one and start at once (a
+    // shared one wakes the whole pool, which then queues up behind the one mutex)
+    for (int w = 0; w < active; w++) {
+      { std::lock_guard<std::mutex> lock(slots_[w]->mutex); slots_[w]->generation++; }
+      slots_[w]->wake.notify_one();
+    }
     job(0);
-    std::unique_lock<std::mutex> lock(mutex_);
-    done_.wait(lock, [this] { return pending_ == 0; });
+    std::unique_lock<std::mutex> lock(done_mutex_);
+    done_.wait(lock, [this] { return pending_.load() == 0; });
     job_ = nullptr;
   }
 
  private:
-  void loop(int index) {
+  struct Slot {
+    std::mutex mutex;
+    std::condition_variable wake;
+    uint64_t generation = 0;
+    std::thread* thread = nullptr;
+  };
+  void loop(Slot* slot, int index) {
     uint64_t seen = 0;
     for (;;) {
-      const std::function<void(int)>* job = nullptr;
       {
-        std::unique_lock<std::mutex> lock(mutex_);
-        wake_.wait(lock, [&] { return generation_ != seen; });
-        seen = generation_;
-        if (index + 1 < count_) job = job_;
-      }
-      if (job != nullptr) {
-        for (int t = index + 1; t < count_; t += stride_) (*job)(t);
-        std::unique_lock<std::mutex> lock(mutex_);
-        if (--pending_ == 0) done_.notify_all();
+        std::unique_lock<std::mutex> lock(slot->mutex);
+        slot->wake.wait(lock, [&] { return slot->generation != seen; });
+        seen = slot->generation;
+      }  // (job_, count_, stride_ were written before the generation changed under this mutex)
+      for (int t = index + 1; t < count_; t += stride_) (*job_)(t);
+      if (pending_.fetch_sub(1) == 1) {
+        { std::lock_guard<std::mutex> lock(done_mutex_); }  // (the caller is either before its check or asleep: never in between)
+        done_.notify_one();
       }
     }
   }
-  std::mutex call_mutex_, mutex_;
-  std::condition_variable wake_, done_;
-  std::vector<std::thread*> threads_;  // (never joined: they live as long as the process)
+  std::mutex call_mutex_, done_mutex_;
+  std::condition_variable done_;
+  std::vector<Slot*> slots_;
   const std::function<void(int)>* job_ = nullptr;
-  int count_ = 0, pending_ = 0, stride_ = 1;
-  uint64_t generation_ = 0;
+  int count_ = 0, stride_ = 1;
+  std::atomic<int> pending_{0};
 };
 
 // One pool per PROCESS: a forked child (DataLoader workers) inherits the parent's object with its mutexes and condition

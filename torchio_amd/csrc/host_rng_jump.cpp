@@ -215,7 +215,11 @@ void jump_state(const uint32_t* in, const std::vector<uint64_t>& g, uint32_t* ou
   memcpy(xs, in, kN * sizeof(uint32_t));
   for (int i = 0; i + 1 < kWindow; i++) xs[kN + i] = step_word(xs[i], xs[i + 1], xs[i + kM]);
   // table[j] = xor over the set bits i of j of f^i(s) = the window of xs at offset i
-  std::vector<uint32_t> table(static_cast<size_t>(kSums) * kN, 0u);
+  // (scratch kept per thread: 640 KB + 100 KB allocated afresh by every jump are an mmap / munmap pair and a few hundred page
+  // faults each, taken under the process's address-space lock by all planning threads at once)
+  static thread_local std::vector<uint32_t> table, line;
+  table.resize(static_cast<size_t>(kSums) * kN);
+  memset(table.data(), 0, kN * sizeof(uint32_t));  // (row 0: the empty sum; every other row is written below)
   for (int j = 1; j < kSums; j++) {
     const int low = __builtin_ctz(j);
     const uint32_t* base = &table[static_cast<size_t>(j & (j - 1)) * kN];
@@ -223,8 +227,9 @@ void jump_state(const uint32_t* in, const std::vector<uint64_t>& g, uint32_t* ou
     for (int m = 0; m < kN; m++) row[m] = base[m] ^ xs[low + m];
   }
   const int groups = deg / kWindow + 1;  // coefficient groups, the top one padded with zeros
-  std::vector<uint32_t> line(static_cast<size_t>(kN) + static_cast<size_t>(groups) * kWindow + 16, 0u);
-  uint32_t* h = line.data();  // the window: h[0 .. 624), all zero
+  line.resize(static_cast<size_t>(kN) + static_cast<size_t>(groups) * kWindow + 16);
+  uint32_t* h = line.data();  // the window: h[0 .. 624), all zero (what lies beyond is written before it is read)
+  memset(h, 0, kN * sizeof(uint32_t));
   for (int q = groups - 1; q >= 0; q--) {
     for (int i = 0; i < kWindow; i++) h[kN + i] = step_word(h[i], h[i + 1], h[i + kM]);  // kWindow word steps (independent: 397 + w < 624)
     h += kWindow;
