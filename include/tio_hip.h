@@ -498,7 +498,7 @@ int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int3
  * groups then straddle state blocks); the caller falls back to tio_host_mt19937_randn.
  * n_threads > 1 cuts long chains into segments: mt19937 is linear over GF(2), so a thread can JUMP to the start of its
  * segment (g(f) applied to the state, g = x^J mod the characteristic polynomial — computed and verified at first use,
- * csrc/host_rng_jump.cpp) and chain from there: 134 M draws are planned in ~1.4 ms on 8 threads (0.9 on 16) instead of 5.5 - 7 ms on one.
+ * csrc/host_rng_jump.cpp) and chain from there: 134 M draws are planned in ~1.2 ms on 8 threads (0.55 - 0.65 on 32) instead of 5.5 - 7 ms on one.
  * The snapshot at the start of a jumped segment may differ from the chained one in the 31 low bits of its first word —
  * bits that are not part of the generator's state (the recurrence never reads them).
  */
