@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 9
+#define TIO_ABI_VERSION 10
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -522,6 +522,10 @@ int tio_abi_version(void);
 const char* tio_last_error(void);
 /* Number of visible HIP devices (0 when none; never throws). */
 int tio_device_count(void);
+/* The library parses its TIO_* environment switches (A/B experiments, see torchio_amd/csrc/common.hpp: EnvSwitches)
+ * ONCE, at the first call that needs one; no entry point calls getenv() afterwards.  A process that changes such a
+ * variable later (tests, tests/native/resample_bench) calls this to have them parsed again.  ABI 10. */
+void tio_reload_env(void);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,35 @@ if GOLDEN not in sys.path:
     sys.path.insert(0, GOLDEN)
 
 
+def _reparse_library_switches_on_environment_writes():
+    """libtio_hip.so parses its TIO_* switches once per process (``tio_reload_env`` parses them again).  The A/B tests flip
+    such switches between calls through ``os.environ`` / ``monkeypatch.setenv``; both end in ``os.putenv`` /
+    ``os.unsetenv``, so those two are wrapped here: a write to a TIO_* variable reloads the switches of a loaded library."""
+    original_put, original_unset = os.putenv, os.unsetenv
+
+    def reload_if_ours(key) -> None:
+        name = key.decode() if isinstance(key, bytes) else str(key)
+        if not name.startswith("TIO_"):
+            return
+        from torchio_amd import _lib
+
+        if _lib._functions is not None:  # (never loads the library: CPU-only boxes may not be able to)
+            _lib._functions["reload_env"]()
+
+    def putenv(key, value):
+        original_put(key, value)
+        reload_if_ours(key)
+
+    def unsetenv(key):
+        original_unset(key)
+        reload_if_ours(key)
+
+    os.putenv, os.unsetenv = putenv, unsetenv
+
+
+_reparse_library_switches_on_environment_writes()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
     config.addinivalue_line("markers", "reference: test imports the reference from /root/reference (build container only)")

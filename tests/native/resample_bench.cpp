@@ -335,6 +335,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     const std::string mix = kPaths[p].v2 ? kPaths[p].v2 : "";
     setenv("TIO_PLANNED_LEAN", mix == "nolean" ? "0" : "1", 1);
     setenv("TIO_NEAREST_KERNEL", p == 0 ? "0" : "1", 1);  // the baseline keeps nearest images on the gather kernel's exact chain
+    tio_reload_env();  // (the library parses its switches once per process otherwise)
     geom.precision = kPaths[p].fast ? TIO_PRECISION_FAST : TIO_PRECISION_EXACT;
     // a FAST call samples its float32 trilinear images within 1e-4 when every other image of the call has a kernel of its
     // own (nearest without a fill rule: resample_nearest.hpp, bit-exact); any other image pins the exact kernels for all

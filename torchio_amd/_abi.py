@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_IMAGES = 8
 
 # tio_status
@@ -137,6 +137,7 @@ HOST_MT_STATE_BYTES = 2688
 HIP_ONLY_PROTOTYPES = {
     "last_error": (C.c_char_p, []),
     "device_count": (C.c_int, []),
+    "reload_env": (None, []),
     "host_mt19937_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "host_mt19937_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "host_mt19937_plan_words": (C.c_int64, [C.c_int64]),

@@ -18,6 +18,33 @@ void set_error(const char* fmt, ...);
 int fail(int status, const char* fmt, ...);
 int check_launch(const char* what);
 
+// ---- environment switches (A/B experiments, tests): read ONCE per process -----
+// Every TIO_* switch of the library, parsed at the first use and again whenever tio_reload_env() is called
+// (tests and A/B tools change the environment between calls; the hot entry points never call getenv —
+// 13 calls per tio_resample3d until round 4, none of them safe against a concurrent setenv).
+struct EnvSwitches {
+  int nearest_kernel = 1;        // TIO_NEAREST_KERNEL (0: nearest images stay with the other images)
+  int has_nearest_eps = 0;       // TIO_NEAREST_EPS (calibration runs only)
+  float nearest_eps = 0.0f;
+  int resample_path = 0;         // TIO_RESAMPLE_PATH: 0 unset, 1 gather, 2 tile
+  int tile_variant = 0;          // TIO_TILE_VARIANT
+  int tile_lds_floats = 0;       // TIO_TILE_LDS_FLOATS
+  int tile_ablate = 0;           // TIO_TILE_ABLATE (instrumented instantiations only)
+  int resample_exact = 0;        // TIO_RESAMPLE_EXACT set: never the FAST kernels
+  int fast_kernel = 0;           // TIO_FAST_KERNEL: 0 unset, 1 brick, 2 planned
+  int planned_lean = 1;          // TIO_PLANNED_LEAN
+  int dma_packed = 1;            // TIO_DMA_PACKED
+  int exact_plan = -1;           // TIO_EXACT_PLAN: -1 unset, else its value
+  int fast_fill_recheck = 1;     // TIO_FAST_FILL_RECHECK (0: the FAST fill rule decides alone, A/B)
+  int conv_no_fuse = 0;          // TIO_CONV_NO_FUSE set
+  int conv_ring = 0;             // TIO_CONV_RING set
+  int march_segs = 0;            // TIO_MARCH_SEGS (0 unset)
+  int march_order = -1;          // TIO_MARCH_ORDER (-1 unset)
+  int min_blocks = 0;            // TIO_MIN_BLOCKS (0 unset)
+  int one_pass_blur = 1;         // TIO_ONE_PASS_BLUR (0: the two marching passes, A/B)
+};
+const EnvSwitches& env_switches();
+
 // ---- element type conversion: `.float()` on load, `.to(dtype)` on store -------
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t h) {
   return __uint_as_float(static_cast<uint32_t>(h) << 16);

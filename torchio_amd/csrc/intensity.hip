@@ -818,7 +818,7 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
   // J and K can share one pass when the whole K row sits in one 256-wide tile and both radii
   // are small: the J kernel filters every row it produces along K before storing it
   const bool fuse_jk = DT == TIO_F32 && radius[1] > 0 && radius[2] > 0 && radius[1] <= kConvMaxRadiusV4 && radius[2] <= 8 &&
-                       shape[2] <= 256 && (shape[2] & 3) == 0 && getenv("TIO_CONV_NO_FUSE") == nullptr;
+                       shape[2] <= 256 && (shape[2] & 3) == 0 && !env_switches().conv_no_fuse;
   if (fuse.any()) {
     // the pointwise stages ride on the marching I pass (loads) and the fused J+K pass (stores)
     const bool ok = DT == TIO_F32 && n_active == 3 && fuse_jk && radius[0] <= kConvMaxRadiusV4 && skip == nullptr &&
@@ -885,20 +885,20 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
           a.noise_mean_b = fuse.noise_mean_b; a.noise_std_b = fuse.noise_std_b; a.noise_seed = fuse.noise_seed;
         }
         // (the bias variant needs > 240 VGPRs beyond radius 6: the LDS ring kernel is the better choice there)
-        if (radius[axis] <= (pre_bias ? 6 : kMarchMaxRadius) && getenv("TIO_CONV_RING") == nullptr) {
+        if (radius[axis] <= (pre_bias ? 6 : kMarchMaxRadius) && !env_switches().conv_ring) {
           // register-window marching: one strip per wave, enough segments for >= 8 waves per SIMD
           a.bcs = bcs;
           a.fma = fuse.fma;
           const int64_t strips = lines;
           int want = static_cast<int>((8192 + strips - 1) / strips);
           want = std::max(1, std::min(want, std::max(1, n / 32)));
-          if (const char* env = getenv("TIO_MARCH_SEGS")) want = std::max(1, atoi(env));  // experiments
+          if (env_switches().march_segs > 0) want = env_switches().march_segs;  // experiments
           const int len = (n + want - 1) / want;
           grid.y = static_cast<unsigned>((n + len - 1) / len);
           grid.z = static_cast<unsigned>((static_cast<int64_t>(other) * bcs + kBlock / 64 - 1) / (kBlock / 64));
           lds = fused ? 4 * 272 * sizeof(float) : 0;
           a.tiles_a = 0;
-          if (const char* env = getenv("TIO_MARCH_ORDER")) a.tiles_a = atoi(env) != 0;  // experiments
+          if (env_switches().march_order >= 0) a.tiles_a = env_switches().march_order != 0;  // experiments
           if (a.tiles_a) std::swap(grid.x, grid.z);
 #define TIO_MARCH_VARIANT(RR)                                                                              \
   {                                                                                                        \
@@ -1473,7 +1473,7 @@ extern "C" int tio_channel_min(const void* x, int32_t dtype, int32_t channels, i
   uint32_t* tickets = keys + ws_cap;
   const int64_t want = (n_spatial + kBlock - 1) / kBlock;
   int64_t cap = 512;  // two blocks per CU: measured 18 us per 64 MiB channel (2048 blocks: 34 us, the atomics and block tails add up)
-  if (const char* env = getenv("TIO_MIN_BLOCKS")) cap = atoi(env) > 0 ? atoi(env) : cap;  // experiments
+  if (env_switches().min_blocks > 0) cap = env_switches().min_blocks;  // experiments
   const unsigned gx = static_cast<unsigned>(want < cap ? want : cap);
 #define TIO_MIN(DT) \
   hipLaunchKernelGGL((min_reduce_kernel<DT>), dim3(gx, static_cast<unsigned>(channels)), dim3(kBlock), 0, s, x, n_spatial, keys, tickets, out_dev)

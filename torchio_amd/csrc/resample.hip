@@ -654,8 +654,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   // nearest images without a fill rule (label maps): their own kernel (resample_nearest.hpp), bit-identical to the exact
   // chain whatever the precision mode of the call; TIO_NEAREST_KERNEL=0 keeps them with the other images (A/B)
   NearestArgs nn{};
-  const bool nn_enabled = !(getenv("TIO_NEAREST_KERNEL") != nullptr && atoi(getenv("TIO_NEAREST_KERNEL")) == 0) &&
-                          static_cast<int64_t>(a.I) * a.J <= (1LL << 24) && a.K <= (1 << 24);
+  const EnvSwitches& env = env_switches();  // (parsed once per process / tio_reload_env(): no getenv on this road)
+  const bool nn_enabled = env.nearest_kernel != 0 &&
+                          static_cast<int64_t>(a.I) * a.J <= (1LL << 24) && a.K < (1 << 24);
   a.n_images = 0;
   pv.n_images = 0;
   pv.any_linear = 1;
@@ -723,7 +724,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     const int64_t blocks = static_cast<int64_t>(nn.B) * nn.tiles_i * nn.tiles_j * nn.tiles_k;
     if (blocks >= (1LL << 31)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: grid too large");
     nn.eps = kNearestEps;
-    if (const char* env = getenv("TIO_NEAREST_EPS")) nn.eps = static_cast<float>(atof(env));  // (calibration runs only)
+    if (env.has_nearest_eps) nn.eps = env.nearest_eps;  // (calibration runs only)
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
     for (int es = 1; es <= 8; es *= 2) {  // one launch per element size present
       bool present = false;
@@ -774,18 +775,15 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   // what the staging removes); pure nearest launches keep the one-load gather kernel.
   // TIO_RESAMPLE_PATH=gather|tile overrides (A/B tests compare the two bit for bit).
   bool use_tile = a.any_linear != 0 && !any_adjoint;  // the adjoint scatters to global memory: gather kernel
-  if (const char* env = getenv("TIO_RESAMPLE_PATH")) {
-    if (strcmp(env, "gather") == 0) use_tile = false;
-    if (strcmp(env, "tile") == 0) use_tile = true;
-  }
+  if (env.resample_path == 1) use_tile = false;
+  if (env.resample_path == 2) use_tile = true;
   if (any_adjoint) use_tile = false;
   if (static_cast<int64_t>(a.Jo) * a.Ko * 8 >= (1LL << 31)) use_tile = false;  // 32-bit byte offsets inside one output plane
   if (n_in >= (1LL << 30)) use_tile = false;  // 32-bit byte offsets inside one input channel (f32 brick DMA)
   if (use_tile) {
-    int variant = 0, cap = 0;
-    if (const char* env = getenv("TIO_TILE_VARIANT")) variant = atoi(env);
-    if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) cap = atoi(env);
-    if (const char* env = getenv("TIO_TILE_ABLATE")) a.ablate = atoi(env);
+    const int variant = env.tile_variant;
+    int cap = env.tile_lds_floats;
+    a.ablate = env.tile_ablate;
     a.cp_lds = (n_cp > 0 && n_cp <= kMaxCpLds) ? ((n_cp + 3) & ~3) : 0;
     // default brick budget: whatever lets kTileBlocksPerCU blocks share the CU's 160 KiB
     // (minus 2 KiB: the hardware allocates LDS in granules, an exact third does not fit three times)
@@ -837,7 +835,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   }
     // fast intensity path: float32 trilinear images only (nearest / label images need the exact coordinates)
     const bool fast = geom->precision == TIO_PRECISION_FAST && dtmode == 0 && !a.any_nearest && variant == 0 &&
-                      getenv("TIO_RESAMPLE_EXACT") == nullptr;
+                      !env.resample_exact;
     if (fast) {
       a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
       a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;
@@ -849,11 +847,10 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       // from its 64-byte descriptor.  Needs 16-byte rows for the LDS-DMA and control cells at least a brick wide (the
       // box comes from <= 27 vertices); everything else — and TIO_FAST_KERNEL=brick, the A/B switch — runs the brick
       // kernel's FAST instantiation with its in-kernel boxes.
-      const char* fast_kernel = getenv("TIO_FAST_KERNEL");
       // (small launches keep the single-kernel road: the planning kernel and the gap before the second launch cost
       // ~10-15 us, more than the planned bricks save below ~12 k bricks; TIO_FAST_KERNEL=planned forces them)
-      const bool force_planned = fast_kernel != nullptr && strcmp(fast_kernel, "planned") == 0;
-      bool planned = !(fast_kernel != nullptr && strcmp(fast_kernel, "brick") == 0) && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned) && blocks < (1LL << 26);
+      const bool force_planned = env.fast_kernel == 2;
+      bool planned = env.fast_kernel != 1 && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned) && blocks < (1LL << 26);
       for (int i = 0; i < a.n_images; i++) planned = planned && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
       if (planned && a.cp != nullptr) {
         const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
@@ -863,11 +860,11 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       if (planned) {
         // one single-channel image (what a FAST intensity launch almost always is): the lean kernel (resample_fast.hpp),
         // whose bricks may be 8 planes thick (half the tile: twice the blocks per CU)
-        bool lean = !(getenv("TIO_PLANNED_LEAN") != nullptr && atoi(getenv("TIO_PLANNED_LEAN")) == 0);
+        bool lean = env.planned_lean != 0;
         for (int i = 0; i < a.n_images; i++) lean = lean && a.img[i].out_min == nullptr;
         const int64_t items64 = blocks;
         int cap_p = kLdsFloatsPerCU / kTileBlocksPerCU - 512;
-        if (const char* env = getenv("TIO_TILE_LDS_FLOATS")) { const int v = atoi(env); if (v > 0) cap_p = v; }
+        if (env.tile_lds_floats > 0) cap_p = env.tile_lds_floats;
         if (cap_p < kTileMinCap) cap_p = kTileMinCap;
         if (cap_p > kLdsFloatsPerCU) cap_p = kLdsFloatsPerCU;
         a.tile_cap = cap_p;
@@ -876,8 +873,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         const int n_items = static_cast<int>(items64);
         // round 3: DMA instructions that cover rows across x-plane boundaries (resample_fast.hpp: stream_stage_packed);
         // TIO_DMA_PACKED=0 switches them off in the general kernel (A/B)
-        a.dma_packed = !(getenv("TIO_DMA_PACKED") != nullptr && atoi(getenv("TIO_DMA_PACKED")) == 0);
-        if (const char* env = getenv("TIO_TILE_ABLATE")) a.ablate = atoi(env);
+        a.dma_packed = env.dma_packed;
         PlanLease lease = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
         int* plan = lease.ptr;  // (the lease is released when this function returns: after both kernels are enqueued)
         if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
@@ -932,6 +928,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           la.hx = a.size_m1[0]; la.hy = a.size_m1[1]; la.hz = a.size_m1[2];
           la.affine_first = a.affine_first; la.ablate = a.ablate;
           auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3> : resample_planned_lean_kernel<false, 16, 16, 16, 3>;
+          if (la.ablate != 0)  // TIO_TILE_ABLATE: the instrumented instantiation (experiments only)
+            kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, true>;
           if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       static_cast<int>(lds_p)) != hipSuccess)
             return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
@@ -972,10 +970,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       // control-point reads per brick cost the planner more than the brick kernel's own reduction), and so do small ones.
       // (Round 3, with the 32-lanes-per-brick planner: elastic 0.604 -> 0.622 ms, affine + elastic 0.666 -> 0.662: the exact
       // elastic kernel is bound by its coordinate chain, not by what precedes it — profiles/r03_exp23_native.log.)
-      const char* env_plan = getenv("TIO_EXACT_PLAN");
-      const bool want = variant == 0 && a.ablate == 0 && a.cp == nullptr && !(env_plan != nullptr && atoi(env_plan) == 0) &&
+      const bool want = variant == 0 && a.ablate == 0 && a.cp == nullptr && env.exact_plan != 0 &&
                         (static_cast<int64_t>(a.B) * ((a.Io + 15) / 16) * ((a.Jo + 15) / 16) * ((a.Ko + 15) / 16) >= kPlannedMinBricks ||
-                         (env_plan != nullptr && atoi(env_plan) == 2));
+                         env.exact_plan == 2);
       if (want) {
         a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
         a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;

@@ -446,11 +446,11 @@ struct PipePlan {
 
 template <int TI, int TJ, int TK>
 __device__ __forceinline__ void pipe_decode(const ResampleArgs& a, unsigned tile, PipePlan& p) {
-  const unsigned t1 = fastdiv(tile, a.magic_k, a.tiles_k);
+  const unsigned t1 = fastdiv_exact(tile, a.magic_k, a.tiles_k);
   p.kt = tile - t1 * a.tiles_k;
-  const unsigned t2 = fastdiv(t1, a.magic_j, a.tiles_j);
+  const unsigned t2 = fastdiv_exact(t1, a.magic_j, a.tiles_j);
   p.jt = t1 - t2 * a.tiles_j;
-  const unsigned t3 = fastdiv(t2, a.magic_i, a.tiles_i);
+  const unsigned t3 = fastdiv_exact(t2, a.magic_i, a.tiles_i);
   p.it = t2 - t3 * a.tiles_i;
   p.b = static_cast<int>(t3);
   p.i_begin = p.it * TI; p.j_lo = p.jt * TJ; p.k_lo = p.kt * TK;
@@ -732,10 +732,8 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
       const bool has_fill = g.fill != nullptr;
       const float fillv = has_fill ? ((const_float_ptr)g.fill)[c] : 0.0f;
       if (!first) __syncthreads();  // the previous channel's taps are read
-      if (!(a.ablate & 1)) {
-        if (a.dma_packed) stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
-        else stream_stage<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
-      }
+      if (a.dma_packed) stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+      else stream_stage<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
       if (first) {
 #pragma unroll
         for (int r = 0; r < 3; r++) col3[r] = __builtin_fmaf(f.m[4 * r + 1], fv, f.m[4 * r + 2] * fw);
@@ -754,7 +752,7 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
       __syncthreads();
       const bool track = g.out_min != nullptr && b == 0;  // block uniform
       uint32_t kmin = 0xFFFFFFFFu;
-      if (col_active && !(a.ablate & 2)) {
+      if (col_active) {
         for (;;) {
           char* o_run = out_chan + static_cast<int64_t>(run0) * slab_b;
           if (track)
@@ -839,10 +837,12 @@ __device__ __forceinline__ float lean_gather(const float* __restrict__ chan, int
 // through registers (global_load_dwordx4 + ds_write_b128) instead of the LDS-DMA, 12- and 14-plane bricks with a fourth
 // block per CU, 512-thread blocks on 16 x 16 x 32 and 8 x 16 x 32 bricks — none faster on the affine launch (the
 // 16 x 16 x 32 bricks gain 6 % on an elastic-only launch and lose 2 x on rotated boxes that outgrow 80 KB).
-// a.ablate (TIO_TILE_ABLATE, tests/native/resample_bench --ablate): 1 no DMA, 2 no sampling, 64 shader-clock stamps
-// written over the brick's first output row (instrumentation), 128 every lane samples one LDS address.
-template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK, int WAVES_PER_SIMD>
+// INSTR = true is the INSTRUMENTED instantiation (launched only when TIO_TILE_ABLATE is set: tests/native/resample_bench
+// --ablate): a.ablate 1 no DMA, 2 no sampling, 64 shader-clock stamps written over the brick's first output row, 128
+// every lane samples one LDS address.  The production instantiation (INSTR = false) carries none of it.
+template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK, int WAVES_PER_SIMD, bool INSTR = false>
 __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_kernel(const LeanArgs a) {
+  const int ablate = INSTR ? a.ablate : 0;
   constexpr int NW = TJ * TK / 64;
   static_assert((TJ * TK) % 64 == 0 && (TK & (TK - 1)) == 0, "one thread per column of the brick");
   constexpr int PLANES = TI;  // output planes per thread
@@ -855,12 +855,12 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
   // wait (left to itself the compiler fetches each kernel argument right before its first use: five round trips)
   {
     const int* plan_p = a.plan; const float* in_p = a.in;
-    asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K),
-                 "s"(a.ablate));
+    asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K));
+    if constexpr (INSTR) asm volatile("" ::"s"(a.ablate));
   }
-  const unsigned long long t_entry = (a.ablate & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_entry = (ablate & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned brick = xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items));
-  const int b = static_cast<int>(fastdiv(brick, a.bpe_magic, a.bricks_per_element));
+  const int b = static_cast<int>(fastdiv_exact(brick, a.bpe_magic, a.bricks_per_element));
   // the two scalar loads everything waits for, requested together
   const_int_ptr d = (const_int_ptr)(a.plan + a.B * 16) + static_cast<size_t>(brick) * kDescInts;
   const_float_ptr fm = (const_float_ptr)(a.plan) + b * 16;
@@ -888,13 +888,13 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
   const int kind = kind_w & 0xFF;
   bx.kind = kind; bx.interior = kind_w >> 8;
   unsigned long long t_desc = 0ull, t_issued = 0ull;
-  if (a.ablate & 64) { asm volatile("" ::"s"(kind)); t_desc = __builtin_amdgcn_s_memtime(); }
-  if (kind == kDescStaged && !(a.ablate & 1)) {  // the road to the first DMA instruction ends here
+  if (ablate & 64) { asm volatile("" ::"s"(kind)); t_desc = __builtin_amdgcn_s_memtime(); }
+  if (kind == kDescStaged && !(ablate & 1)) {  // the road to the first DMA instruction ends here
     StageLanes sl;
     sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
     stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
   }
-  if (a.ablate & 64) t_issued = __builtin_amdgcn_s_memtime();
+  if (ablate & 64) t_issued = __builtin_amdgcn_s_memtime();
 
   const int i_count = min(TI, a.Io - i_begin), nv = min(TJ, a.Jo - j_lo), nw = min(TK, a.Ko - k_lo);
   const bool col_active = (tj < nv) & (tk < nw);
@@ -962,17 +962,17 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
   float A3[3], B3[3];
   int run0 = u0;
   int run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
-  if (a.ablate & 128) {  // experiment: every lane samples the box origin (same instructions, one LDS address per wave)
+  if (ablate & 128) {  // experiment: every lane samples the box origin (same instructions, one LDS address per wave)
 #pragma unroll
     for (int r = 0; r < 3; r++) { A3[r] = 0.25f; B3[r] = 0.0f; }
   }
   unsigned long long t_ready = 0ull, t_own = 0ull, t_landed = 0ull;
-  if (a.ablate & 64) t_ready = __builtin_amdgcn_s_memtime();
+  if (ablate & 64) t_ready = __builtin_amdgcn_s_memtime();
   tile_dma_wait();
-  if (a.ablate & 64) t_own = __builtin_amdgcn_s_memtime();
+  if (ablate & 64) t_own = __builtin_amdgcn_s_memtime();
   __syncthreads();
-  if (a.ablate & 64) t_landed = __builtin_amdgcn_s_memtime();
-  if (col_active && u0 < u1 && !(a.ablate & 2)) {
+  if (ablate & 64) t_landed = __builtin_amdgcn_s_memtime();
+  if (col_active && u0 < u1 && !(ablate & 2)) {
     uint32_t kmin = 0xFFFFFFFFu;
     const bool needs_mask = has_fill & !bx.interior;
     for (;;) {
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
       run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
     }
   }
-  if (a.ablate & 64) {  // instrumentation: the block's shader-clock stamps over the first row of its own output
+  if (ablate & 64) {  // instrumentation: the block's shader-clock stamps over the first row of its own output
     const unsigned long long t_sampled = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();

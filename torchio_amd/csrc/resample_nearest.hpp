@@ -109,16 +109,19 @@ __device__ __forceinline__ int nearest_offset(float x, float y, float z, float h
 }
 
 // (a * b + c on 24-bit operands: one full-rate instruction; written out because the compiler turns __mul24(a, b) + c
-// with a scalar b into the quarter-rate v_mad_u64_u32)
+// with a scalar b into the quarter-rate v_mad_u64_u32).  UNSIGNED 24-bit multiplicands: the offsets are only used for
+// taps inside the volume (indices >= 0), and the inner product ix * J + iy runs up to I * J - 1 < 2^24 — the signed
+// form (v_mad_i32_i24, multiplicands in [-2^23, 2^23)) sign-extended it from 2^23 on and sent the "decided" voxels
+// of such a region to offset < 0, i.e. to 0 (tests/test_gpu_nearest_kernel.py::test_plane_larger_than_2_23).
 __device__ __forceinline__ int mad24(int a, int b, int c) {
   int r;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
 
 // One block per 16 x TJ x TK brick of the output (TJ * TK = 256), one column of 16 planes per thread: 16 x 4 x 64 — a wave
 // is one output row of 64 voxels: its loads touch one or two cache lines and its stores are contiguous — or 16 x 16 x 16
-// for volumes narrower than that.  The host only launches it for I * J <= 2^24 and K <= 2^24 (24-bit multiply-adds).
+// for volumes narrower than that.  The host only launches it for I * J <= 2^24 and K < 2^24 (unsigned 24-bit multiply-adds).
 template <bool ELASTIC_POSSIBLE, int ES, int TJ, int TK, int TI>
 __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs a) {
   typedef typename NearestBits<ES>::type bits_t;
@@ -133,11 +136,11 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs
                  "s"(a.mapping_batched), "s"(a.Io), "s"(a.Jo), "s"(a.Ko), "s"(a.I), "s"(a.J), "s"(a.K), "s"(a.eps), "s"(a.n_images));
   }
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned t1 = fastdiv(tile, a.magic_k, a.tiles_k);
+  const unsigned t1 = fastdiv_exact(tile, a.magic_k, a.tiles_k);
   const int kt = tile - t1 * a.tiles_k;
-  const unsigned t2 = fastdiv(t1, a.magic_j, a.tiles_j);
+  const unsigned t2 = fastdiv_exact(t1, a.magic_j, a.tiles_j);
   const int jt = t1 - t2 * a.tiles_j;
-  const unsigned t3 = fastdiv(t2, a.magic_i, a.tiles_i);
+  const unsigned t3 = fastdiv_exact(t2, a.magic_i, a.tiles_i);
   const int it = t2 - t3 * a.tiles_i;
   const int b = t3;
 

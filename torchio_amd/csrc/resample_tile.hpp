@@ -47,6 +47,16 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned
   return d == 1 ? n : __umulhi(n, magic);  // exact for n * d < 2^32
 }
 __device__ __forceinline__ unsigned fastdiv_magic(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }
+// The same with one correction step: exact for every n, d < 2^31 (q d <= n + d cannot wrap).  magic = ceil(2^32 / d), so the multiply-high is
+// floor(n / d) or one more (the excess n e / (d 2^32), e < d, is below 1); what decodes a block index uses this form —
+// block counts reach 2^31 and the lean kernel divides by the bricks of a whole batch element (B bpe^2 >= 2^32 for one
+// 672^3 volume: ADVICE r3, the last brick of element 0 went to element 1).  Scalar operands: three SALU instructions.
+__device__ __forceinline__ unsigned fastdiv_exact(unsigned n, unsigned magic, unsigned d) {
+  if (d == 1) return n;
+  unsigned q = __umulhi(n, magic);
+  if (q * d > n) q--;
+  return q;
+}
 
 // wave-wide max in 4 DPP steps + 4 readlanes (validated by tests/native/dpp_check.cpp)
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -658,11 +668,11 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
 
   // tile decode on the scalar unit: host-computed magic multipliers instead of divisions
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned t1 = fastdiv(tile, a.magic_k, a.tiles_k);
+  const unsigned t1 = fastdiv_exact(tile, a.magic_k, a.tiles_k);
   const int kt = tile - t1 * a.tiles_k;
-  const unsigned t2 = fastdiv(t1, a.magic_j, a.tiles_j);
+  const unsigned t2 = fastdiv_exact(t1, a.magic_j, a.tiles_j);
   const int jt = t1 - t2 * a.tiles_j;
-  const unsigned t3 = fastdiv(t2, a.magic_i, a.tiles_i);
+  const unsigned t3 = fastdiv_exact(t2, a.magic_i, a.tiles_i);
   const int it = t2 - t3 * a.tiles_i;
   const int b = t3;
 

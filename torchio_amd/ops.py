@@ -82,6 +82,14 @@ def get_stencil_precision() -> str:
     return _STENCIL_PRECISION
 
 
+def reload_env() -> None:
+    """Have ``libtio_hip.so`` parse its ``TIO_*`` environment switches again (it reads them once per process, at the first
+    call that needs one: ``tio_reload_env``, ABI 10).  Only A/B experiments and tests change them after start-up."""
+    from . import _lib  # noqa: PLC0415
+
+    _lib.load()[1]["reload_env"]()
+
+
 def h2d(tensor: Tensor, device) -> Tensor:
     """Upload a (small) host tensor without stalling the device.
 
@@ -157,7 +165,12 @@ class HostNormalStream:
         if status != _abi.OK:
             raise EngineError(f"tio_host_mt19937_seed failed with status {status}")
         threads = os.environ.get("TIO_HOST_RNG_THREADS")
-        self.threads = int(threads) if threads else max(1, min(32, (os.cpu_count() or 2) - 1))
+        if threads:
+            self.threads = int(threads)
+        else:  # this rank's share of the host (LOCAL_WORLD_SIZE ranks per host, the affinity mask), at most 32
+            from .distributed import host_thread_budget  # noqa: PLC0415
+
+            self.threads = host_thread_budget()
 
     @staticmethod
     def takes(shape) -> bool:
