@@ -96,8 +96,21 @@ typedef enum tio_interp {
    * the build image: the arithmetic follows its published algorithm, pinned against scipy.ndimage (mode="reflect",
    * the same extension) instead of against the package itself — "parity unpinned" in DESIGN.md.                      */
   TIO_QUADRATIC = 4,
-  TIO_CUBIC = 5
+  TIO_CUBIC = 5,
+  /* Orders 4 - 7 ("fourth" ... "seventh", ABI 10): the same road — prefilter (2 / 2 / 3 / 3 poles), then the (order + 1)^3
+   * taps.  The basis weights of these orders come from the Cox - de Boor recursion of the uniform B-spline, evaluated in
+   * float64 and rounded to float32 (every term positive: no cancellation; the truncated-power form loses four digits at
+   * order 7), identically in the oracle and on the device.  Orders 4 and 5 are pinned against scipy.ndimage like 2 and 3;
+   * scipy stops at 5, so 6 and 7 are held to what defines them: the interpolation property, partition of unity, exact
+   * reproduction of polynomials up to the order, and a float64 numpy reference built from scipy.interpolate.BSpline
+   * (tests/test_bspline.py).  Parity with the reference (torch-interpol) stays unpinned, as for orders 2 and 3.          */
+  TIO_BSPLINE4 = 6,
+  TIO_BSPLINE5 = 7,
+  TIO_BSPLINE6 = 8,
+  TIO_BSPLINE7 = 9
 } tio_interp;
+/* B-spline order of an interpolation code (0 for the others) */
+#define TIO_BSPLINE_ORDER(interp) ((interp) == TIO_QUADRATIC ? 2 : (interp) == TIO_CUBIC ? 3 : ((interp) >= TIO_BSPLINE4 && (interp) <= TIO_BSPLINE7) ? (interp) - 2 : 0)
 
 /* ------------------------------------------------------------------------ */
 /* Fused spatial resampling                                                  */
@@ -307,7 +320,8 @@ int tio_gamma_pow(const void* x, void* y, int32_t dtype, int32_t batch,
 
 /*
  * B-spline coefficients of a (B * C) stack of volumes for tio_resample3d's TIO_QUADRATIC / TIO_CUBIC images: the
- * recursive prefilter of order `order` (2: pole sqrt(8) - 3, 3: pole sqrt(3) - 2) along I, J, K with the
+ * recursive prefilter of order `order` (2: pole sqrt(8) - 3, 3: pole sqrt(3) - 2; 4 and 5: two poles, 6 and 7: three — the roots
+ * inside the unit circle of the order's B-spline polynomial) along I, J, K, one pole after the other, with the
  * half-sample-symmetric ("dct2") boundary — what grid_pull(prefilter=True, bound="dct2") applies before sampling
  * (spatial.py:1753-1760).  x has `dtype`, y is float32 of the same shape.
  */

@@ -353,15 +353,43 @@ static inline void spline_weights(float x, int order, int* low, float w[4]) {
   }
 }
 
+/* Orders 4 - 7: the order + 1 basis weights at x from the Cox - de Boor recursion of the uniform B-spline,
+ *   N_1(s) = [0 <= s < 1],   N_m(s) = (s N_{m-1}(s) + (m - s) N_{m-1}(s - 1)) / (m - 1),
+ * evaluated for the values v_j = N_m(tau + j) that are not zero (tau in [0, 1): the position inside the knot interval),
+ * in float64 (every term is positive, nothing cancels), rounded to float32 at the end.  Tap k sits at low + k and weighs
+ * v_{order - k}.  Odd orders: knots at the integers (tau = x - floor(x)); even orders: at the half-integers. */
+static inline void spline_weights_high(float x, int order, int* low, float w[8]) {
+  const int odd = order & 1;
+  const float base = odd ? floorf(x) : floorf(x + 0.5f);
+  const double tau = odd ? (double)x - (double)base : ((double)x - (double)base) + 0.5;
+  *low = (int)base - (odd ? (order - 1) / 2 : order / 2);
+  double v[8] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int m = 2; m <= order + 1; m++) {        /* v^(m)_j from v^(m-1)_j and v^(m-1)_{j-1}, highest j first (in place) */
+    const double inv = 1.0 / (double)(m - 1);
+    for (int j = m - 1; j >= 0; j--) {
+      const double same = j <= m - 2 ? v[j] : 0.0, below = j >= 1 ? v[j - 1] : 0.0;
+      v[j] = ((tau + (double)j) * same + ((double)m - tau - (double)j) * below) * inv;
+    }
+  }
+  for (int k = 0; k <= order; k++) w[k] = (float)v[order - k];
+  for (int k = order + 1; k < 8; k++) w[k] = 0.0f;
+}
+
 static float spline_sample(const float* coef, int32_t I, int32_t J, int32_t K, float vi, float vj, float vk, int order) {
   const float tiny = 5e-2f;
   if (!(vi > -tiny && vi < (float)(I - 1) + tiny && vj > -tiny && vj < (float)(J - 1) + tiny && vk > -tiny && vk < (float)(K - 1) + tiny))
     return 0.0f; /* extrapolate=False (NaN coordinates land here too) */
   int li, lj, lk;
-  float wi[4], wj[4], wk[4];
-  spline_weights(vi, order, &li, wi);
-  spline_weights(vj, order, &lj, wj);
-  spline_weights(vk, order, &lk, wk);
+  float wi[8], wj[8], wk[8];
+  if (order <= 3) {
+    spline_weights(vi, order, &li, wi);
+    spline_weights(vj, order, &lj, wj);
+    spline_weights(vk, order, &lk, wk);
+  } else {
+    spline_weights_high(vi, order, &li, wi);
+    spline_weights_high(vj, order, &lj, wj);
+    spline_weights_high(vk, order, &lk, wk);
+  }
   float val = 0.0f;
   for (int a = 0; a <= order; a++) {
     const int64_t ia = spline_reflect(li + a, I);
@@ -379,9 +407,28 @@ static float spline_sample(const float* coef, int32_t I, int32_t J, int32_t K, f
 }
 
 /* one line of the recursive prefilter, in place (stride in elements); float32 like the reference's data.float() */
+/* the poles of the order's prefilter: the roots inside the unit circle of sum_k beta^n(k) z^k (largest first) */
+static int spline_poles(int order, float z[3]) {
+  switch (order) {
+    case 2: z[0] = -0.17157287525380990f; return 1; /* sqrt(8) - 3 */
+    case 3: z[0] = -0.26794919243112270f; return 1; /* sqrt(3) - 2 */
+    case 4: z[0] = -0.36134122590022033f; z[1] = -0.013725429297339118f; return 2;
+    case 5: z[0] = -0.43057534709997358f; z[1] = -0.043096288203264665f; return 2;
+    case 6: z[0] = -0.48829458930304598f; z[1] = -0.081679271076237445f; z[2] = -0.0014141518083258169f; return 3;
+    default: z[0] = -0.53528043079643883f; z[1] = -0.12255461519232658f; z[2] = -0.0091486948096082803f; return 3;
+  }
+}
+
+static void spline_filter_pole(float* c, int64_t n, int64_t stride, float z);
 static void spline_filter_line(float* c, int64_t n, int64_t stride, int order) {
-  const float z = order == 2 ? -0.17157287525380990f : -0.26794919243112270f; /* sqrt(8) - 3, sqrt(3) - 2 */
+  float poles[3];
+  const int n_poles = spline_poles(order, poles);
   if (n < 2) return;
+  for (int p = 0; p < n_poles; p++) spline_filter_pole(c, n, stride, poles[p]);
+}
+
+/* one pole: gain, causal pass from the closed form of the mirrored series, anticausal pass */
+static void spline_filter_pole(float* c, int64_t n, int64_t stride, float z) {
   const float gain = (1.0f - z) * (1.0f - 1.0f / z);
   for (int64_t i = 0; i < n; i++) c[i * stride] = c[i * stride] * gain;
   /* causal initialisation for the half-sample symmetric extension (closed form of the infinite mirrored sum) */
@@ -404,7 +451,7 @@ static void spline_filter_line(float* c, int64_t n, int64_t stride, int order) {
 int tio_oracle_bspline_prefilter(const void* x, float* y, int32_t dtype, int64_t n_bc, const int32_t shape[3], int32_t order,
                                  void* stream) {
   (void)stream;
-  if (!x || !y || !shape || (order != 2 && order != 3) || dtype_size(dtype) == 0) return TIO_ERR_INVALID_ARGUMENT;
+  if (!x || !y || !shape || order < 2 || order > 7 || dtype_size(dtype) == 0) return TIO_ERR_INVALID_ARGUMENT;
   const int64_t I = shape[0], J = shape[1], K = shape[2], n = I * J * K;
 #pragma omp parallel for schedule(static)
   for (int64_t v = 0; v < n_bc; v++) {
@@ -549,9 +596,9 @@ int tio_oracle_resample3d(const tio_resample_geom* g, int32_t n_images,
               const int64_t base_in = ((int64_t)b * img->channels + c) * n_in;
               const int64_t base_out = ((int64_t)b * img->channels + c) * n_out;
               float val;
-              if (img->interp == TIO_QUADRATIC || img->interp == TIO_CUBIC) { /* coefficients in, float32 out */
+              if (TIO_BSPLINE_ORDER(img->interp) != 0) { /* coefficients in, float32 out */
                 ((float*)img->out)[base_out + o_idx] =
-                    spline_sample((const float*)img->in + base_in, I, J, K, vi, vj, vk, img->interp == TIO_QUADRATIC ? 2 : 3);
+                    spline_sample((const float*)img->in + base_in, I, J, K, vi, vj, vk, TIO_BSPLINE_ORDER(img->interp));
                 continue;
               }
               if (img->interp == TIO_LINEAR_ADJOINT) { /* backward of TIO_LINEAR: d(val)/d(in[tap]) = w[tap] */

@@ -13,10 +13,11 @@ from test_gpu_ops_parity import _control_points
 from test_gpu_ops_parity import _mapping
 
 pytestmark = pytest.mark.gpu
-ORDERS = {"quadratic": 2, "cubic": 3}
+ORDERS = {"quadratic": 2, "cubic": 3, "fourth": 4, "fifth": 5, "sixth": 6, "seventh": 7}
+NAMES = list(ORDERS)
 
 
-@pytest.mark.parametrize("name", ["quadratic", "cubic"])
+@pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.int16, torch.uint8])
 @pytest.mark.parametrize("shape", [(24, 20, 28), (5, 3, 2), (40, 1, 17)])
 def test_prefilter_is_bit_identical_to_the_oracle(oracle, hip, name, dtype, shape):
@@ -28,7 +29,7 @@ def test_prefilter_is_bit_identical_to_the_oracle(oracle, hip, name, dtype, shap
     assert got.dtype == torch.float32 and torch.equal(want, got.cpu())
 
 
-@pytest.mark.parametrize("name", ["quadratic", "cubic"])
+@pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("elastic", [False, True])
 @pytest.mark.parametrize("affine_first", [True, False])
 def test_sampling_is_bit_identical_to_the_oracle(oracle, hip, name, elastic, affine_first):
@@ -68,7 +69,7 @@ def test_spline_images_share_a_call_with_the_others(oracle, hip):
         assert torch.equal(w, h.cpu())
 
 
-@pytest.mark.parametrize("name", ["quadratic", "cubic"])
+@pytest.mark.parametrize("name", NAMES)
 def test_transform_with_spline_interpolation_matches_the_oracle(oracle, hip, name):
     g = torch.Generator().manual_seed(13)
     subjects = [tio.Subject(t1=tio.ScalarImage(torch.rand(1, 32, 30, 36, generator=g))) for _ in range(3)]

@@ -96,7 +96,7 @@ def test_label_maps_no_longer_hold_the_float_images_back(hip, monkeypatch, preci
         else:
             assert not torch.equal(r, o)  # the FAST kernels did run
             beyond = (r.double() - o.double()).abs() > 1e-4
-            assert int(beyond.sum()) <= 16, int(beyond.sum())  # (a fill decision within rounding of 0.5 may flip)
+            assert int(beyond.sum()) == 0, int(beyond.sum())  # (fill decisions within rounding of 0.5 take the exact chain's answer)
 
 
 @pytest.mark.parametrize("size,elastic", [(256, True), (512, False), (512, True)])
@@ -195,3 +195,24 @@ def test_label_map_on_another_grid_than_the_normalising_one(hip, monkeypatch, no
     torch.cuda.synchronize()
     assert torch.equal(reference, got)
     assert int((got != 0).sum()) > 0.3 * got.numel()
+
+
+def test_plane_larger_than_2_23(hip, monkeypatch):
+    """the label kernel's offsets are 24-bit multiply-adds; the signed form (v_mad_i32_i24) sign-extended the
+    inner product ix * J + iy from 2^23 on — a 2-D slice of 2900 x 2900 (I * J = 8.4e6 > 2^23) lost every "decided" voxel of
+    its upper half to offset 0.  Unsigned multiplicands now; compared with the all-exact road."""
+    shape = (2900, 2900, 2)
+    seg = _labels((1, 1, *shape), torch.uint8, 51)
+    mapping = torch.eye(3, 4)[None].clone()
+    mapping[0, 0, 3], mapping[0, 1, 3] = 1.25, -0.75
+    mapping[0, 0, 1], mapping[0, 1, 0] = 0.01, -0.01
+    kwargs = dict(out_shape=shape, mapping=mapping.cuda(), control_points=None, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True,
+                  interps=["nearest"], fills=[None])
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([seg], precision="exact", **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([seg], precision="exact", **kwargs)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(reference, got)
+    upper = got[0, 0, 2000:]  # rows whose ix * J lies beyond 2^23
+    assert int((upper != 0).sum()) > upper.numel() // 2

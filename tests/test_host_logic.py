@@ -90,12 +90,19 @@ def test_constructor_validation_matches_reference_errors():
         tio.Gamma()
 
 
-def test_unsupported_modes_raise_instead_of_falling_back():
+def test_every_interpolation_order_of_the_reference_is_taken():
+    """Orders 0 - 7, as names and as integers (reference: spatial.py `_INTERPOLATION_ORDERS`): none falls back, none raises
+    (orders >= 4 raised NotImplementedError until round 4)."""
     s = subject()
-    with pytest.raises(NotImplementedError, match="not implemented by the HIP engine"):
-        tio.Affine(degrees=(5, 5), image_interpolation="fourth")(s)  # (orders 2 and 3 are: tests/test_bspline.py)
-    with pytest.raises(NotImplementedError, match="one_hot_label_interpolation"):
-        tio.Affine(degrees=(5, 5), label_interpolation="label", one_hot_label_interpolation="fifth")(s)
+    for order, name in enumerate(["nearest", "linear", "quadratic", "cubic", "fourth", "fifth", "sixth", "seventh"]):
+        torch.manual_seed(3)
+        by_name = tio.Affine(degrees=(5, 5), image_interpolation=name)(s)
+        torch.manual_seed(3)
+        by_number = tio.Affine(degrees=(5, 5), image_interpolation=order)(s)
+        assert torch.equal(by_name.t1.data, by_number.t1.data)
+        assert by_name.t1.data.shape == s.t1.data.shape and torch.isfinite(by_name.t1.data).all()
+    out = tio.Affine(degrees=(5, 5), label_interpolation="label", one_hot_label_interpolation="fifth")(s)
+    assert set(out.seg.data.unique().tolist()) <= set(s.seg.data.unique().tolist()) | {0}
 
 
 # -- "label" partial-volume mode ------------------------------------------------------

@@ -149,3 +149,32 @@ def test_the_references_own_test_files_pass_through_the_binding():
             assert all(("HighOrder" in w) or ("higher_order" in w) or ("integer_order" in w) or ("file_path" in w) for w in which.split(", ")), which
         else:
             assert failed == 0 and passed > 0, (name, passed, failed, which)
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5, 6, 7])
+def test_high_order_interpolation_through_the_binding(bound, oracle, order):
+    """The reference's classes with `image_interpolation=<order>` (its own tests: TestHighOrderInterpolation,
+    tests/test_spatial.py:978-1014, cover 2 and 3): UNBOUND they need torch-interpol, which this image does not have — the
+    reference raises; BOUND they run the engine's B-spline road for every order the reference names, 2 ... 7 (VERDICT r3
+    item 9).  Against the same transform with linear interpolation: another interpolant of the same samples — close in the
+    mean, not equal — and the identity mapping returns the image (interpolating splines)."""
+    tio = bound
+    calls = []
+    original_call = oracle._call
+    oracle._call = lambda name, *args: (calls.append(name), original_call(name, *args))[1]
+    try:
+        with use_engine(oracle):
+            torch.manual_seed(4)
+            spline = tio.Affine(degrees=8, scales=(0.95, 1.05), image_interpolation=order)(_subject(tio, size=20, seed=5))
+            torch.manual_seed(4)
+            linear = tio.Affine(degrees=8, scales=(0.95, 1.05))(_subject(tio, size=20, seed=5))
+            same = tio.Resample(target=1.0, image_interpolation=order)(_subject(tio, size=12, seed=6))
+    finally:
+        oracle._call = original_call
+    assert "bspline_prefilter" in calls and "resample3d" in calls, calls  # the engine took it: no fallback to torch-interpol
+    assert type(spline["t1"]) is tio.ScalarImage and spline["t1"].data.shape == linear["t1"].data.shape
+    assert torch.equal(spline["seg"].data, linear["seg"].data)  # label maps keep their own (nearest) interpolation
+    inside = linear["t1"].data != 0
+    assert not torch.equal(spline["t1"].data, linear["t1"].data)
+    assert (spline["t1"].data[inside] - linear["t1"].data[inside]).abs().mean() < 0.3
+    assert torch.allclose(same["t1"].data, _subject(tio, size=12, seed=6)["t1"].data, atol=2e-5)

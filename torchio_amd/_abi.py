@@ -19,6 +19,7 @@ UNSUPPORTED_CONFIG = -5  # fused form not available for these arguments; nothing
 F32, F64, F16, BF16, U8, I8, I16, I32, I64 = range(9)
 # tio_interp
 NEAREST, LINEAR, LABEL_PV, LINEAR_ADJOINT, QUADRATIC, CUBIC = 0, 1, 2, 3, 4, 5
+BSPLINE4, BSPLINE5, BSPLINE6, BSPLINE7 = 6, 7, 8, 9  # B-spline orders 4 - 7 ("fourth" ... "seventh")
 # tio_pad_mode
 PAD_CONSTANT, PAD_REFLECT, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2, 3
 # tio_precision

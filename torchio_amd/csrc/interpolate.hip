@@ -391,7 +391,19 @@ __global__ __launch_bounds__(256) void bspline_axis_kernel(float* __restrict__ c
   }
   if (n < 2) return;
   float* p = c + base;
-  const float z = order == 2 ? -0.17157287525380990f : -0.26794919243112270f;
+  // the poles of the order (oracle/tio_oracle.c: spline_poles), one after the other
+  float poles[3] = {0.0f, 0.0f, 0.0f};
+  int n_poles = 1;
+  switch (order) {
+    case 2: poles[0] = -0.17157287525380990f; break;
+    case 3: poles[0] = -0.26794919243112270f; break;
+    case 4: poles[0] = -0.36134122590022033f; poles[1] = -0.013725429297339118f; n_poles = 2; break;
+    case 5: poles[0] = -0.43057534709997358f; poles[1] = -0.043096288203264665f; n_poles = 2; break;
+    case 6: poles[0] = -0.48829458930304598f; poles[1] = -0.081679271076237445f; poles[2] = -0.0014141518083258169f; n_poles = 3; break;
+    default: poles[0] = -0.53528043079643883f; poles[1] = -0.12255461519232658f; poles[2] = -0.0091486948096082803f; n_poles = 3; break;
+  }
+  for (int pole = 0; pole < n_poles; pole++) {
+  const float z = pole == 0 ? poles[0] : (pole == 1 ? poles[1] : poles[2]);
   const float gain = __fmul_rn(__fsub_rn(1.0f, z), __fsub_rn(1.0f, __fdiv_rn(1.0f, z)));
   for (int i = 0; i < n; i++) p[i * stride] = __fmul_rn(p[i * stride], gain);
   float z_n = 1.0f;
@@ -416,6 +428,7 @@ __global__ __launch_bounds__(256) void bspline_axis_kernel(float* __restrict__ c
     prev = __fmul_rn(z, __fsub_rn(prev, p[i * stride]));
     p[i * stride] = prev;
   }
+  }  // poles
 }
 
 }  // namespace tio
@@ -424,7 +437,7 @@ extern "C" int tio_bspline_prefilter(const void* x, float* y, int32_t dtype, int
                                      void* stream) {
   using namespace tio;
   if (x == nullptr || y == nullptr || shape == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bspline_prefilter: null argument");
-  if (order != 2 && order != 3) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bspline_prefilter: order %d (2 and 3 are implemented)", order);
+  if (order < 2 || order > 7) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bspline_prefilter: order %d (2 ... 7 are implemented)", order);
   if (dtype_size(dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_bspline_prefilter: dtype %d", dtype);
   if (n_bc < 0 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_bspline_prefilter: bad shape");
   if (n_bc == 0) return TIO_OK;

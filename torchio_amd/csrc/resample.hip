@@ -72,6 +72,8 @@ struct ResampleArgs {
   int tile_cap;  // floats of LDS available for one staged input brick (tile kernel)
   int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
   int dma_packed;  // planned bricks: DMA instructions cover rows across x-plane boundaries (A/B: TIO_DMA_PACKED=0)
+  int any_fill;      // an image of the launch has a fill rule
+  int fill_recheck;  // FAST kernels: voxels whose in-bounds weight is within a margin of 1/2 take the exact chain's decision (A/B: TIO_FAST_FILL_RECHECK=0)
 };
 
 constexpr int kTileI = 8;          // output slabs walked by one block
@@ -274,7 +276,77 @@ __device__ __forceinline__ void spline_weights(float x, int order, int& low, flo
   }
 }
 
+// Orders 4 - 7 (oracle/tio_oracle.c: spline_weights_high, operation for operation): the Cox - de Boor recursion of the
+// uniform B-spline in float64, v_j = N_m(tau + j), every term positive; tap k at low + k weighs v_{order - k}.
+template <int ORDER>
+__device__ __forceinline__ void spline_weights_high(float x, int& low, float (&w)[ORDER + 1]) {
+  constexpr bool odd = (ORDER & 1) != 0;
+  const float base = odd ? floorf(x) : floorf(__fadd_rn(x, 0.5f));
+  const double tau = odd ? __dsub_rn(static_cast<double>(x), static_cast<double>(base))
+                         : __dadd_rn(__dsub_rn(static_cast<double>(x), static_cast<double>(base)), 0.5);
+  low = static_cast<int>(base) - (odd ? (ORDER - 1) / 2 : ORDER / 2);
+  double v[ORDER + 1];
+  v[0] = 1.0;
+#pragma unroll
+  for (int j = 1; j <= ORDER; j++) v[j] = 0.0;
+#pragma unroll
+  for (int m = 2; m <= ORDER + 1; m++) {
+    const double inv = __ddiv_rn(1.0, static_cast<double>(m - 1));
+#pragma unroll
+    for (int j = ORDER; j >= 0; j--) {
+      if (j <= m - 1) {
+        const double same = j <= m - 2 ? v[j] : 0.0, below = j >= 1 ? v[j - 1] : 0.0;
+        v[j] = __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(tau, static_cast<double>(j)), same),
+                                   __dmul_rn(__dsub_rn(__dsub_rn(static_cast<double>(m), tau), static_cast<double>(j)), below)), inv);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k <= ORDER; k++) w[k] = static_cast<float>(v[ORDER - k]);
+}
+
+template <int ORDER>
+__device__ __forceinline__ float spline_sample_high(const float* __restrict__ coef, int I, int J, int K, float vi, float vj, float vk) {
+  const float tiny = 5e-2f;
+  if (!((vi > -tiny) & (vi < __fadd_rn(static_cast<float>(I - 1), tiny)) & (vj > -tiny) & (vj < __fadd_rn(static_cast<float>(J - 1), tiny)) &
+        (vk > -tiny) & (vk < __fadd_rn(static_cast<float>(K - 1), tiny))))
+    return 0.0f;
+  int li, lj, lk;
+  float wi[ORDER + 1], wj[ORDER + 1], wk[ORDER + 1];
+  spline_weights_high<ORDER>(vi, li, wi);
+  spline_weights_high<ORDER>(vj, lj, wj);
+  spline_weights_high<ORDER>(vk, lk, wk);
+  int kc[ORDER + 1];
+#pragma unroll
+  for (int r = 0; r <= ORDER; r++) kc[r] = spline_reflect(lk + r, K);
+  float val = 0.0f;
+#pragma unroll 1
+  for (int p = 0; p <= ORDER; p++) {
+    const int64_t ia = spline_reflect(li + p, I);
+#pragma unroll 1
+    for (int q = 0; q <= ORDER; q++) {
+      const int64_t jb = spline_reflect(lj + q, J);
+      // (wi / wj indexed by loop counters that are not unrolled: selected from registers, no scratch)
+      float wp = wi[0], wq = wj[0];
+#pragma unroll
+      for (int e = 1; e <= ORDER; e++) { wp = p == e ? wi[e] : wp; wq = q == e ? wj[e] : wq; }
+      const float wab = __fmul_rn(wp, wq);
+      const float* row = coef + (ia * J + jb) * K;
+#pragma unroll
+      for (int r = 0; r <= ORDER; r++) {
+        const float wabc = __fmul_rn(wab, wk[r]);
+        val = __fadd_rn(val, __fmul_rn(wabc, row[kc[r]]));
+      }
+    }
+  }
+  return val;
+}
+
 __device__ __forceinline__ float spline_sample(const float* __restrict__ coef, int I, int J, int K, float vi, float vj, float vk, int order) {
+  if (order == 4) return spline_sample_high<4>(coef, I, J, K, vi, vj, vk);
+  if (order == 5) return spline_sample_high<5>(coef, I, J, K, vi, vj, vk);
+  if (order == 6) return spline_sample_high<6>(coef, I, J, K, vi, vj, vk);
+  if (order == 7) return spline_sample_high<7>(coef, I, J, K, vi, vj, vk);
   const float tiny = 5e-2f;
   if (!((vi > -tiny) & (vi < __fadd_rn(static_cast<float>(I - 1), tiny)) & (vj > -tiny) & (vj < __fadd_rn(static_cast<float>(J - 1), tiny)) &
         (vk > -tiny) & (vk < __fadd_rn(static_cast<float>(K - 1), tiny))))
@@ -433,7 +505,7 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
         for (int c = 0; c < g.channels; c++) {
           const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
           static_cast<float*>(g.out)[bc * n_out + o_idx] =
-              spline_sample(static_cast<const float*>(g.in) + bc * n_in, a.I, a.J, a.K, vi, vj, vk, g.interp == TIO_QUADRATIC ? 2 : 3);
+              spline_sample(static_cast<const float*>(g.in) + bc * n_in, a.I, a.J, a.K, vi, vj, vk, TIO_BSPLINE_ORDER(g.interp));
         }
       }
       continue;
@@ -529,6 +601,7 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 
 }  // namespace tio
 
+#include "resample_exact_chain.hpp"
 #include "resample_tile.hpp"
 #include "resample_fast.hpp"
 #include "resample_nearest.hpp"
@@ -669,9 +742,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d has null data or no channels", i);
     if (dtype_size(s.dtype) == 0) return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d dtype %d", i, s.dtype);
     if (s.interp != TIO_NEAREST && s.interp != TIO_LINEAR && s.interp != TIO_LABEL_PV && s.interp != TIO_LINEAR_ADJOINT &&
-        s.interp != TIO_QUADRATIC && s.interp != TIO_CUBIC)
+        TIO_BSPLINE_ORDER(s.interp) == 0)
       return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: image %d interp %d", i, s.interp);
-    if (s.interp == TIO_QUADRATIC || s.interp == TIO_CUBIC) {
+    if (TIO_BSPLINE_ORDER(s.interp) != 0) {
       if (s.dtype != TIO_F32)
         return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_resample3d: image %d: B-spline images hold float32 coefficients (tio_bspline_prefilter)", i);
       spl.img[spl.n_images++] = ImgArgs{s.in, s.out, nullptr, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, nullptr, nullptr};
@@ -781,6 +854,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   if (static_cast<int64_t>(a.Jo) * a.Ko * 8 >= (1LL << 31)) use_tile = false;  // 32-bit byte offsets inside one output plane
   if (n_in >= (1LL << 30)) use_tile = false;  // 32-bit byte offsets inside one input channel (f32 brick DMA)
   if (use_tile) {
+    a.fill_recheck = env.fast_fill_recheck;
+    a.any_fill = 0;
+    for (int i = 0; i < a.n_images; i++) a.any_fill |= a.img[i].fill != nullptr ? 1 : 0;
     const int variant = env.tile_variant;
     int cap = env.tile_lds_floats;
     a.ablate = env.tile_ablate;
@@ -927,6 +1003,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           for (int e = 0; e < 3; e++) la.dsc[e] = a.rsp[e] * (a.affine_first ? a.half_h[e] / a.dh[e] : 1.0f);
           la.hx = a.size_m1[0]; la.hy = a.size_m1[1]; la.hz = a.size_m1[2];
           la.affine_first = a.affine_first; la.ablate = a.ablate;
+          la.mapping = a.mapping; la.mapping_batched = a.mapping_batched; la.unit_spacing = a.unit_spacing; la.fill_recheck = a.fill_recheck;
+          for (int e = 0; e < 3; e++) { la.sp[e] = a.sp[e]; la.rsp[e] = a.rsp[e]; la.den[e] = a.den[e]; la.rden[e] = a.rden[e]; }
           auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3> : resample_planned_lean_kernel<false, 16, 16, 16, 3>;
           if (la.ablate != 0)  // TIO_TILE_ABLATE: the instrumented instantiation (experiments only)
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, true>;

@@ -145,10 +145,13 @@ __device__ __forceinline__ float fast_mask(const FastTaps& ts, float x0, float y
 // G voxels have their LDS reads in flight before the first interpolation starts.  The output
 // address is a block-uniform running pointer (one plane = slab_b bytes) + this thread's byte offset.
 // TRACK: the ordered-integer key of the smallest value stored (the folded minimum of the launch's own output)
+// MASKED: the fill rule.  The FAST in-bounds weight decides; a voxel whose weight is within `margin` of 1/2 additionally
+// raises bit (plane_base + its index in the run) of `unsure`: the kernel's tail re-decides those with the reference's
+// exact chain (resample_exact_chain.hpp).  margin < 0: nothing is ever recorded (A/B: TIO_FAST_FILL_RECHECK=0).
 template <bool MASKED, int G, bool NOSTORE = false, bool TRACK = false>
 __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float az, float bxs, float bys, float bzs, const FastAddr& ta,
                                                 char* out_generic, unsigned urow, int64_t slab_b, float ox, float oy, float oz, float hx,
-                                                float hy, float hz, float fillv, uint32_t& kmin) {
+                                                float hy, float hz, float fillv, uint32_t& kmin, float margin, int plane_base, unsigned& unsure) {
   // The running pointer passes through an empty asm (to pin it to scalar registers), which hides its address space
   // from the compiler: it MUST be typed global here, or the stores become flat_store_dword — flat operations count
   // on lgkmcnt as well, so every wait for the LDS taps would also wait for the previous voxels' stores to be
@@ -177,7 +180,12 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
 #pragma unroll
     for (int q = 0; q < G; q++) {
       vals[q] = fast_finish(ts[q]);
-      if constexpr (MASKED) vals[q] = (fast_mask(ts[q], x0s[q] + ox, y0s[q] + oy, z0s[q] + oz, hx, hy, hz) > 0.5f) ? vals[q] : fillv;
+      if constexpr (MASKED) {
+        const float mk = fast_mask(ts[q], x0s[q] + ox, y0s[q] + oy, z0s[q] + oz, hx, hy, hz);
+        vals[q] = (mk > 0.5f) ? vals[q] : fillv;
+        // (a NaN weight compares false: the FAST answer — fill — stands; planes beyond the run are never raised)
+        unsure |= ((fabsf(mk - 0.5f) <= margin) & (tg + q < n)) ? (1u << (plane_base + tg + q)) : 0u;
+      }
     }
     if (tg + G <= n) {
 #pragma unroll
@@ -274,7 +282,7 @@ __device__ __forceinline__ int fast_column_line(const FastFrameT<CP>& f, const L
 template <int GMAX, bool TRACK = false>
 __device__ __forceinline__ void fast_sample_line(int len, const float (&A3)[3], const float (&B3)[3], const FastAddr& ta, char* o, unsigned urow,
                                                  int64_t slab_b, bool needs_mask, float ox, float oy, float oz, float hx, float hy, float hz,
-                                                 float fillv, uint32_t& kmin) {
+                                                 float fillv, uint32_t& kmin, float margin, int plane_base, unsigned& unsure) {
   bool masked = false;
   if (needs_mask) {
     const float el = static_cast<float>(len - 1);
@@ -287,11 +295,11 @@ __device__ __forceinline__ void fast_sample_line(int len, const float (&A3)[3], 
   }
   if (!masked) {
     if (GMAX == 8 && len > 4)
-      fast_sample_run<false, 8, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv, kmin);
+      fast_sample_run<false, 8, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv, kmin, margin, plane_base, unsure);
     else
-      fast_sample_run<false, 4, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv, kmin);
+      fast_sample_run<false, 4, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, 0.f, 0.f, 0.f, hx, hy, hz, fillv, kmin, margin, plane_base, unsure);
   } else {  // rare (waves on the volume's surface): four voxels in flight keep the register budget of the common loop
-    fast_sample_run<true, 4, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, ox, oy, oz, hx, hy, hz, fillv, kmin);
+    fast_sample_run<true, 4, false, TRACK>(len, A3[0], A3[1], A3[2], B3[0], B3[1], B3[2], ta, o, urow, slab_b, ox, oy, oz, hx, hy, hz, fillv, kmin, margin, plane_base, unsure);
   }
 }
 
@@ -496,7 +504,7 @@ __device__ __forceinline__ void pipe_vertex(const ResampleArgs& a, const FastFra
 // The plan: 16 dwords per brick, 16 floats per batch element ahead of them
 //   brick:  [0] kind | interior << 8   [1] bx0 [2] by0 [3] za [4] Lx [5] Ly [6] cpr   [7..9] C3 (float bits): the mapping
 //           of (i_begin, j_lo, k_lo) relative to the box origin   [10] b [11] i_begin [12] j_lo [13] k_lo [14] elastic
-//   batch:  [0..11] mapping rows scaled by the axis ratios (S_own - 1) / max(S_norm - 1, 1)
+//   batch:  [0..11] mapping rows scaled by the axis ratios (S_own - 1) / max(S_norm - 1, 1)   [12] margin of the fill decision
 // =====================================================================================================================
 // A group of lanes per brick, one vertex per lane: 32 lanes (27 busy) when the launch has control points — a vertex then
 // reads 24 control values, and one thread walking its 27 vertices one after the other made the planner a chain of 27
@@ -513,7 +521,13 @@ __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, 
     const float* m = a.mapping + (a.mapping_batched ? gtid * 12 : 0);
     float* fr = reinterpret_cast<float*>(plan) + gtid * 16;
     for (int q = 0; q < 12; q++) fr[q] = m[q] * ratio[q >> 2];
-    for (int q = 12; q < 16; q++) fr[q] = 0.0f;
+    {  // [12]: the margin of the fill decision for this element (resample_exact_chain.hpp)
+      float mm[12];
+      for (int q = 0; q < 12; q++) mm[q] = m[q];
+      fr[12] = fast_fill_margin(mm, static_cast<float>(a.Io), static_cast<float>(a.Jo), static_cast<float>(a.Ko), a.size_m1[0] + 1.0f,
+                                a.size_m1[1] + 1.0f, a.size_m1[2] + 1.0f);
+    }
+    for (int q = 13; q < 16; q++) fr[q] = 0.0f;
   }
   const int t = gtid / GROUP, v = gtid % GROUP;
   if (t >= n_items) return;  // (whole groups leave together: the shuffles below stay inside a group)
@@ -681,13 +695,22 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
   }
 
   if (kind == kDescSlow) {  // box beyond the LDS budget / non-finite geometry: per-voxel evaluation, global gathers (rare)
-    pipe_brick_frame(f, j_lo, k_lo);
+    // (with the reference's exact coordinate chain: gather_voxel applies the fill rule to the coordinate it is handed)
+    const float* mp = a.mapping + (a.mapping_batched ? b * 12 : 0);
+    float mm[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) mm[q] = mp[q];
+    Lerp1D lj_e{0, 0, 1.0f, 0.0f}, lk_e{0, 0, 1.0f, 0.0f};
+    if (elastic) {
+      lj_e = lerp_index(j_lo + jv, a.nj, a.Jo, a.scale_j);
+      lk_e = lerp_index(k_lo + kw, a.nk, a.Ko, a.scale_k);
+    }
     for (int im = 0; im < a.n_images; im++) {
       const ImgArgs& g = a.img[im];
       if (col_active) {
         for (int t = u0; t < u1; t++) {
           float x, y, z;
-          fast_coord(f, static_cast<float>(t), static_cast<float>(jv), static_cast<float>(kw), x, y, z);
+          exact_voxel_coords<ELASTIC_POSSIBLE>(a, mm, elastic, f.cp, lj_e, lk_e, t, static_cast<float>(j_lo + jv), static_cast<float>(k_lo + kw), x, y, z);
           gather_voxel<0>(g, a, b, n_in, n_out, t * slab + col_off, x, y, z, false);
         }
       }
@@ -752,18 +775,23 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_planne
       __syncthreads();
       const bool track = g.out_min != nullptr && b == 0;  // block uniform
       uint32_t kmin = 0xFFFFFFFFu;
+      unsigned unsure = 0u;  // planes of this column whose in-bounds weight came within the margin of 1/2
+      const float margin = (a.fill_recheck != 0 && has_fill) ? ((const_float_ptr)(plan) + b * 16)[12] : -1.0f;
       if (col_active) {
         for (;;) {
           char* o_run = out_chan + static_cast<int64_t>(run0) * slab_b;
           if (track)
-            fast_sample_line<4, true>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, has_fill & !bx.interior, ox, oy, oz, hx, hy, hz, fillv, kmin);
+            fast_sample_line<4, true>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, has_fill & !bx.interior, ox, oy, oz, hx, hy, hz, fillv, kmin, margin, run0 - u0, unsure);
           else
-            fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, has_fill & !bx.interior, ox, oy, oz, hx, hy, hz, fillv, kmin);
+            fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, has_fill & !bx.interior, ox, oy, oz, hx, hy, hz, fillv, kmin, margin, run0 - u0, unsure);
           run0 = run1;
           if (run0 >= u1) break;
           run1 = fast_column_line(f, lj, lk, planes, run0, u1, u0, C3, col3, lane, A3, B3);
         }
       }
+      if (has_fill & !bx.interior)  // (block uniform) re-decide the recorded voxels with the exact chain
+        fast_fill_tail<ELASTIC_POSSIBLE>(unsure, a, a.mapping + (a.mapping_batched ? b * 12 : 0), elastic, f.cp, lj, lk, u0, static_cast<float>(j_lo + jv),
+                                         static_cast<float>(k_lo + kw), in_chan, a.I, a.J, a.K, hx, hy, hz, fillv, out_chan, slab_b, urow, track ? &kmin : nullptr);
       if (track) publish_min(g, c, kmin);
     }
   }
@@ -803,12 +831,17 @@ struct LeanArgs {
   float dsc[3];
   float hx, hy, hz;
   int affine_first, ablate;
+  // what the exact chain of the fill recheck reads (resample_exact_chain.hpp; only voxels whose in-bounds weight is within
+  // a margin of 1/2 get there): the unscaled mapping, the spacings, the normalisation divisors
+  const float* mapping;
+  int mapping_batched, unit_spacing, fill_recheck;
+  float sp[3], rsp[3], den[3], rden[3];
 };
 
 // FAST trilinear sample straight from global memory (bricks whose box does not fit the tile, non-finite geometry): zero
 // padding, the staged path's lerp nest and separable fill rule
 __device__ __forceinline__ float lean_gather(const float* __restrict__ chan, int I, int J, int K, float x, float y, float z, bool has_fill,
-                                             float fillv, float hx, float hy, float hz) {
+                                             float fillv, float hx, float hy, float hz, float margin, int plane, unsigned& unsure) {
   if (!(fabsf(x) <= 1e30f) | !(fabsf(y) <= 1e30f) | !(fabsf(z) <= 1e30f)) return has_fill ? fillv : 0.0f;  // NaN / Inf: nothing in bounds
   const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
   FastTaps ts;
@@ -823,7 +856,11 @@ __device__ __forceinline__ float lean_gather(const float* __restrict__ chan, int
     ts.v[t] = ok ? chan[(static_cast<int64_t>(px) * J + py) * K + pz] : 0.0f;
   }
   float val = fast_finish(ts);
-  if (has_fill) val = (fast_mask(ts, x0, y0, z0, hx, hy, hz) > 0.5f) ? val : fillv;
+  if (has_fill) {
+    const float mk = fast_mask(ts, x0, y0, z0, hx, hy, hz);
+    val = (mk > 0.5f) ? val : fillv;
+    unsure |= (fabsf(mk - 0.5f) <= margin) ? (1u << plane) : 0u;  // re-decided by the kernel's tail (exact chain)
+  }
   return val;
 }
 
@@ -925,15 +962,38 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
 #pragma unroll
   for (int e = 0; e < 3; e++) { f.dsc[e] = a.dsc[e]; f.c[e] = 0.0; }
 
+  // The fill decision of voxels whose FAST in-bounds weight comes within `margin` of 1/2 (a few hundred per 256^3 volume, all
+  // in bricks on the volume's surface) is made by the reference's exact chain, in a tail behind the sampling loops
+  // (resample_exact_chain.hpp); the loops only raise the plane's bit in `unsure`.
+  unsigned unsure = 0u;
+  const float margin = (a.fill_recheck != 0 && has_fill) ? fm[12] : -1.0f;
+  auto lean_tail = [&]() {
+    if (__builtin_amdgcn_ballot_w64(unsure != 0u) == 0ull) return;
+    ExactChainArgs ea;
+    ea.ni = a.ni; ea.nj = a.nj; ea.nk = a.nk; ea.Io = a.Io; ea.unit_spacing = a.unit_spacing; ea.affine_first = a.affine_first;
+    ea.scale_i = a.sci;
+#pragma unroll
+    for (int e = 0; e < 3; e++) { ea.sp[e] = a.sp[e]; ea.rsp[e] = a.rsp[e]; ea.den[e] = a.den[e]; ea.rden[e] = a.rden[e]; }
+    ea.size_m1[0] = hx; ea.size_m1[1] = hy; ea.size_m1[2] = hz;
+    Lerp1D lj_e{0, 0, 1.0f, 0.0f}, lk_e{0, 0, 1.0f, 0.0f};
+    if (elastic) {
+      lj_e = lerp_index(j_lo + jv, a.nj, a.Jo, a.scj);
+      lk_e = lerp_index(k_lo + kw, a.nk, a.Ko, a.sck);
+    }
+    fast_fill_tail<ELASTIC_POSSIBLE>(unsure, ea, a.mapping + (a.mapping_batched ? b * 12 : 0), elastic, f.cp, lj_e, lk_e, u0, static_cast<float>(j_lo + jv),
+                                     static_cast<float>(k_lo + kw), in_chan, a.I, a.J, a.K, hx, hy, hz, fillv, out_chan, slab_b, urow);
+  };
+
   if (kind == kDescSlow) {  // box beyond the LDS budget / non-finite geometry: per-voxel evaluation, global gathers (rare)
     pipe_brick_frame(f, j_lo, k_lo);
     if (col_active) {
       for (int t = u0; t < u1; t++) {
         float x, y, z;
         fast_coord(f, static_cast<float>(t), static_cast<float>(jv), static_cast<float>(kw), x, y, z);
-        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = lean_gather(in_chan, a.I, a.J, a.K, x, y, z, has_fill, fillv, hx, hy, hz);
+        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = lean_gather(in_chan, a.I, a.J, a.K, x, y, z, has_fill, fillv, hx, hy, hz, margin, t - u0, unsure);
       }
     }
+    if (has_fill) lean_tail();
     return;
   }
 
@@ -977,12 +1037,13 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
     const bool needs_mask = has_fill & !bx.interior;
     for (;;) {
       char* o_run = out_chan + static_cast<int64_t>(run0) * slab_b;
-      fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, needs_mask, ox, oy, oz, hx, hy, hz, fillv, kmin);
+      fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, needs_mask, ox, oy, oz, hx, hy, hz, fillv, kmin, margin, run0 - u0, unsure);
       run0 = run1;
       if (run0 >= u1) break;
       run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
     }
   }
+  if (has_fill & !bx.interior) lean_tail();  // (block uniform)
   if (ablate & 64) {  // instrumentation: the block's shader-clock stamps over the first row of its own output
     const unsigned long long t_sampled = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0);

@@ -48,49 +48,8 @@ struct NearestArgs {
   NearestImg img[TIO_MAX_IMAGES];
 };
 
-// The exact coordinate chain of ONE voxel — the sequence of resample_kernel (resample.hip), operation for operation.
-template <bool ELASTIC_POSSIBLE, typename Args>
-__device__ __forceinline__ void exact_voxel_coords(const Args& a, const float (&m)[12], bool elastic, const float* __restrict__ cp,
-                                                   const Lerp1D& lj, const Lerp1D& lk, int io, float cj, float ck, float& x, float& y,
-                                                   float& z) {
-  const float ci = static_cast<float>(io);
-  float vi = 0.0f, vj = 0.0f, vk = 0.0f;
-#define TIO_AFFINE_ROW(M0, M1, M2, M3, A, B, C) \
-  __builtin_fmaf(1.0f, M3, __builtin_fmaf(C, M2, __builtin_fmaf(B, M1, __fmul_rn(A, M0))))
-  bool done = false;
-  if constexpr (ELASTIC_POSSIBLE) {
-    if (elastic) {
-      const Lerp1D li = lerp_index(io, a.ni, a.Io, a.scale_i);
-      const Disp d = cp_trilerp3(cp, a.nj * a.nk * 3, a.nk * 3, li, lj, lk);
-      float di = d.i, dj = d.j, dk = d.k;
-      if (!a.unit_spacing) {
-        di = exact_div(di, a.sp[0], a.rsp[0]);
-        dj = exact_div(dj, a.sp[1], a.rsp[1]);
-        dk = exact_div(dk, a.sp[2], a.rsp[2]);
-      }
-      if (a.affine_first) {
-        vi = __fadd_rn(TIO_AFFINE_ROW(m[0], m[1], m[2], m[3], ci, cj, ck), di);
-        vj = __fadd_rn(TIO_AFFINE_ROW(m[4], m[5], m[6], m[7], ci, cj, ck), dj);
-        vk = __fadd_rn(TIO_AFFINE_ROW(m[8], m[9], m[10], m[11], ci, cj, ck), dk);
-      } else {
-        const float ei = __fadd_rn(ci, di), ej = __fadd_rn(cj, dj), ek = __fadd_rn(ck, dk);
-        vi = TIO_AFFINE_ROW(m[0], m[1], m[2], m[3], ei, ej, ek);
-        vj = TIO_AFFINE_ROW(m[4], m[5], m[6], m[7], ei, ej, ek);
-        vk = TIO_AFFINE_ROW(m[8], m[9], m[10], m[11], ei, ej, ek);
-      }
-      done = true;
-    }
-  }
-  if (!done) {
-    vi = TIO_AFFINE_ROW(m[0], m[1], m[2], m[3], ci, cj, ck);
-    vj = TIO_AFFINE_ROW(m[4], m[5], m[6], m[7], ci, cj, ck);
-    vk = TIO_AFFINE_ROW(m[8], m[9], m[10], m[11], ci, cj, ck);
-  }
-#undef TIO_AFFINE_ROW
-  x = normalise_roundtrip(vi, a.den[0], a.rden[0], a.size_m1[0]);
-  y = normalise_roundtrip(vj, a.den[1], a.rden[1], a.size_m1[1]);
-  z = normalise_roundtrip(vk, a.den[2], a.rden[2], a.size_m1[2]);
-}
+// (exact_voxel_coords — the exact coordinate chain of ONE voxel — lives in resample_exact_chain.hpp: the FAST float kernels
+// use it as well, for the fill decision of voxels whose in-bounds weight is within rounding of 1/2)
 
 template <int ES> struct NearestBits;
 template <> struct NearestBits<1> { typedef uint8_t type; };

@@ -120,8 +120,8 @@ std::vector<at::Tensor> resample3d(at::TensorList images, at::IntArrayRef modes,
     d.channels = static_cast<int32_t>(in.size(1));
     d.dtype = dtype_code(in.scalar_type());
     d.interp = static_cast<int32_t>(modes[i]);
-    TORCH_CHECK(d.interp == TIO_NEAREST || d.interp == TIO_LINEAR || d.interp == TIO_QUADRATIC || d.interp == TIO_CUBIC,
-                "resample3d: modes are 0 (nearest), 1 (linear), 4 / 5 (quadratic / cubic B-spline over bspline_prefilter's coefficients)");
+    TORCH_CHECK(d.interp == TIO_NEAREST || d.interp == TIO_LINEAR || TIO_BSPLINE_ORDER(d.interp) != 0,
+                "resample3d: modes are 0 (nearest), 1 (linear), 4 / 5 (quadratic / cubic B-spline over bspline_prefilter's coefficients), 6 ... 9 (B-spline orders 4 ... 7)");
     const c10::optional<at::Tensor> f = fill.get(i);
     if (f.has_value() && f->defined()) TORCH_CHECK(f->numel() == in.size(1), "resample3d: a fill tensor holds one value per channel");
     d.fill_dev = opt_f32(f, keep, device, "resample3d");

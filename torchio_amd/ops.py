@@ -35,6 +35,7 @@ FLOAT_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
 INTERP_CODES = {
     "nearest": _abi.NEAREST, "linear": _abi.LINEAR, "label": _abi.LABEL_PV, "linear_adjoint": _abi.LINEAR_ADJOINT,
     "quadratic": _abi.QUADRATIC, "cubic": _abi.CUBIC,  # the image handed over holds B-spline coefficients (bspline_prefilter)
+    "fourth": _abi.BSPLINE4, "fifth": _abi.BSPLINE5, "sixth": _abi.BSPLINE6, "seventh": _abi.BSPLINE7,
 }
 
 
@@ -665,8 +666,8 @@ class Engine:
         ``interpol.grid_pull(prefilter=True, bound="dct2")`` applies before sampling (spatial.py:1753-1760)."""
         if data.ndim != 5:
             raise ValueError("expected a (B, C, I, J, K) tensor")
-        if order not in (2, 3):
-            raise NotImplementedError(f"B-spline order {order} is not implemented (2 and 3 are)")
+        if order not in (2, 3, 4, 5, 6, 7):
+            raise NotImplementedError(f"B-spline order {order} is not implemented (2 ... 7 are)")
         if _wants_grad(data):
             raise EngineError("bspline_prefilter: B-spline resampling is not differentiable here (use reference_binding)")
         data = data.detach().contiguous()

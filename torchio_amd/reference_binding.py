@@ -15,7 +15,7 @@ Five seams are replaced:
 
 Every replacement keeps the reference's original as the FALLBACK for what the engine does not take — CPU tensors
 (the engine only reads device memory), autograd through an op that has no backward here (nearest-neighbour
-resampling of a tensor that requires grad ...), interpolation orders >= 2 (torch-interpol) — so
+resampling of a tensor that requires grad ...) — so
 ``tio.Affine()(cpu_subject)``, the reference's normal use, keeps working exactly as before.  Inputs that require
 grad run on the engine like any other: trilinear resampling, bias field, blur, noise, gamma and flip have backward
 passes (``ops.Engine``).  The replacements are this package's own seam functions called with the REFERENCE's
@@ -27,6 +27,8 @@ import functools
 import importlib
 from typing import Any
 
+import torch
+
 from . import ops
 
 _ORIGINALS: dict[tuple[Any, str], Any] = {}
@@ -36,9 +38,13 @@ def _with_fallback(ours, original, tensors_of):
     """``ours`` for device tensors, ``original`` (the reference's own code) for everything the engine does not take.
 
     The decision is made UP FRONT from the tensors of the call: a tensor that does not live where the engine computes
-    (a host tensor, for the HIP engine) goes to the reference without touching the engine.  Errors of the engine path
-    fall back only while nothing has been written (the images of the batch are still the same tensor objects); an error
-    after the first image was replaced is re-raised — falling back then would apply the transform to that image twice.
+    (a host tensor, for the HIP engine) goes to the reference without touching the engine.  Of the engine path's errors
+    only the two that MEAN "not taken" fall back — ``EngineError`` and ``NotImplementedError`` — and only while nothing has
+    been written (the images of the batch are still the same tensor objects; after the first image was replaced falling
+    back would apply the transform to that image twice: re-raised).  A ``TypeError`` / ``ValueError`` is a bug on the engine
+    path (bad shapes, marshalling) or a genuine argument error and surfaces as such (swallowing them degraded
+    silently to the slow host path).  The global RNG state is put back before the original runs, so that a fallback draws
+    what the reference alone would have drawn.
     """
     @functools.wraps(original)
     def seam(*args, **kwargs):
@@ -49,12 +55,14 @@ def _with_fallback(ours, original, tensors_of):
         wanted = ops._ENGINE.device_type if ops._ENGINE is not None else "cuda"
         if any(getattr(t, "device", None) is None or t.device.type != wanted for t in before):
             return original(*args, **kwargs)  # the engine only reads device memory
+        rng_state = torch.get_rng_state()
         try:
             return ours(*args, **kwargs)
-        except (ops.EngineError, NotImplementedError, TypeError, ValueError):
+        except (ops.EngineError, NotImplementedError):
             after = list(tensors_of(*args, **kwargs))
             if len(after) != len(before) or any(a is not b for a, b in zip(after, before)):
                 raise
+            torch.set_rng_state(rng_state)  # the engine path may have consumed draws
             return original(*args, **kwargs)
 
     seam.__tio_amd_original__ = original

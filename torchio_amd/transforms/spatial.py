@@ -721,18 +721,13 @@ def _apply_spatial_to_batch(
         data = img_batch.data
         table, pad = None, 0.0
         if interpolation == LABEL_INTERPOLATION:  # only reachable for label maps (validated by the constructors)
-            if _ORDERS[one_hot_label_interpolation] > 3:
-                raise NotImplementedError(
-                    f'one_hot_label_interpolation "{one_hot_label_interpolation}" is not implemented by the HIP engine'
-                    ' (supported: "nearest", "linear", "quadratic", "cubic")'
-                )
             if data.shape[1] > 1:
                 # already one-hot / probabilistic: channels resampled as they are, zero outside,
                 # floating-point result (spatial.py:1345-1358)
                 work = data.float()
                 if antialias:
                     work = _antialias(engine, work, in_affine, out_affine)
-                if _ORDERS[one_hot_label_interpolation] in (2, 3):
+                if _ORDERS[one_hot_label_interpolation] >= 2:
                     coefficients = engine.bspline_prefilter(work, _ORDERS[one_hot_label_interpolation])
                     sampled = resample([coefficients], [one_hot_label_interpolation], [None], gated=False)[0]
                     sampled = sampled.to(data.dtype) if data.dtype.is_floating_point else sampled
@@ -756,7 +751,7 @@ def _apply_spatial_to_batch(
                 fill = None
                 table = engine.unique_labels(data)  # torch.unique(data), sorted; sizes the reference's one-hot (spatial.py:1360)
                 pad = float(default_pad_label)
-        elif _ORDERS[interpolation] in (2, 3):
+        elif _ORDERS[interpolation] >= 2:  # B-spline orders 2 - 7
             # interpol.grid_pull(data.float(), grid, interpolation=order, bound="dct2", extrapolate=False, prefilter=True)
             # .to(data.dtype) (spatial.py:1734-1761, 1860-1878): coefficients first, then the (order + 1)^3-tap sum at the
             # voxel coordinates; zero outside the field of view (the reference does not apply its fill value here).
@@ -769,11 +764,6 @@ def _apply_spatial_to_batch(
                 sampled = torch.where(rows.view(-1, 1, 1, 1, 1), data, sampled)
             finished[name] = sampled
             continue
-        elif _ORDERS[interpolation] > 3:
-            raise NotImplementedError(
-                f'interpolation "{interpolation}" is not implemented by the HIP engine (B-spline orders 2 and 3 are: '
-                '"quadratic", "cubic"; besides "nearest", "linear")'
-            )
         else:
             fill = _fill_value(engine, img_batch, default_pad_value=default_pad_value, default_pad_label=default_pad_label)
             if antialias and not is_label:
@@ -847,7 +837,7 @@ def _label_partial_volume_composite(
     one_hot = (data[:, :1] == labels.view(1, -1, 1, 1, 1)).float()
     if antialias:
         one_hot = _antialias(engine, one_hot, in_affine, out_affine)
-    if _ORDERS[one_hot_label_interpolation] in (2, 3):  # B-spline channels (interpol.grid_pull in the reference; §4.9 of DESIGN.md)
+    if _ORDERS[one_hot_label_interpolation] >= 2:  # B-spline channels, orders 2 - 7 (interpol.grid_pull in the reference; §4.9 of DESIGN.md)
         coefficients = engine.bspline_prefilter(one_hot, _ORDERS[one_hot_label_interpolation])
         sampled = resample([coefficients], [one_hot_label_interpolation], [None], gated=False)[0]
     else:
