@@ -100,25 +100,34 @@ def cpu_reference_ops_baseline(size: int, seed: int) -> dict:
         aten_pipeline.compose_step(data, rng.manual_seed(7))
         return time.perf_counter() - start
 
+    legs = {}
     try:
-        torch.set_num_threads(cores)
-        run()  # warm-up (page-in, thread pool, oneDNN primitive selection)
-        all_cores = sorted(run() for _ in range(2))
-        torch.set_num_threads(1)
-        one_thread = run()
+        # all cores (the protocol's leg), a moderate count (256 hardware threads oversubscribe these memory-bound ATen kernels:
+        # measured on the MI355X box's host 10.4 s per volume on 256 threads against 5.3 s on ONE) and one thread
+        for threads in sorted({cores, min(cores, 32), 1}, reverse=True):
+            torch.set_num_threads(threads)
+            if threads == cores:
+                run()  # warm-up (page-in, thread pool, oneDNN primitive selection)
+            times = sorted(run() for _ in range(2 if threads == cores else 1))
+            legs[threads] = times
     finally:
         torch.set_num_threads(previous)
+    best_threads = min(legs, key=lambda t: legs[t][0])
+    best = legs[best_threads][0]
     return {
-        "value": 1.0 / all_cores[0],
+        "value": 1.0 / best,
         "unit": "volumes/s",
-        "cores": cores,
+        "cores": best_threads,
         "kind": "port",
         "what": "the reference's own CPU op sequence (F.grid_sample x2 per resampling, F.interpolate, replicate pad + F.conv3d, "
                 "torch.randn) on torch-CPU ATen kernels — the arithmetic the reference executes; only its Python glue is restated "
-                "(tests/aten_pipeline.py), because /root/reference does not exist on this box",
-        "sample": f"1 x 1x{size}^3 f32 volume per run: warm-up + 2 runs on {cores} threads (min / max {all_cores[0]:.2f} / {all_cores[-1]:.2f} s), 1 run on 1 thread",
-        "seconds_per_volume": all_cores[0],
-        "one_thread": {"value": 1.0 / one_thread, "unit": "volumes/s", "cores": 1, "seconds_per_volume": one_thread},
+                "(tests/aten_pipeline.py), because /root/reference does not exist on this box.  `value` is the FASTEST of the legs",
+        "sample": f"1 x 1x{size}^3 f32 volume per run; legs (threads: seconds per volume): "
+                  + ", ".join(f"{t}: {legs[t][0]:.2f}" for t in sorted(legs, reverse=True)),
+        "host_cpus": cores,
+        "seconds_per_volume": best,
+        "all_cores": {"value": 1.0 / legs[cores][0], "unit": "volumes/s", "cores": cores, "seconds_per_volume": legs[cores][0]},
+        "one_thread": {"value": 1.0 / legs[1][0], "unit": "volumes/s", "cores": 1, "seconds_per_volume": legs[1][0]},
     }
 
 
@@ -521,8 +530,9 @@ def main() -> None:
             # BASELINE.md holds no published number for this metric, so `vs_baseline` stays null (the bench contract); the ratios
             # to the CPU path measured here are reported under their own names
             line["vs_cpu_reference_ops"] = {
-                "headline_over_all_cores": line["value"] / line["cpu_baseline"]["value"],
-                "reference_identical_over_all_cores": (line.get("value_reference_identical") or 0.0) / line["cpu_baseline"]["value"] or None,
+                "headline_over_best_leg": line["value"] / line["cpu_baseline"]["value"],
+                "reference_identical_over_best_leg": (line.get("value_reference_identical") or 0.0) / line["cpu_baseline"]["value"] or None,
+                "headline_over_all_cores": line["value"] / line["cpu_baseline"]["all_cores"]["value"],
                 "headline_over_one_thread": line["value"] / line["cpu_baseline"]["one_thread"]["value"],
             }
         print(json.dumps(line), flush=True)

@@ -9,7 +9,8 @@ NATIVE=tests/native/_build
 for step in "$@"; do
   case "$step" in
     tests)
-      timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/r4_gpu_tests.txt; tail -5 gpurun_out/r4_gpu_tests.txt ;;
+      timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -200 > gpurun_out/r4_gpu_tests.txt
+      grep -v "Warning\|^$\|warnings.html\|^  " gpurun_out/r4_gpu_tests.txt | tail -40 ;;
     parity)
       (cd $NATIVE && timeout 300 ./resample_bench --cases parity 2>&1 | tail -5) > gpurun_out/r4_native_parity.txt; cat gpurun_out/r4_native_parity.txt ;;
     ab_fast)

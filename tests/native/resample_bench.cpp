@@ -341,7 +341,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     // own (nearest without a fill rule: resample_nearest.hpp, bit-exact); any other image pins the exact kernels for all
     bool fast_set = true;
     for (const Image& im : cs.images)
-      fast_set &= (im.dtype == TIO_F32 && im.interp == TIO_LINEAR) || (im.interp == TIO_NEAREST && !im.with_fill && p != 0);
+      fast_set &= (im.dtype == TIO_F32 && im.interp == TIO_LINEAR) || (im.interp == TIO_NEAREST && p != 0);  // (round 4: with or without a fill rule)
     const bool fast_call = kPaths[p].fast && fast_set;
     for (Image& im : cs.images) HIP_CHECK(hipMemset(im.d_out, 0xCD, static_cast<size_t>(B) * im.channels * n_out * dtype_bytes(im.dtype)));
     int st = tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);

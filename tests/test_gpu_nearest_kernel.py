@@ -216,3 +216,91 @@ def test_plane_larger_than_2_23(hip, monkeypatch):
     assert torch.equal(reference, got)
     upper = got[0, 0, 2000:]  # rows whose ix * J lies beyond 2^23
     assert int((upper != 0).sum()) > upper.numel() // 2
+
+
+# ---- nearest images WITH a fill rule (round 4): `mask > 0.5 ? nearest tap : fill`, the mask trilinear (spatial.py:1719-1728) -----
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int16, torch.int32, torch.int64, torch.float32, torch.float16, torch.float64])
+@pytest.mark.parametrize("elastic", [False, True])
+def test_nearest_images_with_a_fill_value_match_the_oracle(oracle, hip, dtype, elastic):
+    batch, shape = 2, (36, 30, 70)
+    data = _labels((batch, 2, *shape), dtype, 61, device="cpu")
+    kwargs = dict(
+        out_shape=shape, mapping=_mapping(batch, 62, scale=0.1, shift=5.0),
+        control_points=_control_points(batch, (4, 4, 4), 63, amplitude=4.0) if elastic else None, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1),
+        affine_first=True, interps=["nearest"], fills=[torch.tensor([9.0, 11.0])],
+    )
+    cpu, gpu = _both(oracle, hip, "resample3d", ([data],), **kwargs)
+    assert torch.equal(cpu[0], gpu[0].cpu())
+    assert int((gpu[0][:, 0] == 9).sum()) > 100 and int((gpu[0][:, 1] == 11).sum()) > 100  # the fill value does show
+
+
+@pytest.mark.parametrize("size", [256])
+@pytest.mark.parametrize("elastic", [False, True])
+def test_full_size_label_maps_with_a_pad_label_are_bit_identical_to_the_exact_road(hip, monkeypatch, size, elastic):
+    batch = 2
+    seg = _labels((batch, 1, size, size, size), torch.int16, 71)
+    kwargs = dict(
+        out_shape=(size, size, size), mapping=_mapping(batch, 72, scale=0.1, shift=6.0).cuda(),
+        control_points=_control_points(batch, (7, 7, 7), 73, amplitude=6.0).cuda() if elastic else None, in_spacing=(1, 1, 1),
+        out_spacing=(1, 1, 1), affine_first=True, interps=["nearest"], fills=[torch.tensor([200.0], device="cuda")],
+    )
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([seg], precision="exact", **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([seg], precision="exact", **kwargs)[0]
+    torch.cuda.synchronize()
+    assert int((reference == 200).sum()) > 10_000
+    assert torch.equal(reference, got), int((reference != got).sum())
+
+
+def test_label_fill_decisions_on_a_plane_that_sits_on_the_threshold(hip, monkeypatch):
+    """The geometry of test_gpu_resample_planned.py: a whole output plane with in-bounds weights 0.50013 ... 0.49987."""
+    batch, size = 2, 128
+    seg = _labels((batch, 1, size, size, size), torch.uint8, 81) + 1  # (labels 1 ... 7: the zero padding is recognisable too)
+    mapping = torch.eye(3, 4).repeat(batch, 1, 1)
+    for b in range(batch):
+        mapping[b, 0, 1] = 2e-6 * (b + 1)
+        mapping[b, 0, 3] = 0.5 - 1.3e-4 * (b + 1)
+        mapping[b, 1, 3], mapping[b, 2, 3] = 0.37, -0.21
+    kwargs = dict(out_shape=(size, size, size), mapping=mapping.cuda(), control_points=None, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1),
+                  affine_first=True, interps=["nearest"], fills=[torch.tensor([99.0], device="cuda")])
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([seg], precision="exact", **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([seg], precision="exact", **kwargs)[0]
+    torch.cuda.synchronize()
+    last = reference[:, 0, -1]
+    assert 0.05 < float((last == 99).float().mean()) < 0.95  # both answers occur on the plane
+    assert torch.equal(reference, got), int((reference != got).sum())
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_a_label_map_with_a_pad_label_no_longer_holds_the_float_images_back(hip, monkeypatch, precision):
+    """Config 5's shape with `default_pad_label != 0`: two float images and a label map WITH a fill value in one call.  The
+    labels are bit-identical to the all-exact road in both precision modes; in fast mode the float images run the FAST
+    kernels (not bit-identical to the exact ones, within their tolerance, fill decisions identical)."""
+    batch, shape = 3, (128, 128, 128)
+    g = torch.Generator(device="cuda").manual_seed(91)
+    t1 = torch.rand(batch, 1, *shape, generator=g, device="cuda")
+    t2 = torch.rand(batch, 1, *shape, generator=g, device="cuda") + 1
+    seg = _labels((batch, 1, *shape), torch.int16, 93)
+    kwargs = dict(
+        out_shape=shape, mapping=_mapping(batch, 95, scale=0.08, shift=4.0).cuda(), control_points=_control_points(batch, (7, 7, 7), 97, amplitude=5.0).cuda(),
+        in_spacing=(1, 1, 1), out_spacing=(1, 1, 1), affine_first=True, interps=["linear", "linear", "nearest"],
+        fills=[torch.tensor([-50.0], device="cuda"), torch.tensor([-60.0], device="cuda"), torch.tensor([5.0], device="cuda")],
+    )
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([t1, t2, seg], precision="exact", **kwargs)
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    monkeypatch.setenv("TIO_FAST_KERNEL", "planned")
+    got = hip.resample3d([t1, t2, seg], precision=precision, **kwargs)
+    torch.cuda.synchronize()
+    assert torch.equal(reference[2], got[2])
+    for r, o, fill in zip(reference[:2], got[:2], (-50.0, -60.0)):
+        if precision == "exact":
+            assert torch.equal(r, o)
+        else:
+            assert not torch.equal(r, o)  # the FAST kernels did run
+            assert int(((r == fill) != (o == fill)).sum()) == 0
+            assert float((r.double() - o.double()).abs().max()) <= 1e-4

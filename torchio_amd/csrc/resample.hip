@@ -762,8 +762,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       pv.img[pv.n_images++] = ImgArgs{s.in, s.out, nullptr, 1, s.dtype, s.interp, s.labels_dev, s.n_labels, s.pad_label, nullptr, nullptr};
       continue;
     }
-    if (nn_enabled && s.interp == TIO_NEAREST && s.fill_dev == nullptr && s.out_min_dev == nullptr) {
-      nn.img[nn.n_images++] = NearestImg{s.in, s.out, s.channels, dtype_size(s.dtype)};
+    if (nn_enabled && s.interp == TIO_NEAREST && s.out_min_dev == nullptr) {  // (with or without a fill rule: round 4)
+      nn.img[nn.n_images++] = NearestImg{s.in, s.out, s.channels, dtype_size(s.dtype), s.fill_dev, s.dtype};
+      if (s.fill_dev != nullptr) nn.any_fill = 1;
       continue;
     }
     a.img[a.n_images++] = ImgArgs{s.in, s.out, s.fill_dev, s.channels, s.dtype, s.interp, nullptr, 0, 0.0, s.out_min_dev, nullptr};

@@ -50,10 +50,12 @@ def set_resample_precision(mode: str) -> None:
     ``"fast"`` lets the float32 trilinear images of a call skip the coordinates' normalise /
     un-normalise round trip and interpolate with nested fma lerps: the same interpolant, results
     within ~1e-5 of the exact ones on unit-range data (the contract for intensities is 1e-4
-    relative), ~25 % less kernel time.  Label maps resampled with ``"nearest"`` are bit-identical
-    to the reference in either mode (their own kernel, ``csrc/resample_nearest.hpp``); a
-    ``"label"`` (partial-volume) image, or a nearest image with a fill rule, keeps the whole call
-    exact.
+    relative), ~25 % less kernel time; the fill decision (``mask > 0.5``) of every voxel is the
+    reference's in both modes (voxels within rounding of the threshold are re-decided with the exact
+    coordinate chain).  Label maps resampled with ``"nearest"`` — with or without a fill value
+    (``default_pad_label``) — and ``"label"`` (partial-volume) images are bit-identical to the
+    reference in either mode: they run their own kernels inside the call and no longer hold the float
+    images of the same call back.
     """
     global _RESAMPLE_PRECISION
     if mode not in PRECISION_CODES:

@@ -131,13 +131,3 @@ class Noise(IntensityTransform):
                     work, mean_arg, std_arg, rician=rician, philox_seed=(index << 32) | int(seed), keep=keep_arg
                 )
         return batch
-
-
-def _sample_noise(data: Tensor, mean, std, generator: torch.Generator) -> Tensor:
-    """``mean + std * N(0, 1)`` shaped like *data* from a CPU generator (functional seam S4, noise.py:166-178).
-
-    Kept for API parity with the reference; the transform itself hands the raw
-    draws to the kernel, which applies ``mean + std * z`` in the same order.
-    """
-    base = torch.randn(data.shape, generator=generator).to(data.device)
-    return mean + std * base

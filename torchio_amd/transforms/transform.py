@@ -90,16 +90,18 @@ class Transform(nn.Module):
             data = _copy.deepcopy(data)
         return self._forward(data)
 
-    def _forward(self, data: Any) -> Any:
+    def _forward(self, data: Any, *, _gated: bool = False) -> Any:
         batch, unwrap = _wrap(data)
+        # the p-gate comes first: a transform that does not apply moves nothing (staging in front of the gate
+        # paid a PCIe round trip for a skipped transform)
+        if not _gated and not self._per_instance_p_active(batch) and torch.rand(1).item() >= self.p:
+            return unwrap(batch)
         home = _stage_on_engine_device(batch)
         if home is not None:  # host-resident data on the HIP engine: through the device and back (see the helper)
             try:
-                return unwrap(_return_home(self._forward(batch), home))
+                return unwrap(_return_home(self._forward(batch, _gated=True), home))
             finally:
                 _return_home(batch, home)
-        if not self._per_instance_p_active(batch) and torch.rand(1).item() >= self.p:
-            return unwrap(batch)
         params = self.make_params(batch)
         batch = self.apply_transform(batch, params)
         if not _all_gated_out(params):
@@ -267,23 +269,36 @@ def _stage_on_engine_device(batch: SubjectsBatch):
     images = batch.images
     if not images:
         return None
-    first = next(iter(images.values()))
-    raw = getattr(first, "_data", None)
-    if raw is None or raw.device.type != "cpu":
+    on_host = [name for name, image in images.items() if getattr(image, "_data", None) is not None and image._data.device.type == "cpu"]
+    if not on_host:
         return None
     engine = ops._ENGINE
     if engine is not None and engine.device_type != "cuda":
         return None
     if not torch.cuda.is_available():
         return None
-    home = raw.device
-    batch.to(torch.device("cuda", torch.cuda.current_device()))
-    return home
+    if not torch.cuda.is_initialized() and torch.utils.data.get_worker_info() is not None:
+        # a DataLoader worker PROCESS: initialising the device runtime in every forked worker is never what a pipeline
+        # wants — say so instead of doing it silently (transform on the main process, or hand over device tensors)
+        raise ops.EngineError(
+            "host-resident subject inside a DataLoader worker process: the HIP engine computes on the GPU; transform in the "
+            "main process (Queue's worker THREADS are fine) or move the subject to the device first"
+        )
+    # every image is staged on its own and remembers its own home (a subject may mix host and device images)
+    homes = {name: images[name]._data.device for name in on_host}
+    device = torch.device("cuda", torch.cuda.current_device())
+    for name in on_host:
+        images[name].to(device)
+    return homes
 
 
-def _return_home(result, home):
-    if isinstance(result, (SubjectsBatch, ImagesBatch)):
-        result.to(home)
+def _return_home(result, homes):
+    if isinstance(result, SubjectsBatch):
+        for name, device in homes.items():
+            if name in result.images:
+                result.images[name].to(device)
+    elif isinstance(result, ImagesBatch):
+        result.to(next(iter(homes.values())))
     return result
 
 
