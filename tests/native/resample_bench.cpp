@@ -388,9 +388,17 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
         if (flips) printf("  [%zu fill flips]", flips);
         continue;
       }
+      const size_t before_first = diff_first;
+      size_t first_bad = 0;
       for (size_t e = 0; e < got.size() / es; e++) {
-        if (memcmp(&got[e * es], &first[i][e * es], es) != 0) diff_first++;
+        if (memcmp(&got[e * es], &first[i][e * es], es) != 0) { if (diff_first == before_first) first_bad = e; diff_first++; }
         if (check_oracle && memcmp(&got[e * es], &expect[i][e * es], es) != 0) diff_oracle++;
+      }
+      if (diff_first != before_first) {  // which image, where, and what was stored (diagnosis of a failing case)
+        long long g = 0, w = 0;
+        memcpy(&g, &got[first_bad * es], es); memcpy(&w, &first[i][first_bad * es], es);
+        printf("  [image %zu: %zu voxels differ, first at %zu (b %zu): got 0x%llx want 0x%llx]", i, diff_first - before_first, first_bad,
+               first_bad / (static_cast<size_t>(im.channels) * n_out), g, w);
       }
     }
     printf("%-34s %-13s", cs.name.c_str(), kPaths[p].name);

@@ -399,7 +399,9 @@ __device__ __forceinline__ int stream_stage(float* __restrict__ tile, const floa
 // instead of scalar pointer increments: a handful of vector instructions per DMA instruction.
 template <int NW>
 __device__ __forceinline__ int stream_stage_packed(float* __restrict__ tile, const float* __restrict__ src, const StreamBox& bx, int I, int J,
-                                                    int K, int wave, int lane, StageLanes& sl) {
+                                                    int K, int wave, int lane, StageLanes& sl, int skip_mod = 0) {
+  // skip_mod (instrumented instantiation only, --ablate 256 / 512): every skip_mod-th DMA instruction of a wave is NOT issued
+  // (the tile keeps stale data: timing experiment — how much of the launch is the number of line requests)
   typedef __attribute__((address_space(1))) const char* global_byte_ptr;
   stage_lanes(sl, bx.cpr, K, lane);
   const int rpi = sl.rpi;
@@ -424,8 +426,9 @@ __device__ __forceinline__ int stream_stage_packed(float* __restrict__ tile, con
   float* lp = tile + wave * dgroup;
   int issued = 0;
   const bool ch_ok = static_cast<unsigned>(bx.za + sl.gz_rel) < static_cast<unsigned>(K);
-  for (int n = wave; n < n_instr; n += NW) {
-    const bool in_box = sl.lane_ok & (row < total_rows);
+  int it = 0;
+  for (int n = wave; n < n_instr; n += NW, it++) {
+    const bool in_box = sl.lane_ok & (row < total_rows) & !(skip_mod > 0 && (it % skip_mod) == skip_mod - 1);
     if (bx.interior) {
       if (in_box) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
       issued++;
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
   if (kind == kDescStaged && !(ablate & 1)) {  // the road to the first DMA instruction ends here
     StageLanes sl;
     sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
-    stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+    stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl, INSTR ? ((ablate & 256) ? 3 : ((ablate & 512) ? 2 : 0)) : 0);
   }
   if (ablate & 64) t_issued = __builtin_amdgcn_s_memtime();
 
