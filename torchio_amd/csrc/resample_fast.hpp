@@ -397,7 +397,7 @@ __device__ __forceinline__ int stream_stage(float* __restrict__ tile, const floa
 // vector-memory instruction costs this kernel's CU about the same whatever it moves (profiles/r03_resample.md), so the
 // count is what matters.  The price is a per-lane address (row -> x-plane and row inside it, advanced incrementally)
 // instead of scalar pointer increments: a handful of vector instructions per DMA instruction.
-template <int NW>
+template <int NW, int AUX = 0>
 __device__ __forceinline__ int stream_stage_packed(float* __restrict__ tile, const float* __restrict__ src, const StreamBox& bx, int I, int J,
                                                     int K, int wave, int lane, StageLanes& sl, int skip_mod = 0) {
   // skip_mod (instrumented instantiation only, --ablate 256 / 512): every skip_mod-th DMA instruction of a wave is NOT issued
@@ -430,13 +430,13 @@ __device__ __forceinline__ int stream_stage_packed(float* __restrict__ tile, con
   for (int n = wave; n < n_instr; n += NW, it++) {
     const bool in_box = sl.lane_ok & (row < total_rows) & !(skip_mod > 0 && (it % skip_mod) == skip_mod - 1);
     if (bx.interior) {
-      if (in_box) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
+      if (in_box) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, AUX);
       issued++;
     } else {
       const bool in_vol = in_box & ch_ok & (static_cast<unsigned>(bx.bx0 + p) < static_cast<unsigned>(I)) &
                           (static_cast<unsigned>(bx.by0 + r) < static_cast<unsigned>(J));
       if (__builtin_amdgcn_ballot_w64(in_vol) != 0ull) issued++;
-      if (in_vol) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
+      if (in_vol) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, AUX);
       else if (in_box) *reinterpret_cast<float4*>(lp + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     row += step; p += step_p; r += step_r; off += step_b;
@@ -932,7 +932,10 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
   if (kind == kDescStaged && !(ablate & 1)) {  // the road to the first DMA instruction ends here
     StageLanes sl;
     sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
-    stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl, INSTR ? ((ablate & 256) ? 3 : ((ablate & 512) ? 2 : 0)) : 0);
+    if (INSTR && (ablate & 2048))  // experiment: the box requested with the nontemporal hint
+      stream_stage_packed<NW, 2>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl);
+    else
+      stream_stage_packed<NW>(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane, sl, INSTR ? ((ablate & 256) ? 3 : ((ablate & 512) ? 2 : 0)) : 0);
   }
   if (ablate & 64) t_issued = __builtin_amdgcn_s_memtime();
 
