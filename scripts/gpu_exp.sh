@@ -35,9 +35,21 @@ for step in "$@"; do
     stencil)
       timeout 200 python scripts/bench_blur_stages.py 2>&1 | tail -20 | tee gpurun_out/r4_stencil.log ;;
     prof)
-      cd /tmp && export TMPDIR=/tmp
-      timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r4_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --no-cpu-baseline --no-aten-baseline --no-other-configs --no-mode-matrix > $GRAFT_REPO_ROOT/gpurun_out/r4_prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/r4_prof.err
-      cd $GRAFT_REPO_ROOT; find gpurun_out/r4_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -25 {}' ;;
+      # rocprofv3 kernel statistics of (1) the headline bench command, (2) the reference-identical (library default) mode
+      R=$PWD; O=$R/gpurun_out/r4_prof; mkdir -p $O
+      (cd /tmp && export TMPDIR=/tmp
+       timeout 300 rocprofv3 --kernel-trace --stats -d $O -o headline --output-format csv -- python $R/bench.py --steps 20 --no-cpu-baseline --no-aten-baseline --no-other-configs --no-mode-matrix > $O/headline.log 2>&1
+       timeout 300 rocprofv3 --kernel-trace --stats -d $O -o reference --output-format csv -- python $R/bench.py --steps 20 --noise-rng reference --resample-precision exact --no-cpu-baseline --no-aten-baseline --no-other-configs --no-mode-matrix > $O/reference.log 2>&1)
+      for f in headline reference; do echo "== $f"; find $O -name "${f}_kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -12 {} | cut -c1-170'; tail -c 400 $O/$f.log | head -c 400; echo; done ;;
+    pmc)
+      # HBM traffic of the lean planned kernels (FETCH_SIZE / WRITE_SIZE, separate passes, with the calibration kernels of known byte counts)
+      R=$PWD; B=$R/tests/native/_build/resample_bench; O=$R/gpurun_out/r4_pmc; mkdir -p $O
+      (cd /tmp && export TMPDIR=/tmp
+       for c in FETCH_SIZE WRITE_SIZE; do
+         timeout 200 rocprofv3 --kernel-trace --pmc $c -d $O -o calib_$c --output-format csv -- $B --cases calib > $O/calib_$c.log 2>&1
+         timeout 200 rocprofv3 --kernel-trace --pmc $c -d $O -o planned_$c --output-format csv -- $B --cases perf --reps 2 --case "f32 fill" --path "fast" > $O/planned_$c.log 2>&1
+       done)
+      python scripts/pmc_summary.py $(dirname $(find $O -name "calib_FETCH_SIZE_counter_collection.csv" | head -1)) "" 2>&1 | grep -v "fast-\|gather" | tee gpurun_out/r4_pmc_traffic_lean.txt | tail -60 ;;
     *) echo "unknown step $step" ;;
   esac
 done
