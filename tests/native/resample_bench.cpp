@@ -384,7 +384,9 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
             if (fill_flip) flips++; else diff_first++;
           } else if (rel > max_rel) max_rel = rel;
         }
-        if (flips > 64) diff_first += flips;
+        // (until round 4 up to 64 flipped fill decisions per image were tolerated here; the FAST kernels now take the decision of
+        // voxels within rounding of the threshold from the exact chain — resample_exact_chain.hpp —, so a flip is a failure)
+        diff_first += flips;
         if (flips) printf("  [%zu fill flips]", flips);
         continue;
       }
