@@ -304,3 +304,47 @@ def test_a_label_map_with_a_pad_label_no_longer_holds_the_float_images_back(hip,
             assert not torch.equal(r, o)  # the FAST kernels did run
             assert int(((r == fill) != (o == fill)).sum()) == 0
             assert float((r.double() - o.double()).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_label_maps_with_a_pad_label_fuzz(hip, monkeypatch, seed):
+    """Random geometries (zooms 0.5 - 2, rotations up to +-40 degrees, shifts, anisotropic spacings, both composition orders,
+    several control grids, ragged shapes, three dtypes): label maps with a fill value are bit-identical to the all-exact road."""
+    import math
+
+    g = torch.Generator().manual_seed(3000 + seed)
+
+    def rnd(lo, hi):
+        return lo + (hi - lo) * float(torch.rand(1, generator=g))
+
+    batch = 2
+    shape = (int(rnd(30, 80)), int(rnd(30, 80)), int(rnd(30, 140)))
+    dtype = [torch.uint8, torch.int16, torch.float32][seed % 3]
+    seg = _labels((batch, 1, *shape), dtype, 3100 + seed)
+    mapping = torch.zeros(batch, 3, 4)
+    for b in range(batch):
+        rot = torch.eye(3, dtype=torch.float64)
+        for axis in range(3):
+            a = math.radians(rnd(-40, 40))
+            c, s = math.cos(a), math.sin(a)
+            i, j = [(1, 2), (0, 2), (0, 1)][axis]
+            r = torch.eye(3, dtype=torch.float64)
+            r[i, i], r[i, j], r[j, i], r[j, j] = c, -s, s, c
+            rot = rot @ r
+        lin = rot @ torch.diag(torch.tensor([rnd(0.5, 2.0) for _ in range(3)], dtype=torch.float64))
+        centre = torch.tensor([(s - 1) / 2 for s in shape], dtype=torch.float64)
+        mapping[b, :, :3] = lin.float()
+        mapping[b, :, 3] = (centre - lin @ centre + torch.tensor([rnd(-10, 10) for _ in range(3)], dtype=torch.float64)).float()
+    elastic = seed % 4 != 0
+    spacing = tuple(rnd(0.6, 1.8) for _ in range(3)) if seed % 3 == 1 else (1, 1, 1)
+    kwargs = dict(
+        out_shape=shape, mapping=mapping.cuda(),
+        control_points=_control_points(batch, [(4, 4, 4), (6, 5, 7), (7, 7, 7)][seed % 3], 3200 + seed, amplitude=rnd(1.0, 7.0)).cuda() if elastic else None,
+        in_spacing=spacing, out_spacing=spacing, affine_first=bool(seed % 2), interps=["nearest"], fills=[torch.tensor([42.0], device="cuda")],
+    )
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "0")
+    reference = hip.resample3d([seg], precision="exact", **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
+    got = hip.resample3d([seg], precision="fast", **kwargs)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(reference, got), (int((reference != got).sum()), shape, dtype, elastic)

@@ -357,3 +357,55 @@ def test_two_host_threads_share_a_stream_without_sharing_a_plan(hip, monkeypatch
         t.join()
     torch.cuda.synchronize()
     assert not failures, failures
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fast_fill_decisions_fuzz(hip, monkeypatch, seed):
+    """Random geometries far from the bench's (zooms 0.5 - 2, rotations up to +-40 degrees, shifts, anisotropic spacings, both
+    composition orders, control grids of several densities and amplitudes, ragged shapes): on every FAST road the fill decision
+    of every voxel is the exact kernel's, and kept values stay within the tolerance (smooth data: the bar is about the
+    arithmetic, not about white noise amplifying a coordinate's last bits)."""
+    import math
+
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def rnd(lo, hi):
+        return lo + (hi - lo) * float(torch.rand(1, generator=g))
+
+    batch = 2 + seed % 2
+    shape = tuple(int(rnd(40, 97)) for _ in range(2)) + (4 * int(rnd(10, 25)),)
+    axes = [torch.arange(s, dtype=torch.float32) / s for s in shape]
+    volume = 0.5 + 0.25 * torch.sin(6.0 * axes[0])[:, None, None] + 0.2 * torch.cos(5.0 * axes[1])[None, :, None] + 0.3 * axes[2][None, None, :]
+    data = torch.stack([volume + 0.1 * b for b in range(batch)])[:, None].contiguous().cuda()
+    mapping = torch.zeros(batch, 3, 4)
+    for b in range(batch):
+        angles = [math.radians(rnd(-40, 40)) for _ in range(3)]
+        rot = torch.eye(3, dtype=torch.float64)
+        for axis, a in enumerate(angles):
+            c, s = math.cos(a), math.sin(a)
+            i, j = [(1, 2), (0, 2), (0, 1)][axis]
+            r = torch.eye(3, dtype=torch.float64)
+            r[i, i], r[i, j], r[j, i], r[j, j] = c, -s, s, c
+            rot = rot @ r
+        lin = rot @ torch.diag(torch.tensor([rnd(0.5, 2.0) for _ in range(3)], dtype=torch.float64))
+        centre = torch.tensor([(s - 1) / 2 for s in shape], dtype=torch.float64)
+        shift = torch.tensor([rnd(-12, 12) for _ in range(3)], dtype=torch.float64)
+        mapping[b, :, :3] = lin.float()
+        mapping[b, :, 3] = (centre - lin @ centre + shift).float()
+    elastic = seed % 3 != 0
+    grid = [(4, 4, 4), (5, 6, 7), (7, 7, 7)][seed % 3]
+    spacing_in = tuple(rnd(0.6, 1.8) for _ in range(3)) if seed % 4 == 1 else (1, 1, 1)
+    kwargs = dict(
+        out_shape=shape, mapping=mapping.cuda(), control_points=_control_points(batch, grid, 2000 + seed, amplitude=rnd(1.0, 8.0)).cuda() if elastic else None,
+        in_spacing=spacing_in, out_spacing=spacing_in, affine_first=bool(seed % 2), interps=["linear"], fills=[torch.tensor([FILL], device="cuda")],
+    )
+    exact = hip.resample3d([data], precision="exact", **kwargs)[0]
+    filled = exact == FILL
+    for road in ("planned", "brick"):
+        monkeypatch.setenv("TIO_FAST_KERNEL", road)
+        monkeypatch.setenv("TIO_PLANNED_LEAN", "1" if seed % 2 else "0")
+        fast = hip.resample3d([data], precision="fast", **kwargs)[0]
+        torch.cuda.synchronize()
+        flips = int((filled != (fast == FILL)).sum())
+        assert flips == 0, (road, flips, shape, elastic)
+        assert float(_rel(exact, fast).max()) <= REL_TOL, (road, float(_rel(exact, fast).max()))
