@@ -177,6 +177,7 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
     }
     __builtin_amdgcn_sched_barrier(0);
     float vals[G];
+    unsigned redo = 0u;  // voxels of this group the tail will store again (their first value never reaches the folded minimum)
 #pragma unroll
     for (int q = 0; q < G; q++) {
       vals[q] = fast_finish(ts[q]);
@@ -184,14 +185,16 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
         const float mk = fast_mask(ts[q], x0s[q] + ox, y0s[q] + oy, z0s[q] + oz, hx, hy, hz);
         vals[q] = (mk > 0.5f) ? vals[q] : fillv;
         // (a NaN weight compares false: the FAST answer — fill — stands; planes beyond the run are never raised)
-        unsure |= ((fabsf(mk - 0.5f) <= margin) & (tg + q < n)) ? (1u << (plane_base + tg + q)) : 0u;
+        const bool again = (fabsf(mk - 0.5f) <= margin) & (tg + q < n);
+        unsure |= again ? (1u << (plane_base + tg + q)) : 0u;
+        if constexpr (TRACK) redo |= again ? (1u << q) : 0u;
       }
     }
     if (tg + G <= n) {
 #pragma unroll
       for (int q = 0; q < G; q++) {
         if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + urow) = vals[q];
-        if constexpr (TRACK) kmin = min(kmin, float_to_key(vals[q]));
+        if constexpr (TRACK) kmin = ((redo >> q) & 1u) ? kmin : min(kmin, float_to_key(vals[q]));
         out_t += slab_b;
         asm volatile("" : "+s"(out_t));  // one running pointer (2 scalar adds per plane), not G precomputed ones
       }
@@ -200,7 +203,7 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
       for (int q = 0; q < G; q++) {
         if (tg + q < n) {
           if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + urow) = vals[q];
-          if constexpr (TRACK) kmin = min(kmin, float_to_key(vals[q]));
+          if constexpr (TRACK) kmin = ((redo >> q) & 1u) ? kmin : min(kmin, float_to_key(vals[q]));
         }
         out_t += slab_b;
         asm volatile("" : "+s"(out_t));
