@@ -519,6 +519,13 @@ int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int3
 int64_t tio_host_mt19937_plan_words(int64_t n);
 int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int64_t* used_words,
                           int32_t n_threads);
+/* The same plan started AHEAD of its launch (ABI 10): _begin hands the call to a native thread and returns a handle (0: bad
+ * arguments) at once, _end waits for it and returns what tio_host_mt19937_plan would have (status, *used_words).  The state
+ * and the plan buffer belong to the job until _end has returned; one job per state at a time.  For a caller that knows the
+ * seed before it is ready to launch (Compose drawing its children's parameters ahead, torchio_amd/transforms/compose.py):
+ * the 0.6 - 0.9 ms of the state chain then overlap the caller's enqueue work instead of sitting on its critical path. */
+int64_t tio_host_mt19937_plan_begin(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int32_t n_threads);
+int tio_host_mt19937_plan_end(int64_t handle, int64_t* used_words);
 int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream);
 /* Noise.apply_transform for a float32 image in one kernel: out = x + (mean + std z) with z the plan's draws (the three
  * float32 roundings of noise.py:178, :119, as tio_add_noise) — the draws never exist in memory.  x / out: the image's

@@ -14,7 +14,8 @@ import bench  # noqa: E402
 import torchio_amd as tio  # noqa: E402
 
 warnings.simplefilter("ignore")
-tio.set_noise_rng("philox"); tio.set_resample_precision("fast")
+mode = os.environ.get("TIO_PROFILE_MODE", "philox,fast").split(",")  # noise rng, resample (= stencil) precision
+tio.set_noise_rng(mode[0]); tio.set_resample_precision(mode[1]); tio.set_stencil_precision(mode[1])
 transform = bench.build_transform()
 batch = bench.make_batch(256, 8, 0, "cuda")
 for _ in range(10):

@@ -719,3 +719,52 @@ def test_gaussian_taps_from_one_block_equal_the_per_axis_form():
         expected, expected_radius = per_axis(sigmas)
         taps, radius, skip = _stacked_gaussian_taps(sigmas, per_element=True)
         assert skip is None and radius == expected_radius and torch.equal(taps, expected)
+
+
+# -- Compose draws ahead (round 4): gates and parameters of all children first, in order; then the children apply ----------
+def _draw_ahead_pipeline(p=1.0):
+    return tio.Compose([
+        tio.Affine(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-2, 2), p=p),
+        tio.ElasticDeformation(p=p),
+        tio.BiasField(p=p),
+        tio.Blur(std=(0.5, 1.5), p=p),
+        tio.Noise(std=(0.05, 0.1), p=p),
+        tio.Gamma(log_gamma=(-0.2, 0.2), p=p),
+    ])
+
+
+@pytest.mark.parametrize("p", [1.0, 0.6])
+def test_compose_drawing_ahead_changes_nothing_observable(monkeypatch, p):
+    """Same values bit for bit, same history (names and parameter dictionaries), same state of the global generator afterwards
+    as the child-by-child road (`TIO_NO_DRAW_AHEAD=1`), with gates that fail and per-element keep masks in play."""
+    import warnings
+
+    subjects = [subject(size=12, seed=seed) for seed in range(3)]
+    results = []
+    for ahead in (True, False):
+        monkeypatch.setenv("TIO_NO_DRAW_AHEAD", "0" if ahead else "1")
+        pipeline = _draw_ahead_pipeline(p)
+        assert pipeline._may_draw_ahead() is ahead
+        outs = []
+        for seed in range(4):
+            torch.manual_seed(40 + seed)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = pipeline(tio.SubjectsBatch.from_subjects(subjects))
+            outs.append((out.t1.data.clone(), out.seg.data.clone(), [(t.name, dict(t.params)) for t in out.applied_transforms], torch.rand(3)))
+        results.append(outs)
+    for with_ahead, without in zip(*results):
+        assert torch.equal(with_ahead[0], without[0]) and torch.equal(with_ahead[1], without[1])
+        assert with_ahead[2] == without[2]
+        assert torch.equal(with_ahead[3], without[3])  # the generator stands where it stood
+
+
+def test_compose_does_not_draw_ahead_across_a_change_of_geometry(monkeypatch):
+    monkeypatch.delenv("TIO_NO_DRAW_AHEAD", raising=False)
+    assert tio.Compose([tio.Affine(degrees=5), tio.Noise()])._may_draw_ahead()
+    assert not tio.Compose([tio.Resample(target=2.0), tio.Noise()])._may_draw_ahead()      # the grid changes: later parameters may read it
+    assert not tio.Compose([tio.Affine(degrees=5), tio.Flip(axes=(0,))])._may_draw_ahead()  # a child that does not say it may
+    assert not tio.Compose([tio.Noise()])._may_draw_ahead()                                  # nothing to be ahead of
+    hooked = tio.Noise()
+    hooked.register_forward_hook(lambda module, args, output: output)
+    assert not tio.Compose([tio.Affine(degrees=5), hooked])._may_draw_ahead()

@@ -498,6 +498,47 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
   return TIO_OK;
 }
 
+// ---- the plan started AHEAD of its launch (round 4) -------------------------------------------------------------------
+// tio_host_mt19937_plan_begin hands the call above to a native thread and returns at once; tio_host_mt19937_plan_end waits
+// for it.  Between the two the caller (a Python thread that knows the seed one millisecond of enqueue work before it
+// launches the noise kernel: Compose's draw-ahead road) does something else — no interpreter lock is involved, the job
+// never touches Python.  One job per state at a time; the state belongs to the job until _end has returned.
+namespace {
+struct PlanJob {
+  std::thread worker;
+  int status = TIO_OK;
+  int64_t used = 0;
+};
+std::mutex g_jobs_mu;
+std::vector<std::pair<int64_t, PlanJob*>> g_jobs;
+int64_t g_next_job = 1;
+}  // namespace
+
+extern "C" int64_t tio_host_mt19937_plan_begin(tio_host_mt_state* state, int64_t n, uint32_t* plan, int64_t capacity_words, int32_t n_threads) {
+  if (state == nullptr || plan == nullptr) return 0;
+  PlanJob* job = new PlanJob();
+  job->worker = std::thread([=] { job->status = tio_host_mt19937_plan(state, n, plan, capacity_words, &job->used, n_threads); });
+  std::lock_guard<std::mutex> lock(g_jobs_mu);
+  const int64_t handle = g_next_job++;
+  g_jobs.emplace_back(handle, job);
+  return handle;
+}
+
+extern "C" int tio_host_mt19937_plan_end(int64_t handle, int64_t* used_words) {
+  PlanJob* job = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_jobs_mu);
+    for (size_t i = 0; i < g_jobs.size(); i++)
+      if (g_jobs[i].first == handle) { job = g_jobs[i].second; g_jobs.erase(g_jobs.begin() + static_cast<long>(i)); break; }
+  }
+  if (job == nullptr) return TIO_ERR_INVALID_ARGUMENT;
+  job->worker.join();
+  const int status = job->status;
+  if (used_words != nullptr) *used_words = job->used;
+  delete job;
+  return status;
+}
+
 extern "C" int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int64_t n, int32_t n_threads) {
   MtState* st = reinterpret_cast<MtState*>(state);
   if (st == nullptr || out == nullptr || n < 0 || st->seeded != 1) return TIO_ERR_INVALID_ARGUMENT;

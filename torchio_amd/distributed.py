@@ -86,6 +86,19 @@ def host_thread_budget(cap: int = 32) -> int:
     return max(1, min(cap, cpus - 1))
 
 
+_BUDGET_CACHE: dict = {}
+
+
+def cached_host_thread_budget() -> int:
+    """``host_thread_budget()`` remembered per (LOCAL_WORLD_SIZE, affinity change counter): the hot path asks once per Noise call,
+    and reading a 256-CPU affinity mask costs tens of microseconds.  ``pin_host_threads`` invalidates it."""
+    key = os.environ.get("LOCAL_WORLD_SIZE", "1")
+    value = _BUDGET_CACHE.get(key)
+    if value is None:
+        value = _BUDGET_CACHE[key] = host_thread_budget()
+    return value
+
+
 def _gpu_local_cpus(index: int) -> list[int] | None:
     """CPUs of the NUMA node GPU *index* hangs off (sysfs ``local_cpulist`` of its PCI function), or None."""
     try:
@@ -134,6 +147,7 @@ def pin_host_threads(info: RankInfo | None = None) -> list[int] | None:
         os.sched_setaffinity(0, cpus)
     except (AttributeError, OSError):
         return None
+    _BUDGET_CACHE.clear()  # the share changed
     return cpus
 
 

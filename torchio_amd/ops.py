@@ -171,9 +171,9 @@ class HostNormalStream:
         if threads:
             self.threads = int(threads)
         else:  # this rank's share of the host (LOCAL_WORLD_SIZE ranks per host, the affinity mask), at most 32
-            from .distributed import host_thread_budget  # noqa: PLC0415
+            from .distributed import cached_host_thread_budget  # noqa: PLC0415
 
-            self.threads = host_thread_budget()
+            self.threads = cached_host_thread_budget()
 
     @staticmethod
     def takes(shape) -> bool:
@@ -191,6 +191,12 @@ class HostNormalStream:
             count *= int(extent)
         device = torch.device(device)
         on_gpu = device.type == "cuda"
+        ahead = self._prefetched
+        if ahead is not None and not (on_gpu and count == ahead[0] and device == ahead[1] and count >= self.DEVICE_DRAW_MIN
+                                      and os.environ.get("TIO_DEVICE_RNG", "1") != "0"):
+            self._prefetched = None
+            self._fn["host_mt19937_plan_end"](ahead[3], None)
+            raise EngineError("HostNormalStream: a plan was started ahead for a draw that is not the next one")
         if on_gpu and count >= self.DEVICE_DRAW_MIN and os.environ.get("TIO_DEVICE_RNG", "1") != "0":
             out = self._randn_on_device(count, device)
             if out is not None:
@@ -219,14 +225,46 @@ class HostNormalStream:
             HostNormalStream._rings().uploaded[id(host)].record()  # the staging buffer is free again once this copy has completed
         return out
 
+    _prefetched = None  # (count, device, staging buffer, native job handle) of a plan started ahead of its launch
+
+    def prefetch_plan(self, count: int, device) -> None:
+        """Start the plan of the NEXT ``count`` draws of this stream on a native thread (``tio_host_mt19937_plan_begin``: the
+        state chain runs on this rank's worker threads, no interpreter lock involved) while the caller goes on enqueueing; the
+        next ``_device_plan(count, device)`` — whoever asks first: the fused Noise kernel or ``randn`` — collects it.  Called
+        by ``Noise._prefetch`` from a ``Compose`` that drew its children's parameters ahead: the seed is known one millisecond
+        of host work before the noise kernel is launched."""
+        if self._prefetched is not None or count < self.DEVICE_DRAW_MIN or os.environ.get("TIO_DEVICE_RNG", "1") == "0":
+            return
+        device = torch.device(device)
+        with torch.cuda.device(device):
+            words = int(self._fn["host_mt19937_plan_words"](count))
+            plan_host = self._plan_staging(words)
+        handle = int(self._fn["host_mt19937_plan_begin"](C.addressof(self._state), count, C.c_void_p(plan_host.data_ptr()), words, self.threads))
+        if handle != 0:
+            self._prefetched = (count, device, plan_host, handle)
+
+    def __del__(self):  # a job that nobody collected still owns the state and the staging buffer: wait for it
+        ahead = getattr(self, "_prefetched", None)
+        if ahead is not None:
+            self._prefetched = None
+            self._fn["host_mt19937_plan_end"](ahead[3], None)
+
     def _device_plan(self, count: int, device):
         """The plan of ``count`` draws (``tio_host_mt19937_plan``: the host runs the mt19937 state chain — in parallel, by
         jump-ahead — and keeps a snapshot every 128 blocks), uploaded: 2.5 KB of state per 79 872 draws instead of 4 bytes
         per draw.  ``None`` when the stream stands inside a group of 16 (the host road takes over; the state is untouched)."""
-        words = int(self._fn["host_mt19937_plan_words"](count))
-        plan_host = self._plan_staging(words)
-        used = C.c_int64(0)
-        status = self._fn["host_mt19937_plan"](C.addressof(self._state), count, C.c_void_p(plan_host.data_ptr()), words, C.byref(used), self.threads)
+        ahead, self._prefetched = self._prefetched, None
+        if ahead is not None:
+            used = C.c_int64(0)
+            status = self._fn["host_mt19937_plan_end"](ahead[3], C.byref(used))  # (the state is the job's until it has returned)
+            if ahead[0] != count or ahead[1] != torch.device(device):
+                raise EngineError(f"HostNormalStream: a plan of {ahead[0]} draws on {ahead[1]} was started ahead, {count} on {device} are asked for")
+            plan_host = ahead[2]
+        else:
+            words = int(self._fn["host_mt19937_plan_words"](count))
+            plan_host = self._plan_staging(words)
+            used = C.c_int64(0)
+            status = self._fn["host_mt19937_plan"](C.addressof(self._state), count, C.c_void_p(plan_host.data_ptr()), words, C.byref(used), self.threads)
         if status == _abi.UNSUPPORTED_CONFIG:
             return None
         if status != _abi.OK:

@@ -37,6 +37,10 @@ class BiasField(IntensityTransform):
     def supports_per_instance_p(self) -> bool:
         return True
 
+    @property
+    def draws_ahead(self) -> bool:
+        return True  # parameters from the batch size alone; intensities change, geometry does not
+
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
         n = self._resolve_n(batch)
         if n is None:  # draw order: std, then the seed (bias_field.py:71-72)

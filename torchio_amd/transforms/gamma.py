@@ -33,6 +33,10 @@ class Gamma(IntensityTransform):
     def supports_per_instance_p(self) -> bool:
         return True
 
+    @property
+    def draws_ahead(self) -> bool:
+        return True  # parameters from the batch size alone; intensities change, geometry does not
+
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
         n = self._resolve_n(batch)
         keep = self._keep_mask(batch, n)

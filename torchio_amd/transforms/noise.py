@@ -30,6 +30,7 @@ from .parameter_range import to_range
 from .transform import IntensityTransform
 
 _NOISE_RNG = os.environ.get("TIO_NOISE_RNG", "reference")
+_STREAMS_AHEAD: dict[int, Any] = {}  # id(params) -> HostNormalStream whose first plan a Compose started ahead (Noise._prefetch)
 
 
 def set_noise_rng(mode: str) -> None:
@@ -42,6 +43,18 @@ def set_noise_rng(mode: str) -> None:
 
 def get_noise_rng() -> str:
     return _NOISE_RNG
+
+
+def _reference_stream_images(transform, batch: SubjectsBatch):
+    """The tensors the reference-identical stream would be drawn for on the device, or None (another mode / host images).
+    (A module function: `Noise.apply_transform` also runs with the REFERENCE's transform instance as `self`, reference_binding.)"""
+    images = transform._get_images(batch)
+    if _NOISE_RNG != "reference" or not images or os.environ.get("TIO_HOST_RNG", "1") == "0":
+        return None
+    tensors = [img._data if hasattr(img, "_data") else img.data for img in images.values()]  # (shape / device: pending stages keep both)
+    if all(t.is_cuda and ops.HostNormalStream.takes(t.shape) for t in tensors):
+        return tensors
+    return None
 
 
 class Noise(IntensityTransform):
@@ -61,6 +74,10 @@ class Noise(IntensityTransform):
     def supports_per_instance_p(self) -> bool:
         return True
 
+    @property
+    def draws_ahead(self) -> bool:
+        return True  # parameters from the batch size alone; intensities change, geometry does not
+
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
         seed = int(torch.randint(0, 2**31, (1,)).item())  # seed FIRST, then mean, std (noise.py:75-80)
         n = self._resolve_n(batch)
@@ -76,6 +93,18 @@ class Noise(IntensityTransform):
         self._tag_batched(params, batch, n, keep, ["mean", "std"])
         return params
 
+    def _prefetch(self, batch: SubjectsBatch, params: dict[str, Any]) -> None:
+        """Draw-ahead road (Compose): the seed is known — start the plan of the stream's first image on the helper thread."""
+        tensors = _reference_stream_images(self, batch)
+        if not tensors or params.get("_keep") is not None:
+            return
+        first = tensors[0]
+        if first.dtype not in (torch.float32, torch.float64) or not first.is_contiguous():
+            return  # (another dtype is converted first: its draw keeps the count, but stay on the simple road)
+        stream = ops.HostNormalStream(params["seed"])
+        stream.prefetch_plan(first.numel(), first.device)
+        _STREAMS_AHEAD[id(params)] = stream
+
     def apply_transform(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
         mean, std, seed = params["mean"], params["std"], params["seed"]
         rician = params.get("rician", False)
@@ -87,11 +116,9 @@ class Noise(IntensityTransform):
         # the reference-identical stream for device-resident images: the same draws as `torch.randn(..., generator=generator)`
         # below — made on the device from the host's plan of the state chain, or on all host cores (ops.HostNormalStream);
         # one stream object = the one generator of this call
-        stream = None
-        if _NOISE_RNG == "reference" and images and os.environ.get("TIO_HOST_RNG", "1") != "0":
-            tensors = [img._data if hasattr(img, "_data") else img.data for img in images.values()]  # (shape / device: pending stages keep both)
-            if all(t.is_cuda and ops.HostNormalStream.takes(t.shape) for t in tensors):
-                stream = ops.HostNormalStream(seed)
+        stream = _STREAMS_AHEAD.pop(id(params), None)  # (started by `_prefetch`: its first plan is being computed, or done)
+        if stream is None and _reference_stream_images(self, batch) is not None:
+            stream = ops.HostNormalStream(seed)
         for index, img_batch in enumerate(images.values()):
             queue = getattr(img_batch, "_pending", None)  # foreign containers (reference_binding) never defer
             if (

@@ -148,6 +148,12 @@ class Spatial(SpatialTransform):
         # per-element gating needs a shape-preserving transform (spatial.py:375-380)
         return self.target is None
 
+    @property
+    def draws_ahead(self) -> bool:
+        # without a target the output grid is the input grid: sizes, affines and image names survive, and `make_params` reads
+        # nothing else of the batch (transform.py: Transform.draws_ahead)
+        return self.target is None and type(self).make_params is Spatial.make_params and type(self).apply_transform is Spatial.apply_transform
+
     # -- sampling: global-RNG order is scales, degrees, translation, max_displacement,
     #    control points (spatial.py:382-434) ----------------------------------
     def _scalar_plan(self):

@@ -103,6 +103,20 @@ class Transform(nn.Module):
             finally:
                 _return_home(batch, home)
         params = self.make_params(batch)
+        result = unwrap(self._apply_drawn(batch, params))
+        if isinstance(result, (Image, ImagesBatch)):
+            result.applied_transforms = list(batch.applied_transforms)
+        return result
+
+    # -- the two halves of the envelope, for containers that draw ahead (Compose) ------------------------------------
+    def _draw(self, batch: SubjectsBatch) -> dict[str, Any] | None:
+        """The global-RNG half: the p-gate, then the parameters (`None`: gated out) — exactly what `_forward` draws."""
+        if not self._per_instance_p_active(batch) and torch.rand(1).item() >= self.p:
+            return None
+        return self.make_params(batch)
+
+    def _apply_drawn(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
+        """The data half: apply, then record (transform.py:229-248)."""
         batch = self.apply_transform(batch, params)
         if not _all_gated_out(params):
             batch.applied_transforms.append(
@@ -113,10 +127,19 @@ class Transform(nn.Module):
                     exclude=None if self.exclude is None else list(self.exclude),
                 )
             )
-        result = unwrap(batch)
-        if isinstance(result, (Image, ImagesBatch)):
-            result.applied_transforms = list(batch.applied_transforms)
-        return result
+        return batch
+
+    @property
+    def draws_ahead(self) -> bool:
+        """True when (a) `make_params` reads nothing of the batch that an earlier transform could change as long as that
+        transform keeps the batch's geometry — no voxel values, only sizes, affines and image names — and (b) `apply_transform`
+        itself keeps that geometry.  A `Compose` whose children all say so may draw every child's gate and parameters first,
+        in order (the global generator sees the reference's sequence), and apply afterwards: what a later child needs for its
+        launch (the plan of Noise's generator stream) can then be prepared while the earlier children are still being applied."""
+        return False
+
+    def _prefetch(self, batch: SubjectsBatch, params: dict[str, Any]) -> None:
+        """Hook of the draw-ahead road: start whatever of `apply_transform(batch, params)` only needs the parameters."""
 
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
         return {}
