@@ -35,7 +35,8 @@ class Gamma(IntensityTransform):
 
     @property
     def draws_ahead(self) -> bool:
-        return True  # parameters from the batch size alone; intensities change, geometry does not
+        # parameters from the batch size alone; intensities change, geometry does not (a subclass that overrides either half speaks for itself)
+        return type(self).make_params is Gamma.make_params and type(self).apply_transform is Gamma.apply_transform
 
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
         n = self._resolve_n(batch)

@@ -76,7 +76,8 @@ class Noise(IntensityTransform):
 
     @property
     def draws_ahead(self) -> bool:
-        return True  # parameters from the batch size alone; intensities change, geometry does not
+        # parameters from the batch size alone; intensities change, geometry does not (a subclass that overrides either half speaks for itself)
+        return type(self).make_params is Noise.make_params and type(self).apply_transform is Noise.apply_transform
 
     def make_params(self, batch: SubjectsBatch) -> dict[str, Any]:
         seed = int(torch.randint(0, 2**31, (1,)).item())  # seed FIRST, then mean, std (noise.py:75-80)
