@@ -256,3 +256,15 @@ def test_every_24_bit_uniform_against_torch_itself(functions):
         view[640] = 0
         assert functions["host_mt19937_randn"](C.addressof(state), C.c_void_p(ours.ctypes.data), 608, 1) == _abi.OK
         assert np.array_equal(theirs.view(np.uint32), ours.view(np.uint32)), block
+
+
+def test_the_stream_checks_itself_against_this_torch_build(monkeypatch):
+    """the restatement is tied to one torch build's arithmetic.  The first use compares 4 096 + 48 draws with
+    `torch.randn`; a stream that is not verified is not used (`takes` -> False: the callers keep `torch.randn`)."""
+    from torchio_amd import ops
+
+    monkeypatch.setattr(ops.HostNormalStream, "_self_check", None)
+    assert ops.HostNormalStream.verified() is True          # this image: torch 2.10, AVX2
+    assert ops.HostNormalStream.takes((4, 4)) is True
+    monkeypatch.setattr(ops.HostNormalStream, "_self_check", False)
+    assert ops.HostNormalStream.takes((1 << 20,)) is False  # switched off for the process: nobody draws from it

@@ -175,13 +175,46 @@ class HostNormalStream:
 
             self.threads = cached_host_thread_budget()
 
-    @staticmethod
-    def takes(shape) -> bool:
-        """torch uses another algorithm below 16 values (not restated): such draws stay with ``torch.randn``."""
+    _self_check: bool | None = None  # does the restated stream equal THIS torch build's? (checked once per process)
+
+    @classmethod
+    def verified(cls) -> bool:
+        """The restatement is tied to the arithmetic of torch's CPU ``normal_`` (mt19937 + the 16-lane Box-Muller of
+        ``normal_fill_16_AVX2`` with ``avx_mathfun.h``'s polynomials: torch 2.10 on AVX2 hosts).  Another torch build or a host
+        without AVX2 may take another path, so the first use draws 4 096 values both ways from one seed — a microsecond-scale
+        check — and on ANY difference the stream is switched off for the process: ``takes`` then answers False and the
+        callers keep ``torch.randn`` (slow, and by definition the reference's stream)."""
+        if cls._self_check is None:
+            try:
+                from . import _lib  # noqa: PLC0415
+
+                _, functions = _lib.load()
+                state = (C.c_uint64 * (_abi.HOST_MT_STATE_BYTES // 8))()
+                ok = functions["host_mt19937_seed"](C.addressof(state), 20260922) == _abi.OK
+                ours = torch.empty(4096 + 48, dtype=torch.float32)
+                for start, length in ((0, 4096), (4096, 48)):  # a continuation too: the state must end up where torch's does
+                    ok = ok and functions["host_mt19937_randn"](C.addressof(state), C.c_void_p(ours.data_ptr() + 4 * start), length, 1) == _abi.OK
+                generator = torch.Generator().manual_seed(20260922)
+                theirs = torch.cat([torch.randn(4096, generator=generator), torch.randn(48, generator=generator)])
+                cls._self_check = bool(ok and torch.equal(ours.view(torch.int32), theirs.view(torch.int32)))
+            except Exception:  # noqa: BLE001 - whatever went wrong, the answer is "not verified"
+                cls._self_check = False
+            if not cls._self_check:
+                import warnings  # noqa: PLC0415
+
+                warnings.warn(
+                    "torchio_amd: the restated CPU normal stream differs from this torch build's torch.randn; reference-identical "
+                    "noise falls back to torch.randn on the host (slow)", RuntimeWarning, stacklevel=2)
+        return cls._self_check
+
+    @classmethod
+    def takes(cls, shape) -> bool:
+        """torch uses another algorithm below 16 values (not restated): such draws stay with ``torch.randn`` — and so does
+        everything when the stream could not be verified against this torch build (``verified``)."""
         count = 1
         for extent in shape:
             count *= int(extent)
-        return count >= 16
+        return count >= 16 and cls.verified()
 
     DEVICE_DRAW_MIN = 1 << 20  # draws from which the device produces the stream itself (below: the host road's one small upload)
 

@@ -103,8 +103,14 @@ def _register_dispatcher_extras() -> None:
         # defaults as it chose to pass them): built from its own spec, then the images' slot filled in
         from torch.utils import _pytree  # noqa: PLC0415
 
-        spec = ctx._pt_metadata.input_spec  # (its last child is the dispatcher's own metadata argument: its slot is added by the caller)
-        structure = list(_pytree.tree_unflatten([None] * spec.num_leaves, spec))[:-1]
+        # (`ctx._pt_metadata` is private to torch.library's autograd glue — torch 2.10 here; ADVICE r3: version fragile.  Where it
+        # is missing or shaped differently the documented form is returned: one entry per positional input of the schema, the
+        # list argument as a list)
+        try:
+            spec = ctx._pt_metadata.input_spec  # (its last child is the dispatcher's own metadata argument: its slot is added by the caller)
+            structure = list(_pytree.tree_unflatten([None] * spec.num_leaves, spec))[:-1]
+        except (AttributeError, TypeError, ValueError):
+            structure = [None] * ctx.n_inputs
         structure[0] = image_grads
         return tuple(structure)
 
