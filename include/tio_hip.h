@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 10
+#define TIO_ABI_VERSION 11
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -169,6 +169,15 @@ typedef struct tio_resample_geom {
    * half-integer are re-evaluated with the exact chain); any other image in the call — a
    * nearest image with a fill rule, TIO_LABEL_PV, another dtype — keeps the whole call exact. */
   int32_t precision;
+  /* Optional (NULL / 0 = the call plans for itself): a brick plan made AHEAD of the call by tio_resample3d_plan from a
+   * geometry with exactly these fields (ABI 11).  Large launches of 16^3 bricks start from a plan — one descriptor per
+   * brick, written by a small kernel that reads only the geometry above (mapping, control points, flags), never the
+   * images — and that kernel plus the gap behind it sit on the critical path of the call (~8 - 23 us + ~5 us on the
+   * bench launch).  A caller that knows the geometry before the data is ready (a Compose that has drawn every child's
+   * parameters) can have the plan made on another stream while earlier work runs.  The plan must stay untouched until
+   * the call's kernels have finished; a call that takes another road than the one the plan was made for ignores it. */
+  const void* plan_dev;
+  int64_t plan_bytes;
 } tio_resample_geom;
 
 /* One image tensor resampled with the shared geometry
@@ -204,6 +213,14 @@ typedef struct tio_resample_image {
    * NaN propagates like torch.min.  Ignored for TIO_LINEAR_ADJOINT. */
   float* out_min_dev;
 } tio_resample_image;
+
+/* Bytes of the brick plan tio_resample3d would make for this geometry when every image of the call is a float32
+ * trilinear image (0: such a call takes a road without a plan — small launches, K not a multiple of 4, ...);
+ * geom->plan_dev / plan_bytes are ignored.  Host-only: nothing is enqueued. */
+int64_t tio_resample3d_plan_bytes(const tio_resample_geom* geom);
+/* Enqueue the planning kernel for this geometry on `stream`: plan_dev (>= tio_resample3d_plan_bytes(geom) bytes,
+ * 16-byte aligned) is then handed to tio_resample3d in geom->plan_dev, on any stream ordered behind this one. */
+int tio_resample3d_plan(const tio_resample_geom* geom, void* plan_dev, int64_t plan_bytes, void* stream);
 
 /* Resample n_images image tensors through ONE coordinate computation. */
 int tio_resample3d(const tio_resample_geom* geom, int32_t n_images,

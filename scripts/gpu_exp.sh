@@ -50,6 +50,19 @@ for step in "$@"; do
          timeout 200 rocprofv3 --kernel-trace --pmc $c -d $O -o planned_$c --output-format csv -- $B --cases perf --reps 2 --case "f32 fill" --path "fast" > $O/planned_$c.log 2>&1
        done)
       python scripts/pmc_summary.py $(dirname $(find $O -name "calib_FETCH_SIZE_counter_collection.csv" | head -1)) "" 2>&1 | grep -v "fast-\|gather" | tee gpurun_out/r4_pmc_traffic_lean.txt | tail -60 ;;
+    tests_ahead)
+      timeout 900 python -m pytest tests/test_gpu_ahead.py tests/test_gpu_resample_planned.py tests/test_gpu_full_size.py -m gpu -q --tb=short -x 2>&1 | tail -60 > gpurun_out/r4_gpu_tests_ahead.txt
+      grep -v "Warning\|^$\|warnings.html\|^  " gpurun_out/r4_gpu_tests_ahead.txt | tail -40 ;;
+    ab_ahead)
+      # the side stream (uploads + brick plans ahead of the data) and the announced minimum, on and off, alternating
+      L=gpurun_out/r4_ab_ahead.log; : > $L
+      for rep in 1 2 3; do
+        for off in 0 3 1 2; do
+          TIO_NO_AHEAD_STREAM=$((off & 1)) TIO_NO_ANNOUNCED_MIN=$((off >> 1)) timeout 200 python bench.py --steps 60 --no-cpu-baseline --no-aten-baseline --no-other-configs --no-mode-matrix 2>/dev/null |
+            python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('off(1=stream,2=announced min)=$off', round(d['value'],1), 'vol/s', round(d['ms_per_step'],4), 'ms/step host', round(d['host_enqueue_ms_per_step'],3), 'launch_ms', round(d['roofline']['launch_ms'],4))" >> $L
+        done
+      done
+      cat $L ;;
     *) echo "unknown step $step" ;;
   esac
 done

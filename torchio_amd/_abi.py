@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_IMAGES = 8
 
 # tio_status
@@ -45,6 +45,8 @@ class ResampleGeom(C.Structure):
         ("out_spacing", C.c_float * 3),
         ("norm_shape", C.c_int32 * 3),
         ("precision", C.c_int32),
+        ("plan_dev", C.c_void_p),
+        ("plan_bytes", C.c_int64),
     ]
 
 
@@ -139,6 +141,8 @@ HIP_ONLY_PROTOTYPES = {
     "last_error": (C.c_char_p, []),
     "device_count": (C.c_int, []),
     "reload_env": (None, []),
+    "resample3d_plan_bytes": (C.c_int64, [C.POINTER(ResampleGeom)]),
+    "resample3d_plan": (C.c_int, [C.POINTER(ResampleGeom), C.c_void_p, C.c_int64, C.c_void_p]),
     "host_mt19937_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "host_mt19937_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "host_mt19937_plan_words": (C.c_int64, [C.c_int64]),

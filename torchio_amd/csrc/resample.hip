@@ -659,9 +659,21 @@ static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
 }
 
 // `folded` comes back true when the launch itself produced every requested out_min_dev (planned FAST bricks)
-static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, const tio_resample_image* images, void* stream, bool* folded) {
+// `mode`: kPlanNone — the call itself; kPlanQuery — only *plan_bytes (the plan this geometry's launch would start from; 0: none);
+// kPlanOnly — enqueue the planning kernel into plan_out and return (tio_resample3d_plan).  The two plan modes run the same
+// decisions as the call, with one float32 trilinear image standing in for the caller's (the planner never reads an image).
+enum { kPlanNone = 0, kPlanQuery = 1, kPlanOnly = 2 };
+static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, const tio_resample_image* images, void* stream, bool* folded,
+                           int mode = kPlanNone, int* plan_out = nullptr, int64_t plan_out_bytes = 0, int64_t* plan_bytes = nullptr) {
   using namespace tio;
   *folded = false;
+  if (plan_bytes != nullptr) *plan_bytes = 0;
+  tio_resample_image stand_in{};
+  if (mode != kPlanNone) {
+    static float aligned_dummy[4] __attribute__((aligned(16)));  // never dereferenced: the plan modes return before any sampling launch
+    stand_in.in = aligned_dummy; stand_in.out = aligned_dummy; stand_in.channels = 1; stand_in.dtype = TIO_F32; stand_in.interp = TIO_LINEAR;
+    images = &stand_in; n_images = 1;
+  }
   if (geom == nullptr || images == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: null argument");
   if (n_images < 1 || n_images > TIO_MAX_IMAGES)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d: n_images=%d not in [1, %d]", n_images, TIO_MAX_IMAGES);
@@ -937,8 +949,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       if (planned) {
         // one single-channel image (what a FAST intensity launch almost always is): the lean kernel (resample_fast.hpp),
         // whose bricks may be 8 planes thick (half the tile: twice the blocks per CU)
-        bool lean = env.planned_lean != 0;
-        for (int i = 0; i < a.n_images; i++) lean = lean && a.img[i].out_min == nullptr;
+        const bool lean = env.planned_lean != 0;
         const int64_t items64 = blocks;
         int cap_p = kLdsFloatsPerCU / kTileBlocksPerCU - 512;
         if (env.tile_lds_floats > 0) cap_p = env.tile_lds_floats;
@@ -951,14 +962,32 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         // round 3: DMA instructions that cover rows across x-plane boundaries (resample_fast.hpp: stream_stage_packed);
         // TIO_DMA_PACKED=0 switches them off in the general kernel (A/B)
         a.dma_packed = env.dma_packed;
-        PlanLease lease = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
-        int* plan = lease.ptr;  // (the lease is released when this function returns: after both kernels are enqueued)
-        if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
-        const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
-        const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
-        const dim3 plan_grid((plan_threads + 255) / 256);
-        if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-        else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+        const size_t plan_need = (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int);
+        if (mode == kPlanQuery) { *plan_bytes = static_cast<int64_t>(plan_need); return TIO_OK; }
+        PlanLease lease;
+        int* plan = nullptr;
+        bool planned_ahead = false;
+        if (mode == kPlanOnly) {
+          if (plan_out == nullptr || plan_out_bytes < static_cast<int64_t>(plan_need) || (reinterpret_cast<uintptr_t>(plan_out) & 15) != 0)
+            return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d_plan: the plan needs %zu bytes, 16-byte aligned", plan_need);
+          plan = plan_out;
+        } else if (geom->plan_dev != nullptr && geom->plan_bytes >= static_cast<int64_t>(plan_need) &&
+                   (reinterpret_cast<uintptr_t>(geom->plan_dev) & 15) == 0) {
+          plan = static_cast<int*>(const_cast<void*>(geom->plan_dev));  // made ahead by tio_resample3d_plan: no planning kernel on this stream
+          planned_ahead = true;
+        } else {
+          lease = plan_workspace(s, plan_need);
+          plan = lease.ptr;  // (the lease is released when this function returns: after both kernels are enqueued)
+          if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+        }
+        if (!planned_ahead) {
+          const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
+          const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
+          const dim3 plan_grid((plan_threads + 255) / 256);
+          if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+          else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+        }
+        if (mode == kPlanOnly) { *plan_bytes = static_cast<int64_t>(plan_need); return check_launch("tio_resample3d_plan"); }
         // the folded minimum: kMinSlots keys per channel that asked for it (common.hpp: min_workspace, all ones between
         // launches), finished by min_finish_kernel behind the sampling kernel
         uint32_t* min_keys = nullptr;
@@ -992,7 +1021,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
             hipLaunchKernelGGL(min_finish_kernel, dim3(static_cast<unsigned>(min_channels)), dim3(kMinSlots), 0, s, min_keys, min_outs, min_channels);
           return check_launch("tio_resample3d");
         };
-        if (lean && min_channels == 0) {
+        if (lean) {
           LeanArgs la{};
           la.plan = plan; la.cp = a.cp;
           la.I = a.I; la.J = a.J; la.K = a.K; la.Io = a.Io; la.Jo = a.Jo; la.Ko = a.Ko;
@@ -1009,6 +1038,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3> : resample_planned_lean_kernel<false, 16, 16, 16, 3>;
           if (la.ablate != 0)  // TIO_TILE_ABLATE: the instrumented instantiation (experiments only)
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, true>;
+          else if (min_channels > 0)  // the folded minimum: the instantiation whose element-0 bricks track what they store
+            kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, false, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, false, true>;
           if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       static_cast<int>(lds_p)) != hipSuccess)
             return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
@@ -1021,14 +1052,18 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
               la.in = static_cast<const float*>(g.in) + static_cast<int64_t>(c) * n_in;
               la.out = static_cast<float*>(g.out) + static_cast<int64_t>(c) * n_out;
               la.fill = g.fill != nullptr ? g.fill + c : nullptr;
+              la.min_keys = (min_channels > 0 && g.min_keys != nullptr) ? g.min_keys + c * kMinSlots : nullptr;
               hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(256), lds_p, s, la);
             }
           }
+          if (min_channels > 0)
+            hipLaunchKernelGGL(min_finish_kernel, dim3(static_cast<unsigned>(min_channels)), dim3(kMinSlots), 0, s, min_keys, min_outs, min_channels);
           return check_launch("tio_resample3d");
         }
         if (a.cp != nullptr) return launch_planned(resample_planned_kernel<true, 16, 16, 16, 3>);
         return launch_planned(resample_planned_kernel<false, 16, 16, 16, 3>);
       }
+      if (mode != kPlanNone) return TIO_OK;  // a FAST launch of in-kernel boxes: no plan
       auto launch_fast = [&](auto kernel) -> int {
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    static_cast<int>(lds)) != hipSuccess)
@@ -1060,18 +1095,36 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         const int64_t items64 = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
         if (items64 < (1LL << 26)) {
           const int n_items = static_cast<int>(items64);
-          exact_lease = plan_workspace(s, (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int));
-          int* plan = exact_lease.ptr;
-          if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
-          const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
-          const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
-          const dim3 plan_grid((plan_threads + 255) / 256);
-          if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
-          else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+          const size_t plan_need = (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int);
+          if (mode == kPlanQuery) { *plan_bytes = static_cast<int64_t>(plan_need); return TIO_OK; }
+          int* plan = nullptr;
+          bool planned_ahead = false;
+          if (mode == kPlanOnly) {
+            if (plan_out == nullptr || plan_out_bytes < static_cast<int64_t>(plan_need) || (reinterpret_cast<uintptr_t>(plan_out) & 15) != 0)
+              return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d_plan: the plan needs %zu bytes, 16-byte aligned", plan_need);
+            plan = plan_out;
+          } else if (geom->plan_dev != nullptr && geom->plan_bytes >= static_cast<int64_t>(plan_need) &&
+                     (reinterpret_cast<uintptr_t>(geom->plan_dev) & 15) == 0) {
+            plan = static_cast<int*>(const_cast<void*>(geom->plan_dev));
+            planned_ahead = true;
+          } else {
+            exact_lease = plan_workspace(s, plan_need);
+            plan = exact_lease.ptr;
+            if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+          }
+          if (!planned_ahead) {
+            const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
+            const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
+            const dim3 plan_grid((plan_threads + 255) / 256);
+            if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+            else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
+          }
+          if (mode == kPlanOnly) { *plan_bytes = static_cast<int64_t>(plan_need); return check_launch("tio_resample3d_plan"); }
           plan_exact = plan;
         }
       }
     }
+    if (mode != kPlanNone) return TIO_OK;  // bricks with in-kernel boxes: no plan
     switch (variant) {
       case 1: TIO_TILE_SHAPE_F32(16, 8, 32, 3) break;
       case 2: TIO_TILE_SHAPE_F32(8, 8, 32, 4) break;
@@ -1085,6 +1138,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     return check_launch("tio_resample3d");
   }
 
+  if (mode != kPlanNone) return TIO_OK;  // the gather kernel: no plan
   a.tiles_k = (a.Ko + kLanes - 1) / kLanes;
   a.tiles_j = (a.Jo + kRowsPerBlock - 1) / kRowsPerBlock;
   a.tiles_i = (a.Io + kTileI - 1) / kTileI;
@@ -1100,6 +1154,23 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   }
 #undef TIO_LAUNCH
   return check_launch("tio_resample3d");
+}
+
+extern "C" int64_t tio_resample3d_plan_bytes(const tio_resample_geom* geom) {
+  bool folded = false;
+  int64_t bytes = 0;
+  if (geom == nullptr || geom->batch < 1) return 0;
+  const int status = resample3d_impl(geom, 0, nullptr, nullptr, &folded, kPlanQuery, nullptr, 0, &bytes);
+  return status == TIO_OK ? bytes : 0;
+}
+
+extern "C" int tio_resample3d_plan(const tio_resample_geom* geom, void* plan_dev, int64_t plan_bytes, void* stream) {
+  bool folded = false;
+  int64_t bytes = 0;
+  if (geom == nullptr || geom->batch < 1) return tio::fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d_plan: no geometry / empty batch");
+  const int status = resample3d_impl(geom, 0, nullptr, stream, &folded, kPlanOnly, static_cast<int*>(plan_dev), plan_bytes, &bytes);
+  if (status == TIO_OK && bytes == 0) return tio::fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d_plan: this geometry's launch does not start from a plan");
+  return status;
 }
 
 extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images, const tio_resample_image* images, void* stream) {

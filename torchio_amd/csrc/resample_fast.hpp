@@ -842,6 +842,9 @@ struct LeanArgs {
   const float* mapping;
   int mapping_batched, unit_spacing, fill_recheck;
   float sp[3], rsp[3], den[3], rden[3];
+  // the folded minimum (tio_resample_image.out_min_dev): kMinSlots keys of this channel, or nullptr.  Only the bricks of batch
+  // element 0 track what they store (a block-uniform branch into the TRACK instantiation of the sampling loop).
+  uint32_t* min_keys;
 };
 
 // FAST trilinear sample straight from global memory (bricks whose box does not fit the tile, non-finite geometry): zero
@@ -883,7 +886,10 @@ __device__ __forceinline__ float lean_gather(const float* __restrict__ chan, int
 // INSTR = true is the INSTRUMENTED instantiation (launched only when TIO_TILE_ABLATE is set: tests/native/resample_bench
 // --ablate): a.ablate 1 no DMA, 2 no sampling, 64 shader-clock stamps written over the brick's first output row, 128
 // every lane samples one LDS address.  The production instantiation (INSTR = false) carries none of it.
-template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK, int WAVES_PER_SIMD, bool INSTR = false>
+// FOLD_MIN = true is the instantiation launched when the caller asked for the folded minimum (LeanArgs::min_keys): the
+// bricks of batch element 0 run the TRACK form of the sampling loop.  Its own instantiation because the second copy of the
+// loop costs scalar registers (14 / 26 more spilled) that launches without the request should not pay for.
+template <bool ELASTIC_POSSIBLE, int TI, int TJ, int TK, int WAVES_PER_SIMD, bool INSTR = false, bool FOLD_MIN = false>
 __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_kernel(const LeanArgs a) {
   const int ablate = INSTR ? a.ablate : 0;
   constexpr int NW = TJ * TK / 64;
@@ -953,13 +959,22 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
   const float fillv = has_fill ? ((const_float_ptr)a.fill)[0] : 0.0f;
   const float hx = a.hx, hy = a.hy, hz = a.hz;
 
+  const bool track = FOLD_MIN && a.min_keys != nullptr && b == 0;  // block uniform
+  uint32_t kmin = 0xFFFFFFFFu;
+  auto publish_min = [&]() {  // (one returnless atomic per wave, spread over kMinSlots addresses by brick: resample_planned_kernel)
+    const uint32_t wmin = wave_min_u32(kmin);
+    if (lane == 0 && wmin != 0xFFFFFFFFu)
+      __hip_atomic_fetch_min(a.min_keys + (brick & (kMinSlots - 1)), wmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   if (kind == kDescGated || kind == kDescOutside) {  // gated-out element: bit-exact copy; nothing of the volume in sight: fill (or 0)
     if (col_active) {
       for (int t = u0; t < u1; t++) {
         const float val = kind == kDescGated ? in_chan[static_cast<int64_t>(t) * slab + col_off] : fillv;
         *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
+        kmin = min(kmin, float_to_key(val));
       }
     }
+    if (track) publish_min();
     return;
   }
 
@@ -990,7 +1005,7 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
       lk_e = lerp_index(k_lo + kw, a.nk, a.Ko, a.sck);
     }
     fast_fill_tail<ELASTIC_POSSIBLE>(unsure, ea, a.mapping + (a.mapping_batched ? b * 12 : 0), elastic, f.cp, lj_e, lk_e, u0, static_cast<float>(j_lo + jv),
-                                     static_cast<float>(k_lo + kw), in_chan, a.I, a.J, a.K, hx, hy, hz, fillv, out_chan, slab_b, urow);
+                                     static_cast<float>(k_lo + kw), in_chan, a.I, a.J, a.K, hx, hy, hz, fillv, out_chan, slab_b, urow, track ? &kmin : nullptr);
   };
 
   if (kind == kDescSlow) {  // box beyond the LDS budget / non-finite geometry: per-voxel evaluation, global gathers (rare)
@@ -999,10 +1014,13 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
       for (int t = u0; t < u1; t++) {
         float x, y, z;
         fast_coord(f, static_cast<float>(t), static_cast<float>(jv), static_cast<float>(kw), x, y, z);
-        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = lean_gather(in_chan, a.I, a.J, a.K, x, y, z, has_fill, fillv, hx, hy, hz, margin, t - u0, unsure);
+        const float val = lean_gather(in_chan, a.I, a.J, a.K, x, y, z, has_fill, fillv, hx, hy, hz, margin, t - u0, unsure);
+        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
+        if (!((unsure >> (t - u0)) & 1u)) kmin = min(kmin, float_to_key(val));  // (a re-decided voxel is counted by the tail)
       }
     }
     if (has_fill) lean_tail();
+    if (track) publish_min();
     return;
   }
 
@@ -1042,17 +1060,20 @@ __global__ __launch_bounds__(TJ* TK, WAVES_PER_SIMD) void resample_planned_lean_
   __syncthreads();
   if (ablate & 64) t_landed = __builtin_amdgcn_s_memtime();
   if (col_active && u0 < u1 && !(ablate & 2)) {
-    uint32_t kmin = 0xFFFFFFFFu;
     const bool needs_mask = has_fill & !bx.interior;
     for (;;) {
       char* o_run = out_chan + static_cast<int64_t>(run0) * slab_b;
-      fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, needs_mask, ox, oy, oz, hx, hy, hz, fillv, kmin, margin, run0 - u0, unsure);
+      if (track)
+        fast_sample_line<4, true>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, needs_mask, ox, oy, oz, hx, hy, hz, fillv, kmin, margin, run0 - u0, unsure);
+      else
+        fast_sample_line<4, false>(run1 - run0, A3, B3, ta, o_run, urow, slab_b, needs_mask, ox, oy, oz, hx, hy, hz, fillv, kmin, margin, run0 - u0, unsure);
       run0 = run1;
       if (run0 >= u1) break;
       run1 = fast_column_line(f, lj, lk, planes, run0, u1, u_ref, C3, col3, lane, A3, B3);
     }
   }
   if (has_fill & !bx.interior) lean_tail();  // (block uniform)
+  if (track) publish_min();
   if (ablate & 64) {  // instrumentation: the block's shader-clock stamps over the first row of its own output
     const unsigned long long t_sampled = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0);

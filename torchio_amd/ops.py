@@ -136,6 +136,69 @@ def h2d_packed(tensors: Sequence[Tensor | None], device) -> list[Tensor | None]:
     return out
 
 
+_MINIMUM_WANTED = False
+_ANNOUNCED_MINIMUM_ENABLED = os.environ.get("TIO_NO_ANNOUNCED_MIN", "") in ("", "0")  # (A/B switch)
+
+
+def expect_minimum_fill(flag: bool) -> None:
+    """Announce (or withdraw) that the consumer of the next resampling's output will ask for the per-channel minimum of its
+    first element (``default_pad_value="minimum"``): large FAST launches then fold it into their stores (``resample3d``)."""
+    global _MINIMUM_WANTED
+    _MINIMUM_WANTED = bool(flag) and _ANNOUNCED_MINIMUM_ENABLED
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Work AHEAD of the data: parameter uploads and brick plans depend on a transform's drawn parameters, not on voxel values.
+# A Compose that has drawn every child's parameters (transforms/compose.py) has its spatial children enqueue them on a side
+# stream — while the kernels of the previous children (or of the previous step: the host runs ahead of the GPU) are still
+# running — so that the upload copies, the planning kernels and the dependency gaps around them (~5 us each on this GPU) are
+# off the critical path of the stream the data lives on.  The data stream waits for the side stream's event right before the
+# launch that reads those buffers; buffers allocated on the side stream are marked as used by the data stream
+# (`record_stream`), so the caching allocator does not hand them out again before that launch has finished.
+# ---------------------------------------------------------------------------------------------------------------------
+_AHEAD_STREAMS: dict[int, "torch.cuda.Stream"] = {}
+_AHEAD_ENABLED = os.environ.get("TIO_NO_AHEAD_STREAM", "") in ("", "0")
+
+
+def set_ahead_stream(enabled: bool) -> None:
+    """Switch the side stream for work ahead of the data on or off (on by default; ``TIO_NO_AHEAD_STREAM=1`` starts with it off)."""
+    global _AHEAD_ENABLED
+    _AHEAD_ENABLED = bool(enabled)
+
+
+def ahead_stream(device) -> "torch.cuda.Stream | None":
+    """The side stream of *device* for work ahead of the data (``None`` on the host or when switched off)."""
+    device = torch.device(device)
+    if device.type != "cuda" or not _AHEAD_ENABLED:
+        return None
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = _AHEAD_STREAMS.get(index)
+    if stream is None:
+        stream = _AHEAD_STREAMS[index] = torch.cuda.Stream(device=index)
+    return stream
+
+
+class Ahead:
+    """Device tensors prepared on the side stream + the event that says they are ready."""
+
+    __slots__ = ("tensors", "event", "payload")
+
+    def __init__(self) -> None:
+        self.tensors: list[Tensor] = []
+        self.event = None
+        self.payload = None
+
+    def join(self, device) -> None:
+        """Order the current stream of *device* behind the preparation and hand the buffers over to it."""
+        if self.event is None:
+            return
+        current = torch.cuda.current_stream(device)
+        current.wait_event(self.event)
+        for tensor in self.tensors:
+            tensor.record_stream(current)
+        self.event = None
+
+
 def folded_channel_min(data: Tensor) -> Tensor | None:
     """The per-channel minimum of element 0 that the launch which produced *data* left behind, if it did and the
     tensor has not been written since (``Engine.resample3d``); ``None`` otherwise."""
@@ -564,6 +627,70 @@ class Engine:
         return flags.to(torch.uint8).contiguous()
 
     # -- spatial ------------------------------------------------------------
+    def _resample_geom(
+        self, batch: int, in_shape, out_shape, mapping: Tensor, control_points: Tensor | None, in_spacing, out_spacing,
+        affine_first: bool, cp_skip: Tensor | None, passthrough: Tensor | None, norm_shape, precision: str | None,
+    ):
+        """``tio_resample_geom`` of one launch and the tensors it points into (mapping, control points, flags — keep them alive)."""
+        if mapping.dtype != torch.float32 or not mapping.is_contiguous():
+            mapping = mapping.to(torch.float32).contiguous()
+        if mapping.ndim != 3 or mapping.shape[1:] != (3, 4) or mapping.shape[0] not in (1, batch):
+            raise ValueError(f"mapping must be (1|B, 3, 4), got {tuple(mapping.shape)}")
+        geom = _abi.ResampleGeom()
+        geom.batch = batch
+        geom.in_shape = _i32x3(in_shape)
+        geom.out_shape = _i32x3(out_shape)
+        geom.affine_first = int(bool(affine_first))
+        geom.mapping_dev = mapping.data_ptr()
+        geom.mapping_batched = int(mapping.shape[0] == batch and batch > 1)
+        if control_points is not None:
+            if control_points.dtype != torch.float32 or not control_points.is_contiguous():
+                control_points = control_points.to(torch.float32).contiguous()
+            if control_points.ndim != 5 or control_points.shape[-1] != 3 or control_points.shape[0] not in (1, batch):
+                raise ValueError(f"control_points must be (1|B, ni, nj, nk, 3), got {tuple(control_points.shape)}")
+            geom.control_points_dev = control_points.data_ptr()
+            geom.cp_batched = int(control_points.shape[0] == batch and batch > 1)
+            geom.cp_shape = _i32x3(control_points.shape[1:4])
+        cp_skip = self._flags(cp_skip, batch, "cp_skip")
+        passthrough = self._flags(passthrough, batch, "passthrough")
+        geom.cp_skip_dev = None if cp_skip is None else cp_skip.data_ptr()
+        geom.passthrough_dev = None if passthrough is None else passthrough.data_ptr()
+        geom.in_spacing = (C.c_float * 3)(*[float(s) for s in in_spacing])
+        geom.out_spacing = (C.c_float * 3)(*[float(s) for s in out_spacing])
+        if norm_shape is not None:  # the shape the coordinates are normalised with, when it is not the images' own
+            geom.norm_shape = _i32x3(norm_shape)
+        geom.precision = PRECISION_CODES[precision if precision is not None else _RESAMPLE_PRECISION]
+        self._check("resample3d", mapping, control_points, cp_skip, passthrough)
+        return geom, [mapping, control_points, cp_skip, passthrough]
+
+    def resample_plan(
+        self, *, batch: int, in_shape, out_shape, mapping: Tensor, control_points: Tensor | None, in_spacing, out_spacing,
+        affine_first: bool, cp_skip: Tensor | None = None, passthrough: Tensor | None = None, norm_shape=None,
+        precision: str | None = None,
+    ) -> Tensor | None:
+        """The brick plan of the launch ``resample3d`` would make for this geometry with float32 trilinear images, enqueued on
+        the CURRENT stream of the mapping's device (``tio_resample3d_plan``, ABI 11) — or ``None`` when that launch takes a
+        road without a plan (small batches, ...).  Hand the tensor to ``resample3d(..., plan=...)`` with the same geometry, on
+        a stream ordered behind this one; the planning kernel then leaves that call's critical path."""
+        if "resample3d_plan" not in self._fn or mapping.device.type != "cuda":
+            return None
+        geom, keep_alive = self._resample_geom(
+            batch, tuple(in_shape), tuple(int(s) for s in out_shape), mapping, control_points, in_spacing, out_spacing,
+            affine_first, cp_skip, passthrough, norm_shape, precision,
+        )
+        reference = keep_alive[0]
+        if reference.device.index != torch.cuda.current_device():
+            with torch.cuda.device(reference.device):
+                size = self._fn["resample3d_plan_bytes"](C.byref(geom))
+        else:
+            size = self._fn["resample3d_plan_bytes"](C.byref(geom))
+        if size <= 0:
+            return None
+        plan = torch.empty((size + 3) // 4, dtype=torch.int32, device=reference.device)
+        self._call("resample3d_plan", reference, C.byref(geom), C.c_void_p(plan.data_ptr()), size, self._stream(reference))
+        del keep_alive
+        return plan
+
     def resample3d(
         self,
         images: Sequence[Tensor],
@@ -582,6 +709,7 @@ class Engine:
         pad_labels: Sequence[float] | None = None,
         norm_shape: Sequence[int] | None = None,
         precision: str | None = None,
+        plan: Tensor | None = None,
         _adjoint_of: Sequence[Tensor] | None = None,
     ) -> list[Tensor]:
         """Resample every ``(B, C, I, J, K)`` tensor in *images* through one coordinate pass.
@@ -605,37 +733,15 @@ class Engine:
         batch = first.shape[0]
         in_shape = tuple(first.shape[2:])
         out_shape = tuple(int(s) for s in out_shape)
-        if mapping.dtype != torch.float32 or not mapping.is_contiguous():
-            mapping = mapping.to(torch.float32).contiguous()
-        if mapping.ndim != 3 or mapping.shape[1:] != (3, 4) or mapping.shape[0] not in (1, batch):
-            raise ValueError(f"mapping must be (1|B, 3, 4), got {tuple(mapping.shape)}")
-        geom = _abi.ResampleGeom()
-        geom.batch = batch
-        geom.in_shape = _i32x3(in_shape)
-        geom.out_shape = _i32x3(out_shape)
-        geom.affine_first = int(bool(affine_first))
-        geom.mapping_dev = mapping.data_ptr()
-        geom.mapping_batched = int(mapping.shape[0] == batch and batch > 1)
-        keep_alive = [mapping]
-        if control_points is not None:
-            if control_points.dtype != torch.float32 or not control_points.is_contiguous():
-                control_points = control_points.to(torch.float32).contiguous()
-            if control_points.ndim != 5 or control_points.shape[-1] != 3 or control_points.shape[0] not in (1, batch):
-                raise ValueError(f"control_points must be (1|B, ni, nj, nk, 3), got {tuple(control_points.shape)}")
-            geom.control_points_dev = control_points.data_ptr()
-            geom.cp_batched = int(control_points.shape[0] == batch and batch > 1)
-            geom.cp_shape = _i32x3(control_points.shape[1:4])
-            keep_alive.append(control_points)
-        cp_skip = self._flags(cp_skip, batch, "cp_skip")
-        passthrough = self._flags(passthrough, batch, "passthrough")
-        geom.cp_skip_dev = None if cp_skip is None else cp_skip.data_ptr()
-        geom.passthrough_dev = None if passthrough is None else passthrough.data_ptr()
-        geom.in_spacing = (C.c_float * 3)(*[float(s) for s in in_spacing])
-        geom.out_spacing = (C.c_float * 3)(*[float(s) for s in out_spacing])
-        if norm_shape is not None:  # the shape the coordinates are normalised with, when it is not the images' own
-            geom.norm_shape = _i32x3(norm_shape)
-        geom.precision = PRECISION_CODES[precision if precision is not None else _RESAMPLE_PRECISION]
-        self._check("resample3d", mapping, control_points, cp_skip, passthrough)
+        geom, keep_alive = self._resample_geom(
+            batch, in_shape, out_shape, mapping, control_points, in_spacing, out_spacing, affine_first, cp_skip, passthrough,
+            norm_shape, precision,
+        )
+        mapping, control_points, cp_skip, passthrough = keep_alive[:4]
+        if plan is not None and plan.device == first.device:  # made ahead by `resample_plan` for exactly this geometry
+            geom.plan_dev = plan.data_ptr()
+            geom.plan_bytes = plan.numel() * plan.element_size()
+            keep_alive.append(plan)
 
         # images that take part in autograd (float, trilinear): the kernel sees the detached data, the result gets
         # the adjoint launch as its backward
@@ -650,15 +756,16 @@ class Engine:
         else:  # (the usual call: nothing takes part in autograd)
             wants = [False] * len(images)
 
-        # The folded minimum (opt-in, TIO_FOLDED_MIN=1): a large FAST launch can hand back the per-channel minimum of
-        # element 0 of each output (tio_resample_image.out_min_dev), which is what the NEXT spatial transform's
-        # default_pad_value="minimum" will ask of exactly this tensor (`folded_channel_min`).  Measured on the bench step
-        # (DESIGN.md section 7): the tracking costs every planned launch ~17 us, the reduction it saves is ~26 us for the
-        # one consumer that exists — a wash, and a loss for pipelines whose next transform is not spatial — so it is off
-        # by default.  Requested only where the C side folds it (the rule of resample.hip's planned path, mirrored
-        # loosely: a miss costs one tio_channel_min launch, never a wrong value).
+        # The folded minimum: a large FAST launch can hand back the per-channel minimum of element 0 of each output
+        # (tio_resample_image.out_min_dev), which is what the NEXT spatial transform's default_pad_value="minimum" will ask
+        # of exactly this tensor (`folded_channel_min`).  Requested when somebody has announced that consumer
+        # (`expect_minimum_fill`: a Compose that draws ahead knows its next child) or with TIO_FOLDED_MIN=1; only the bricks of
+        # element 0 track what they store, in an instantiation of its own (resample_fast.hpp), and a ~2 us kernel decodes the
+        # result: it replaces the ~21 us reduction and its re-read of the volume.  Requested only where the C side folds it
+        # (the rule of resample.hip's planned path, mirrored loosely: a miss costs one tio_channel_min launch, never a wrong
+        # value).
         fold_min = (
-            _adjoint_of is None and geom.precision == _abi.PRECISION_FAST and os.environ.get("TIO_FOLDED_MIN", "") not in ("", "0")
+            _adjoint_of is None and geom.precision == _abi.PRECISION_FAST and (_MINIMUM_WANTED or os.environ.get("TIO_FOLDED_MIN", "") not in ("", "0"))
             and batch * -(-out_shape[0] // 16) * -(-out_shape[1] // 16) * -(-out_shape[2] // 16) >= 12288 and not any(wants)
             and len(images) <= _abi.MAX_IMAGES and all(t.dtype == torch.float32 for t in images) and all(c == _abi.LINEAR for c in codes)
         )

@@ -19,6 +19,7 @@ import contextlib
 import torch
 
 from ..data.batch import SubjectsBatch
+from .. import ops
 from .transform import Transform
 from .transform import _return_home
 from .transform import _stage_on_engine_device
@@ -61,9 +62,16 @@ class Compose(Transform):
             for transform, params in zip(self.transforms, drawn, strict=True):
                 if params is not None:
                     transform._prefetch(batch, params)
-            for transform, params in zip(self.transforms, drawn, strict=True):
-                if params is not None:
+            applying = [(transform, params) for transform, params in zip(self.transforms, drawn, strict=True) if params is not None]
+            try:
+                for index, (transform, params) in enumerate(applying):
+                    # the child after this one will ask for the minimum of what this one writes (default_pad_value="minimum"):
+                    # a large resampling launch folds it into its stores (ops.expect_minimum_fill)
+                    follower = applying[index + 1][0] if index + 1 < len(applying) else None
+                    ops.expect_minimum_fill(follower is not None and getattr(follower, "asks_minimum_fill", False))
                     batch = transform._apply_drawn(batch, params)
+            finally:
+                ops.expect_minimum_fill(False)
             return unwrap(batch)
         for transform in self.transforms:
             # Children apply without copying: the container copied the input once (compose.py:18-35).  For a child whose

@@ -149,6 +149,11 @@ class Spatial(SpatialTransform):
         return self.target is None
 
     @property
+    def asks_minimum_fill(self) -> bool:
+        """This transform's fill value is the minimum of the data it is handed (a producer that can fold it in does: `Compose`)."""
+        return self.default_pad_value == "minimum"
+
+    @property
     def draws_ahead(self) -> bool:
         # without a target the output grid is the input grid: sizes, affines and image names survive, and `make_params` reads
         # nothing else of the batch (transform.py: Transform.draws_ahead)
@@ -365,14 +370,66 @@ class Spatial(SpatialTransform):
         self._tag_batched(params, batch, n, keep, ["affine_matrix", "control_points", "max_displacement"])
         return params
 
+    def _prefetch(self, batch: SubjectsBatch, params: dict[str, Any]) -> None:
+        """Draw-ahead road (Compose): mapping, control points, flags and the brick plan of the fused launch depend on the drawn
+        parameters and the batch's geometry only — they go to the device on the side stream (`ops.ahead_stream`) now, while
+        the children before this one are still being enqueued (or their kernels still run); `apply_transform` picks them up."""
+        selected = params.get("selected_images", [])
+        if not selected or not isinstance(params, LazyParams):
+            return
+        first = batch.images[selected[0]]
+        tensor = first._data if hasattr(first, "_data") else first.data
+        side = ops.ahead_stream(tensor.device) if tensor.is_cuda else None
+        if side is None:
+            return
+        try:
+            target_space = _deserialize_space(params["target"])
+            matrix, field, displacement, per_sample = _resolve_spatial_params(params)
+            if target_space is None and matrix is None and field is None and displacement is None and per_sample is None:
+                return
+            ahead = ops.Ahead()
+            with torch.cuda.stream(side):
+                geometry = _prepare_launch_geometry(
+                    first, tensor.device, target_space=target_space, affine_matrix=matrix, control_points=field,
+                    max_displacement=displacement, per_sample=per_sample,
+                )
+                images = [batch.images[name] for name in selected]
+                if params["image_interpolation"] == "linear" and all(
+                    (img._data if hasattr(img, "_data") else img.data).dtype == torch.float32 or _is_label_batch(img) for img in images
+                ):  # (the launch of float32 trilinear images is the one that starts from a plan; label maps have their own kernel)
+                    geometry.plan = ops.engine().resample_plan(
+                        batch=first.batch_size, in_shape=geometry.in_shape, out_shape=geometry.out_shape, mapping=geometry.mapping_dev,
+                        control_points=geometry.field_tensor, in_spacing=geometry.in_affine.spacing, out_spacing=geometry.out_affine.spacing,
+                        affine_first=params["affine_first"], cp_skip=geometry.cp_skip, passthrough=geometry.passthrough_all,
+                    )
+                ahead.event = side.record_event()
+            ahead.tensors = [
+                t for t in (geometry.mapping_dev, geometry.field_tensor, geometry.cp_skip, geometry.passthrough_all, geometry.plan) if t is not None
+            ]
+            ahead.payload = geometry
+            params._ahead = ahead
+        except Exception:  # noqa: BLE001 — whatever is wrong with these parameters is reported by `apply_transform`, in its turn
+            params._ahead = None
+
     def apply_transform(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
         selected = params.get("selected_images", [])
         if not selected:
             return batch
+        ahead = getattr(params, "_ahead", None)
+        prepared = None
+        if ahead is not None:  # (Compose drew ahead: the launch geometry is on the device, or on its way on the side stream)
+            params._ahead = None
+            tensor = batch.images[selected[0]].data
+            if ahead.payload is not None and tensor.is_cuda and ahead.payload.mapping_dev.device == tensor.device:
+                ahead.join(tensor.device)
+                prepared = ahead.payload
         target_space = _deserialize_space(params["target"])
-        matrix, field, displacement, per_sample = _resolve_spatial_params(params)
-        if target_space is None and matrix is None and field is None and displacement is None and per_sample is None:
-            return batch  # exact no-op: nothing sampled / every element gated out (spatial.py:579-590)
+        if prepared is not None:  # (the parameters were resolved by `_prefetch`, which only prepares launches that sample)
+            matrix = field = displacement = per_sample = None
+        else:
+            matrix, field, displacement, per_sample = _resolve_spatial_params(params)
+            if target_space is None and matrix is None and field is None and displacement is None and per_sample is None:
+                return batch  # exact no-op: nothing sampled / every element gated out (spatial.py:579-590)
         _apply_spatial_to_batch(
             batch=batch,
             image_names=selected,
@@ -388,6 +445,7 @@ class Spatial(SpatialTransform):
             default_pad_value=params["default_pad_value"],
             default_pad_label=float(params["default_pad_label"]),
             per_sample=per_sample,
+            prepared=prepared,
         )
         return batch
 
@@ -568,38 +626,24 @@ class ElasticDeformation(Spatial):
         )
 
 
-# =============================================================================
-# functional seam S1 (SURVEY.md §8b): _apply_spatial_to_batch on the engine
-# =============================================================================
-def _apply_spatial_to_batch(
-    *,
-    batch: SubjectsBatch,
-    image_names: list[str],
-    target_space,
-    affine_matrix: np.ndarray | None,
-    control_points: Tensor | None,
-    max_displacement,
-    affine_first: bool,
-    image_interpolation: str,
-    label_interpolation: str,
-    one_hot_label_interpolation: str = "linear",
-    antialias: bool,
-    default_pad_value,
-    default_pad_label: float,
-    per_sample: _PerSampleGrids | None = None,
-) -> None:
-    """Resample every selected image of *batch* with one fused launch (spatial.py:1110-1272).
+class _LaunchGeometry:
+    """What every launch of one `_apply_spatial_to_batch` call shares, on the device: grids, mapping, control points, flags
+    (+ the brick plan of the fused launch when it was made ahead, `Spatial._prefetch`)."""
 
-    Same keyword signature as the reference function.  The geometry comes from the
-    first image (shape, affine); all selected images share it (checked in
-    ``make_params``).  With *per_sample* every batch element gets its own 3x4
-    mapping / control-point field; elements with no geometry and no target are
-    passed through bit-exactly (spatial.py:1167-1174).
-    """
-    if not image_names:
-        return
-    first = batch.images[image_names[0]]
-    device = first.data.device
+    __slots__ = ("in_shape", "in_affine", "out_shape", "out_affine", "mapping_dev", "field_tensor", "cp_skip", "passthrough_all", "flags", "plan")
+
+    def __init__(self, in_shape, in_affine, out_shape, out_affine, mapping_dev, field_tensor, cp_skip, passthrough_all, flags) -> None:
+        self.in_shape, self.in_affine, self.out_shape, self.out_affine = in_shape, in_affine, out_shape, out_affine
+        self.mapping_dev, self.field_tensor, self.cp_skip, self.passthrough_all, self.flags = mapping_dev, field_tensor, cp_skip, passthrough_all, flags
+        self.plan = None
+
+
+def _prepare_launch_geometry(
+    first: ImagesBatch, device, *, target_space, affine_matrix: np.ndarray | None, control_points: Tensor | None, max_displacement,
+    per_sample: _PerSampleGrids | None,
+) -> _LaunchGeometry:
+    """The parameter half of `_apply_spatial_to_batch`: reads the first image's geometry (never its voxels) and the drawn
+    parameters, uploads on the CURRENT stream of *device*."""
     batch_size = first.batch_size
     in_shape, in_affine = _spatial_shape(first), first.affines[0]
     out_shape, out_affine = target_space if target_space is not None else (in_shape, in_affine)
@@ -678,8 +722,54 @@ def _apply_spatial_to_batch(
     else:
         flags = [False] * batch_size
 
-    engine = ops.engine()
     mapping_dev = _identity_mapping(device) if mapping is None else ops.h2d(torch.from_numpy(mapping), device)
+    return _LaunchGeometry(in_shape, in_affine, out_shape, out_affine, mapping_dev, field_tensor, cp_skip, passthrough_all, flags)
+
+
+
+# =============================================================================
+# functional seam S1 (SURVEY.md §8b): _apply_spatial_to_batch on the engine
+# =============================================================================
+def _apply_spatial_to_batch(
+    *,
+    batch: SubjectsBatch,
+    image_names: list[str],
+    target_space,
+    affine_matrix: np.ndarray | None,
+    control_points: Tensor | None,
+    max_displacement,
+    affine_first: bool,
+    image_interpolation: str,
+    label_interpolation: str,
+    one_hot_label_interpolation: str = "linear",
+    antialias: bool,
+    default_pad_value,
+    default_pad_label: float,
+    per_sample: _PerSampleGrids | None = None,
+    prepared: "_LaunchGeometry | None" = None,
+) -> None:
+    """Resample every selected image of *batch* with one fused launch (spatial.py:1110-1272).
+
+    Same keyword signature as the reference function (plus *prepared*: the launch geometry when a `Compose` that draws
+    ahead has already put it on the device, `Spatial._prefetch`).  The geometry comes from the
+    first image (shape, affine); all selected images share it (checked in
+    ``make_params``).  With *per_sample* every batch element gets its own 3x4
+    mapping / control-point field; elements with no geometry and no target are
+    passed through bit-exactly (spatial.py:1167-1174).
+    """
+    if not image_names:
+        return
+    first = batch.images[image_names[0]]
+    if prepared is None:
+        prepared = _prepare_launch_geometry(
+            first, first.data.device, target_space=target_space, affine_matrix=affine_matrix, control_points=control_points,
+            max_displacement=max_displacement, per_sample=per_sample,
+        )
+    in_shape, in_affine, out_shape, out_affine = prepared.in_shape, prepared.in_affine, prepared.out_shape, prepared.out_affine
+    field_tensor, cp_skip, passthrough_all, flags, mapping_dev = (
+        prepared.field_tensor, prepared.cp_skip, prepared.passthrough_all, prepared.flags, prepared.mapping_dev
+    )
+    engine = ops.engine()
 
     def resample(tensors, interps, fills, gated=True, **label_arguments):
         passthrough = passthrough_all if gated else None
@@ -712,6 +802,7 @@ def _apply_spatial_to_batch(
             fills=fills,
             cp_skip=cp_skip,
             passthrough=passthrough,
+            plan=prepared.plan if gated else None,  # (made for the gated geometry of the fused call; ignored by calls that take another road)
             **label_arguments,
         )
 
