@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 11
+#define TIO_ABI_VERSION 12
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -279,7 +279,13 @@ int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, int32_t bat
                    const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],
                    int32_t noise_on, float noise_mean, float noise_std,
                    const float* noise_mean_dev, const float* noise_std_dev,
-                   int32_t noise_batched, uint64_t philox_seed, int32_t fast_math, void* stream);
+                   int32_t noise_batched, uint64_t philox_seed, const float* noise_base_dev,
+                   int32_t fast_math, void* stream);
+/* noise_on (ABI 12): 0 = no noise stage; 1 = in-kernel Philox draws (philox_seed), as tio_add_noise with base1_dev == NULL;
+ * 2 = explicit draws: noise_base_dev holds one float32 normal draw per element, laid out like x (16-byte aligned) — as
+ * tio_add_noise with base1_dev.  This is how the REFERENCE's noise stream (noise.py:108-116: one seeded CPU generator,
+ * reproduced on the device by tio_mt19937_randn_device) rides on the stencil's stores: the draws are made ahead on another
+ * stream, the sum x + (mean + std z) costs no pass of its own.  Same float32 operations as tio_add_noise. */
 /* fast_math (ABI 8): 0 = every tap is `acc = acc + w * v` with two roundings, the reference's accumulation (bit-identical
  * to tio_separable_conv3d); 1 = fused multiply-adds in the register-window passes (radii <= 8): one rounding per tap,
  * results within float rounding of the exact ones (~1e-7 relative; the contract for intensities is 1e-4), and a J+K pass

@@ -41,6 +41,19 @@ for step in "$@"; do
        timeout 300 rocprofv3 --kernel-trace --stats -d $O -o headline --output-format csv -- python $R/bench.py --steps 20 --no-cpu-baseline --no-aten-baseline --no-other-configs --no-mode-matrix > $O/headline.log 2>&1
        timeout 300 rocprofv3 --kernel-trace --stats -d $O -o reference --output-format csv -- python $R/bench.py --steps 20 --noise-rng reference --resample-precision exact --no-cpu-baseline --no-aten-baseline --no-other-configs --no-mode-matrix > $O/reference.log 2>&1)
       for f in headline reference; do echo "== $f"; find $O -name "${f}_kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -12 {} | cut -c1-170'; tail -c 400 $O/$f.log | head -c 400; echo; done ;;
+    prof_refnoise)
+      # reference-noise modes: where the host's time goes (cProfile) and what the GPU runs (rocprofv3 kernel statistics), with the
+      # draws ahead on the draw stream and on the previous road (TIO_NO_DRAW_STREAM=1)
+      R=$PWD; O=$R/gpurun_out/r4b_prof_refnoise; mkdir -p $O
+      for road in 0 1; do
+        echo "== host profile, reference,fast, TIO_NO_DRAW_STREAM=$road"
+        TIO_NO_DRAW_STREAM=$road TIO_PROFILE_MODE=reference,fast timeout 200 python scripts/host_profile.py tottime 2>&1 | grep -v "^$" | head -34 | cut -c1-150 | tee $O/host_profile_road$road.txt
+      done
+      (cd /tmp && export TMPDIR=/tmp
+       for road in 0 1; do
+         TIO_NO_DRAW_STREAM=$road timeout 300 rocprofv3 --kernel-trace --stats -d $O -o road$road --output-format csv -- python $R/bench.py --steps 30 --noise-rng reference --resample-precision fast --no-cpu-baseline --no-aten-baseline --no-other-configs --no-mode-matrix > $O/road$road.log 2>&1
+       done)
+      for road in 0 1; do echo "== kernels, TIO_NO_DRAW_STREAM=$road"; find $O -name "road${road}_kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -14 {} | cut -c1-150'; python -c "import json,sys; d=json.loads(open('$O/road$road.log').read().strip().splitlines()[-1]); print(round(d['value'],1), 'vol/s', round(d['ms_per_step'],4), 'ms/step host', round(d['host_enqueue_ms_per_step'],3))"; done ;;
     pmc)
       # HBM traffic of the lean planned kernels (FETCH_SIZE / WRITE_SIZE, separate passes, with the calibration kernels of known byte counts)
       R=$PWD; B=$R/tests/native/_build/resample_bench; O=$R/gpurun_out/r4_pmc; mkdir -p $O

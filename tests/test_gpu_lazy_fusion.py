@@ -185,3 +185,84 @@ def test_host_resident_subjects_are_staged_through_the_device(hip, oracle):
         assert got.t1.data.device.type == "cpu" and torch.equal(got.seg.data, want.seg.data)
     finally:
         tio.set_noise_rng(previous)
+
+
+# ---- the REFERENCE's noise stream on the stencil's stores (round 4: tio_blur_fused(noise_on = 2), HostNormalStream.randn_ahead) ----
+def _reference_noise_expected(transform_without_noise, gpu_batch, seed_of_step, history, names):
+    """blurred + (mean + std * torch.randn(shape, generator=Generator().manual_seed(seed))) — ONE generator for all images of
+    the call, in dict order (noise.py:108-116) — computed with torch on the host from the recorded parameters."""
+    torch.manual_seed(seed_of_step)
+    blurred = transform_without_noise(gpu_batch)
+    params = history[-1].params
+    generator = torch.Generator().manual_seed(params["seed"])
+    expected = {}
+    for name in names:
+        x = getattr(blurred, name).data.cpu()
+        z = torch.randn(x.shape, generator=generator)
+        mean = torch.tensor(params["mean"], dtype=torch.float32).reshape(-1, 1, 1, 1, 1) if isinstance(params["mean"], list) else params["mean"]
+        std = torch.tensor(params["std"], dtype=torch.float32).reshape(-1, 1, 1, 1, 1) if isinstance(params["std"], list) else params["std"]
+        expected[name] = x + (mean + std * z)
+    return expected
+
+
+@pytest.mark.parametrize("size,batch,per_instance,second", [(72, 3, True, False), (112, 1, False, False), (64, 5, True, True)])
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_reference_noise_rides_on_the_stencil_stores(hip, size, batch, per_instance, second, precision):
+    """Noise mode "reference": the draws of the seeded CPU generator are made ahead on the draw stream and added by the fused
+    J + K pass.  Same bits as the separate launches (which are pinned to torch.randn by tests/test_gpu_device_rng.py) and as
+    torch's own stream applied on the host; two float images share ONE generator in dict order."""
+    subjects = make_subjects(size, batch, seed=23, with_label=False, second_modality=second)
+    gpu_batch = tio.SubjectsBatch.from_subjects(subjects).to("cuda")
+    names = ["t1", "t2"] if second else ["t1"]
+    head = lambda: [tio.BiasField(per_instance=per_instance), tio.Blur(std=(0.5, 2), per_instance=per_instance)]  # noqa: E731
+    transform = tio.Compose([*head(), tio.Noise(per_instance=per_instance)])
+    previous, previous_stencil = tio.get_noise_rng(), tio.get_stencil_precision()
+    tio.set_noise_rng("reference")
+    tio.set_stencil_precision(precision)
+    try:
+        seen_draws = []
+        original = hip.blur_fused
+
+        def spying(data, taps, radius, *, bias_coarse=None, noise=None):
+            out = original(data, taps, radius, bias_coarse=bias_coarse, noise=noise)
+            if out is not None and noise is not None:
+                seen_draws.append(isinstance(noise[2], torch.Tensor))
+            return out
+
+        hip.blur_fused = spying
+        try:
+            fused, _ = _run(transform, gpu_batch, 5, lazy=True)
+            fused_data = {name: getattr(fused, name).data.clone() for name in names}
+        finally:
+            del hip.blur_fused
+        assert seen_draws == [True] * len(names), seen_draws  # every float image: explicit draws on the fused launch
+        plain, _ = _run(transform, gpu_batch, 5, lazy=False)
+        assert [t.params for t in fused.applied_transforms] == [t.params for t in plain.applied_transforms]
+        if precision == "exact":  # (the fast taps only exist in the fused launch)
+            for name in names:
+                assert torch.equal(fused_data[name], getattr(plain, name).data), name
+        expected = _reference_noise_expected(tio.Compose(head()), gpu_batch, 5, fused.applied_transforms, names)
+        for name in names:
+            if precision == "exact":
+                assert torch.equal(fused_data[name].cpu(), expected[name]), name
+            else:
+                torch.testing.assert_close(fused_data[name].cpu(), expected[name], rtol=0, atol=4e-6)
+        # the generator of the global stream ends where the reference's would: the next draw is the same either way
+        torch.manual_seed(5)
+        transform(gpu_batch)
+        probe_a = torch.rand(3)
+        torch.manual_seed(5)
+        os.environ["TIO_NO_DRAW_STREAM"] = "1"
+        try:
+            again = transform(gpu_batch)
+            again_data = {name: getattr(again, name).data for name in names}
+        finally:
+            os.environ.pop("TIO_NO_DRAW_STREAM", None)
+        probe_b = torch.rand(3)
+        assert torch.equal(probe_a, probe_b)
+        for name in names:  # the switch takes the previous road (draws + sum in one kernel after the stencil): same values
+            if precision == "exact":
+                assert torch.equal(again_data[name], fused_data[name])
+    finally:
+        tio.set_noise_rng(previous)
+        tio.set_stencil_precision(previous_stencil)

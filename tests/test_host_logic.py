@@ -768,3 +768,31 @@ def test_compose_does_not_draw_ahead_across_a_change_of_geometry(monkeypatch):
     hooked = tio.Noise()
     hooked.register_forward_hook(lambda module, args, output: output)
     assert not tio.Compose([tio.Affine(degrees=5), hooked])._may_draw_ahead()
+
+
+def test_compose_prepares_threaded_children_first_and_applies_in_order(monkeypatch):
+    """Draw-ahead road: the DRAWS and the APPLICATIONS keep the children's order (the global generator's sequence, the data's
+    dependencies); only the preparations are reordered — a child whose `_prefetch` hands work to a native thread (Noise: the
+    plan of its generator's stream) prepares before the others, so that their preparation runs beside that thread."""
+    monkeypatch.delenv("TIO_NO_DRAW_AHEAD", raising=False)
+    pipeline = tio.Compose([tio.Affine(degrees=5), tio.BiasField(), tio.Blur(std=(0.5, 1.0)), tio.Noise()])
+    assert pipeline._may_draw_ahead() and tio.Noise.prefetch_is_threaded
+    events = []
+    for child in pipeline.transforms:
+        name = type(child).__name__
+        for phase in ("make_params", "_prefetch", "apply_transform"):
+            original = getattr(child, phase)
+
+            def wrapper(*args, _original=original, _name=name, _phase=phase, **kwargs):
+                events.append((_phase, _name))
+                return _original(*args, **kwargs)
+
+            monkeypatch.setattr(child, phase, wrapper)
+    torch.manual_seed(3)
+    pipeline(tio.SubjectsBatch.from_subjects([subject(size=10, seed=1)]))
+    order = ["Affine", "BiasField", "Blur", "Noise"]
+    assert [name for phase, name in events if phase == "make_params"] == order
+    assert [name for phase, name in events if phase == "apply_transform"] == order
+    assert [name for phase, name in events if phase == "_prefetch"] == ["Noise", "Affine", "BiasField", "Blur"]
+    first_apply = next(i for i, (phase, _) in enumerate(events) if phase == "apply_transform")
+    assert all(phase != "_prefetch" for phase, _ in events[first_apply:])  # every preparation before the first application

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_IMAGES = 8
 
 # tio_status
@@ -157,7 +157,7 @@ HIP_ONLY_PROTOTYPES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, C.c_int32,
          _I32x3, C.c_void_p, _I32x3, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64,
-         C.c_int32, C.c_void_p],
+         C.c_void_p, C.c_int32, C.c_void_p],
     ),
 }
 

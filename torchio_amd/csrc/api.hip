@@ -59,7 +59,6 @@ static const EnvSwitches* parse_env() {
   e->march_segs = num("TIO_MARCH_SEGS", 0);
   e->march_order = num("TIO_MARCH_ORDER", -1);
   e->min_blocks = num("TIO_MIN_BLOCKS", 0);
-  e->one_pass_blur = num("TIO_ONE_PASS_BLUR", 1) != 0;
   return e;
 }
 

@@ -41,7 +41,6 @@ struct EnvSwitches {
   int march_segs = 0;            // TIO_MARCH_SEGS (0 unset)
   int march_order = -1;          // TIO_MARCH_ORDER (-1 unset)
   int min_blocks = 0;            // TIO_MIN_BLOCKS (0 unset)
-  int one_pass_blur = 1;         // TIO_ONE_PASS_BLUR (0: the two marching passes, A/B)
 };
 const EnvSwitches& env_switches();
 

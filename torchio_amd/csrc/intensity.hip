@@ -97,6 +97,7 @@ struct ConvArgs {
   const float* noise_mean_b;
   const float* noise_std_b;
   uint64_t noise_seed;
+  const float* noise_base;  // noise_on == 2: the normal draws of every element, laid out like the data (the reference's seeded stream)
   // tio_blur_fused(fast_math = 1): the taps of the marching kernel accumulate with fused multiply-adds (one rounding per
   // tap instead of the reference's two: results within float rounding, ~1e-7 relative — the J+K pass is bound by vector
   // instructions, not by memory, and the taps are two thirds of them)
@@ -214,7 +215,7 @@ constexpr int kConvMaxRadiusV4 = 16;  // (32 + 2*16) rows x 1 KiB = 64 KiB of LD
 
 constexpr int kConvStep = 16;  // output rows per marching step (axes I, J)
 
-template <bool FUSE_K, bool PRE_BIAS, bool POST_NOISE>
+template <bool FUSE_K, bool PRE_BIAS, int POST_NOISE>
 __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) {
   // axes I and J.  grid: x = K tiles (256 = 64 lanes x float4), y = segments along the axis, z = other axis * (B*C).
   // A block marches along the stencil axis with a ring of kConvStep + 2r + kConvStep rows in
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   const_float_ptr tk = (const_float_ptr)(a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride);
   (void)s_taps; (void)tk; (void)s_krow;
   float noise_mu = a.noise_mean, noise_sd = a.noise_std;  // scalar loads, once (see conv_march_kernel)
-  if constexpr (POST_NOISE) {
+  if constexpr (POST_NOISE != 0) {
     if (a.noise_batched) {
       noise_mu = ((const_float_ptr)a.noise_mean_b)[b];
       noise_sd = ((const_float_ptr)a.noise_std_b)[b];
@@ -395,12 +396,17 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
             acc = out;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if constexpr (POST_NOISE) {
+            if constexpr (POST_NOISE != 0) {
               // the arithmetic of noise_kernel's 16-byte path: same Philox block (global element
               // index >> 2), same mean + std * z, same add
               const int64_t e0 = line + static_cast<int64_t>(p0 + o) * stride;  // element index of acc.x in the tensor
               float z[4];
-              philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
+              if constexpr (POST_NOISE == 2) {  // explicit draws (tio_add_noise with base1_dev): the reference's own stream
+                const float4 zb = *reinterpret_cast<const float4*>(a.noise_base + e0);
+                z[0] = zb.x; z[1] = zb.y; z[2] = zb.z; z[3] = zb.w;
+              } else {
+                philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
+              }
               const float mu = noise_mu, sd = noise_sd;
               acc.x = __fadd_rn(acc.x, __fadd_rn(mu, __fmul_rn(sd, z[0])));
               acc.y = __fadd_rn(acc.y, __fadd_rn(mu, __fmul_rn(sd, z[1])));
@@ -452,7 +458,7 @@ constexpr int kMarchMaxRadius = 8;
 #endif
 constexpr int kMarchAhead = TIO_MARCH_AHEAD;
 
-template <int R, bool FUSE_K, bool PRE_BIAS, bool POST_NOISE>
+template <int R, bool FUSE_K, bool PRE_BIAS, int POST_NOISE>
 __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
   constexpr int W = 2 * R + 1;
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
   // the marching loop they sit behind a branch, and the compiler's wait at the join is vmcnt(0) - it
   // drained the two prefetched rows (and the previous store) on every row
   float noise_mu = a.noise_mean, noise_sd = a.noise_std;
-  if constexpr (POST_NOISE) {
+  if constexpr (POST_NOISE != 0) {
     if (a.noise_batched) {
       noise_mu = ((const_float_ptr)a.noise_mean_b)[b];
       noise_sd = ((const_float_ptr)a.noise_std_b)[b];
@@ -581,6 +587,11 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
       win[(2 * R + u) % W] = bias_row(nxt[0], TIO_ROW_POS(p + R));
 #pragma unroll
       for (int d = 0; d + 1 < kMarchAhead; d++) nxt[d] = nxt[d + 1];
+      // explicit draws of this output row: requested BEFORE the row that is loaded ahead (vector loads return in order: the
+      // wait in front of the sum then leaves the newer row load in flight), used a whole window of taps later
+      v4f zrow = {0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (POST_NOISE == 2) zrow = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(a.noise_base + line + static_cast<int64_t>(p) * stride));
+      (void)zrow;
       nxt[kMarchAhead - 1] = TIO_ROW_LOAD(p + R + kMarchAhead);
       float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (a.fma) {  // (block uniform)
@@ -648,10 +659,14 @@ __global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
         acc = out;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if constexpr (POST_NOISE) {  // the arithmetic of noise_kernel's 16-byte path
+        if constexpr (POST_NOISE != 0) {  // the arithmetic of noise_kernel's 16-byte path
           const int64_t e0 = line + static_cast<int64_t>(p) * stride;
           float z[4];
-          philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
+          if constexpr (POST_NOISE == 2) {
+            z[0] = zrow.x; z[1] = zrow.y; z[2] = zrow.z; z[3] = zrow.w;
+          } else {
+            philox_normal4(a.noise_seed, 0, static_cast<uint64_t>(e0 >> 2), z);
+          }
           const float mu = noise_mu, sd = noise_sd;
           acc.x = __fadd_rn(acc.x, __fadd_rn(mu, __fmul_rn(sd, z[0])));
           acc.y = __fadd_rn(acc.y, __fadd_rn(mu, __fmul_rn(sd, z[1])));
@@ -803,6 +818,7 @@ struct ConvFuse {  // optional pointwise stages of tio_blur_fused
   const float* noise_mean_b = nullptr;
   const float* noise_std_b = nullptr;
   uint64_t noise_seed = 0;
+  const float* noise_base = nullptr;
   int fma = 0;
   bool any() const { return bias_coarse != nullptr || noise_on != 0; }
 };
@@ -875,13 +891,14 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
         a.radius_k = fused ? radius[2] : 0;
         const bool pre_bias = axis == 0 && fuse.bias_coarse != nullptr;
         const bool post_noise = fused && fuse.noise_on != 0;
+        const bool noise_base = post_noise && fuse.noise_on == 2;
         if (pre_bias) {
           a.bias_coarse = fuse.bias_coarse;
           a.bias_ci = fuse.bias_shape[0]; a.bias_cj = fuse.bias_shape[1]; a.bias_ck = fuse.bias_shape[2];
           a.bias_si = lerp_scale(a.bias_ci, shape[0]); a.bias_sj = lerp_scale(a.bias_cj, shape[1]); a.bias_sk = lerp_scale(a.bias_ck, shape[2]);
         }
         if (post_noise) {
-          a.noise_on = 1; a.noise_batched = fuse.noise_batched; a.noise_mean = fuse.noise_mean; a.noise_std = fuse.noise_std;
+          a.noise_on = fuse.noise_on; a.noise_base = fuse.noise_base; a.noise_batched = fuse.noise_batched; a.noise_mean = fuse.noise_mean; a.noise_std = fuse.noise_std;
           a.noise_mean_b = fuse.noise_mean_b; a.noise_std_b = fuse.noise_std_b; a.noise_seed = fuse.noise_seed;
         }
         // (the bias variant needs > 240 VGPRs beyond radius 6: the LDS ring kernel is the better choice there)
@@ -902,10 +919,11 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
           if (a.tiles_a) std::swap(grid.x, grid.z);
 #define TIO_MARCH_VARIANT(RR)                                                                              \
   {                                                                                                        \
-    if (fused && post_noise) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, true>), grid, dim3(kBlock), lds, stream, a);  \
-    else if (fused) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, false>), grid, dim3(kBlock), lds, stream, a);          \
-    else if (pre_bias) hipLaunchKernelGGL((conv_march_kernel<RR, false, true, false>), grid, dim3(kBlock), lds, stream, a);       \
-    else hipLaunchKernelGGL((conv_march_kernel<RR, false, false, false>), grid, dim3(kBlock), lds, stream, a);                    \
+    if (fused && noise_base) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 2>), grid, dim3(kBlock), lds, stream, a);     \
+    else if (fused && post_noise) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 1>), grid, dim3(kBlock), lds, stream, a); \
+    else if (fused) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 0>), grid, dim3(kBlock), lds, stream, a);              \
+    else if (pre_bias) hipLaunchKernelGGL((conv_march_kernel<RR, false, true, 0>), grid, dim3(kBlock), lds, stream, a);           \
+    else hipLaunchKernelGGL((conv_march_kernel<RR, false, false, 0>), grid, dim3(kBlock), lds, stream, a);                        \
   }
           switch (radius[axis]) {
             case 1: TIO_MARCH_VARIANT(1) break;
@@ -930,10 +948,11 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
       return fail(TIO_ERR_LAUNCH, "tio_separable_conv3d: cannot reserve %zu bytes of LDS", lds);                       \
     hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, stream, a);                                                      \
   }
-        if (fused && post_noise) TIO_LINE_LAUNCH(true, false, true)
-        else if (fused) TIO_LINE_LAUNCH(true, false, false)
-        else if (pre_bias) TIO_LINE_LAUNCH(false, true, false)
-        else TIO_LINE_LAUNCH(false, false, false)
+        if (fused && noise_base) TIO_LINE_LAUNCH(true, false, 2)
+        else if (fused && post_noise) TIO_LINE_LAUNCH(true, false, 1)
+        else if (fused) TIO_LINE_LAUNCH(true, false, 0)
+        else if (pre_bias) TIO_LINE_LAUNCH(false, true, 0)
+        else TIO_LINE_LAUNCH(false, false, 0)
 #undef TIO_LINE_LAUNCH
       }
       src = dst;
@@ -1349,7 +1368,8 @@ extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, 
                               const int32_t shape[3], const float* taps_dev, int32_t taps_batched, int32_t tap_stride,
                               const int32_t radius[3], const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],
                               int32_t noise_on, float noise_mean, float noise_std, const float* noise_mean_dev,
-                              const float* noise_std_dev, int32_t noise_batched, uint64_t philox_seed, int32_t fast_math, void* stream) {
+                              const float* noise_std_dev, int32_t noise_batched, uint64_t philox_seed, const float* noise_base_dev,
+                              int32_t fast_math, void* stream) {
   if (batch == 0) return TIO_OK;
   if (x == nullptr || y == nullptr || tmp == nullptr || shape == nullptr || radius == nullptr || taps_dev == nullptr)
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: null argument");
@@ -1367,6 +1387,9 @@ extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, 
   }
   if (noise_on && noise_batched && (noise_mean_dev == nullptr || noise_std_dev == nullptr))
     return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: batched noise needs mean_dev and std_dev");
+  if (noise_on < 0 || noise_on > 2) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: noise_on must be 0, 1 or 2");
+  if (noise_on == 2 && noise_base_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_blur_fused: noise_on == 2 needs noise_base_dev");
+  if (noise_on == 2 && (reinterpret_cast<uintptr_t>(noise_base_dev) & 15) != 0) return TIO_ERR_UNSUPPORTED_CONFIG;
   if (batch == 0) return TIO_OK;
   const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
   ConvFuse fuse;
@@ -1375,6 +1398,7 @@ extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, 
     for (int d = 0; d < 3; d++) fuse.bias_shape[d] = bias_coarse_shape[d];
   fuse.noise_on = noise_on; fuse.noise_batched = noise_batched; fuse.noise_mean = noise_mean; fuse.noise_std = noise_std;
   fuse.noise_mean_b = noise_mean_dev; fuse.noise_std_b = noise_std_dev; fuse.noise_seed = philox_seed;
+  fuse.noise_base = noise_on == 2 ? noise_base_dev : nullptr;
   fuse.fma = fast_math != 0;
   float* tmp0 = static_cast<float*>(tmp);
   float* tmp1 = tmp0 + static_cast<int64_t>(batch) * channels * n;

@@ -46,7 +46,10 @@ def eligible(data: Tensor) -> bool:
 
 
 def flush(data: Tensor, pending: Pending, *, noise: tuple | None = None) -> Tensor:
-    """Run what is queued (optionally with a trailing noise stage) and return the finished tensor."""
+    """Run what is queued (optionally with a trailing noise stage) and return the finished tensor.
+
+    ``noise``: ``(mean, std, source)`` — *source* a Philox seed word, a tensor of explicit draws shaped like the data, or a
+    callable returning either (called once, after the parameter uploads)."""
     from .. import ops  # noqa: PLC0415
 
     engine = ops.engine()
@@ -62,7 +65,12 @@ def flush(data: Tensor, pending: Pending, *, noise: tuple | None = None) -> Tens
     if pending.blur is not None:
         pending.blur = (taps_dev, pending.blur[1])
     if noise is not None:
-        noise = (mean_dev if host_mean is not None else mean, std_dev if host_std is not None else std, noise[2])
+        source = noise[2]
+        if callable(source):
+            # explicit draws that are still being prepared (the reference's stream: the host may have to wait for the plan of the
+            # generator's state chain here) — asked for AFTER the uploads above have been enqueued, so that wait overlaps them
+            source = source()
+        noise = (mean_dev if host_mean is not None else mean, std_dev if host_std is not None else std, source)
     if pending.blur is not None:
         taps, radius = pending.blur
         fused = engine.blur_fused(data, taps, radius, bias_coarse=pending.bias_coarse, noise=noise)
@@ -76,5 +84,8 @@ def flush(data: Tensor, pending: Pending, *, noise: tuple | None = None) -> Tens
         data = engine.separable_conv3d(data, taps, radius)
     if noise is not None:
         mean, std, seed = noise
-        data = engine.add_noise(data, mean, std, philox_seed=seed)
+        if isinstance(seed, Tensor):  # explicit draws (the reference's stream, made ahead): the same sum as its own pass
+            data = engine.add_noise(data, mean, std, base1=seed.view(data.shape))
+        else:
+            data = engine.add_noise(data, mean, std, philox_seed=seed)
     return data

@@ -9,6 +9,7 @@ reference transform.py:220-221).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 import threading
@@ -176,6 +177,76 @@ def ahead_stream(device) -> "torch.cuda.Stream | None":
     if stream is None:
         stream = _AHEAD_STREAMS[index] = torch.cuda.Stream(device=index)
     return stream
+
+
+_DRAW_STREAMS: dict[int, "torch.cuda.Stream"] = {}
+_DRAW_MARKS: dict = {}
+_DRAWS_IN_FLIGHT = 4
+
+
+def draw_stream(device) -> "torch.cuda.Stream | None":
+    """The stream of *device* on which the reference's noise stream is drawn ahead of the data (``HostNormalStream.randn_ahead``).
+    A stream of its own: a draw kernel runs for a third of a millisecond, and the brick plans of the next step — which the
+    data stream waits for — must not queue behind it on ``ahead_stream``."""
+    device = torch.device(device)
+    if device.type != "cuda" or not _AHEAD_ENABLED or os.environ.get("TIO_NO_DRAW_STREAM", "") not in ("", "0"):
+        return None
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = _DRAW_STREAMS.get(index)
+    if stream is None:
+        stream = _DRAW_STREAMS[index] = _low_priority_stream(index) or torch.cuda.Stream(device=index)
+    return stream
+
+
+def _low_priority_stream(index: int):
+    """A HIP stream of the LOWEST priority the device offers (torch hands out default- and high-priority streams only), wrapped
+    for torch — the dispatcher then prefers the data stream's workgroups whenever both have some ready.  ``None`` when the
+    runtime cannot be reached this way or offers one priority only (``TIO_DRAW_STREAM_PRIORITY=default`` switches it off)."""
+    if os.environ.get("TIO_DRAW_STREAM_PRIORITY", "low") != "low":
+        return None
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        least, greatest = C.c_int(0), C.c_int(0)
+        if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0 or least.value == greatest.value:
+            return None
+        handle = C.c_void_p()
+        with torch.cuda.device(index):
+            if hip.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), C.c_int(least.value)) != 0 or not handle.value:  # 1 = non-blocking
+                return None
+        return torch.cuda.ExternalStream(handle.value, device=index)
+    except (OSError, AttributeError, RuntimeError):
+        return None
+
+
+def on_draw_stream(device, make):
+    """``make()`` — a launch that produces a tensor of draws and depends on nothing on the data stream — enqueued on the draw
+    stream of *device*; the current stream is ordered behind it by an event and takes the buffer over.  ``None`` when there
+    is no draw stream (host tensors, switched off)."""
+    device = torch.device(device)
+    side = draw_stream(device)
+    if side is None:
+        return None
+    with torch.cuda.device(device):
+        main = torch.cuda.current_stream()
+        # Back-pressure: the draw stream waits for nothing on the data stream, so with a host that enqueues faster than the data
+        # stream works it would run ahead without bound — one buffer of draws (as large as the image batch) per step.  Every
+        # call marks the data stream ("the consumers of all earlier draws are enqueued before this point") and waits, on the
+        # host, for the mark of `_DRAWS_IN_FLIGHT` calls ago.
+        marks = _DRAW_MARKS.setdefault((side.device.index, main.stream_id), collections.deque())
+        mark = torch.cuda.Event()
+        mark.record(main)
+        marks.append(mark)
+        if len(marks) > _DRAWS_IN_FLIGHT:
+            marks.popleft().synchronize()
+        with torch.cuda.stream(side):
+            out = make()
+            if out is None:
+                return None
+            done = torch.cuda.Event()
+            done.record(side)
+        main.wait_event(done)
+        out.record_stream(main)
+    return out
 
 
 class Ahead:
@@ -369,6 +440,40 @@ class HostNormalStream:
         plan_dev.copy_(plan_host[: used.value], non_blocking=True)
         HostNormalStream._rings().uploaded[id(plan_host)].record()
         return plan_host, plan_dev
+
+    def can_draw_ahead(self, shape, device) -> bool:
+        """Can :meth:`randn_ahead` take these draws?  (Nothing is drawn; a stream that stands inside a group of 16 still
+        declines later — the caller then draws with :meth:`randn`.)"""
+        count = 1
+        for extent in shape:
+            count *= int(extent)
+        device = torch.device(device)
+        ahead = self._prefetched
+        return not (
+            draw_stream(device) is None or count < self.DEVICE_DRAW_MIN or os.environ.get("TIO_DEVICE_RNG", "1") == "0"
+            or (ahead is not None and (count != ahead[0] or device != ahead[1]))
+        )
+
+    def randn_ahead(self, shape, device) -> Tensor | None:
+        """The next draws of this stream, made on the device's DRAW stream (``draw_stream``) instead of the data's: the kernel
+        that turns the plan into normal draws is bound by vector arithmetic (torch's Box-Muller, ~135 instructions per pair)
+        and depends on nothing but the plan, so it runs next to the memory-bound kernels of the data stream — the resamplers
+        and the stencil's first pass of this step, or, with the host running ahead, of the step before.  The current stream is
+        ordered behind the draws (an event: no host wait) and the buffer is handed over to it.  ``None`` (nothing drawn, the
+        state untouched) when this road does not apply; the caller then draws with :meth:`randn` / :meth:`add_noise`."""
+        count = 1
+        for extent in shape:
+            count *= int(extent)
+        device = torch.device(device)
+        side = draw_stream(device)
+        ahead = self._prefetched
+        if (
+            side is None or count < self.DEVICE_DRAW_MIN or os.environ.get("TIO_DEVICE_RNG", "1") == "0"
+            or (ahead is not None and (count != ahead[0] or device != ahead[1]))
+        ):
+            return None
+        out = on_draw_stream(device, lambda: self._randn_on_device(count, device))
+        return None if out is None else out.view(tuple(int(extent) for extent in shape))
 
     def _randn_on_device(self, count: int, device) -> Tensor | None:
         """The draws made on the device (``tio_mt19937_randn_device``) from the host's plan of the state chain."""
@@ -916,7 +1021,9 @@ class Engine:
         """``Noise(Blur(BiasField(data)))`` in the passes of the separable stencil (``tio_blur_fused``).
 
         ``bias_coarse``: ``(B, C, si, sj, sk)`` float32 or ``None``; ``noise``: ``(mean, std,
-        philox_seed)`` with scalar or ``(B,)`` tensors, or ``None``.  Returns ``None`` when this
+        philox_seed)`` with scalar or ``(B,)`` tensors, or ``(mean, std, draws)`` with *draws* a float32
+        device tensor of the data's shape holding one normal draw per element (the reference's seeded
+        stream, ``HostNormalStream.randn_ahead``), or ``None``.  Returns ``None`` when this
         engine / these arguments have no fused form (nothing was launched): the caller then runs
         the three ops one after the other, which gives the same values.
         """
@@ -932,10 +1039,14 @@ class Engine:
             if bias_coarse.ndim != 5 or bias_coarse.shape[:2] != data.shape[:2]:
                 raise ValueError("bias_coarse must be (B, C, si, sj, sk)")
             coarse_shape = _i32x3(bias_coarse.shape[2:])
-        noise_on, mean_f, std_f, mean_t, std_t, batched, seed = 0, 0.0, 0.0, None, None, 0, 0
+        noise_on, mean_f, std_f, mean_t, std_t, batched, seed, base = 0, 0.0, 0.0, None, None, 0, 0, None
         if noise is not None:
             mean, std, seed = noise
             noise_on = 1
+            if isinstance(seed, Tensor):  # explicit draws
+                base, seed, noise_on = seed, 0, 2
+                if base.dtype != torch.float32 or base.device != data.device or base.numel() != data.numel() or not base.is_contiguous():
+                    raise ValueError("blur_fused: the draws must be a dense float32 tensor of the data's size on its device")
             batched = int(isinstance(mean, Tensor) or isinstance(std, Tensor))
             if batched:
                 mean_t = torch.as_tensor(mean, dtype=torch.float32, device=data.device).expand(batch).contiguous()
@@ -947,8 +1058,8 @@ class Engine:
         arguments = (
             _ptr(data), _ptr(out), _ptr(tmp), dtype_code(data.dtype), batch, channels, _i32x3(data.shape[2:]), _ptr(taps),
             int(taps.shape[0] == batch and batch > 1), taps.shape[2], _i32x3(radius), _ptr(bias_coarse), coarse_shape,
-            noise_on, mean_f, std_f, _ptr(mean_t), _ptr(std_t), batched, int(seed) & (2**64 - 1), int(_STENCIL_PRECISION == "fast"),
-            self._stream(data),
+            noise_on, mean_f, std_f, _ptr(mean_t), _ptr(std_t), batched, int(seed) & (2**64 - 1), _ptr(base),
+            int(_STENCIL_PRECISION == "fast"), self._stream(data),
         )
         if self.device_type == "cuda" and data.device.index != torch.cuda.current_device():
             with torch.cuda.device(data.device):

@@ -59,9 +59,12 @@ class Compose(Transform):
             # known while the earlier ones are still being enqueued (Noise's seed: the plan of its generator stream, 0.6 - 0.9 ms
             # of host time in the reference-identical noise mode, is computed on a helper thread meanwhile).
             drawn = [transform._draw(batch) for transform in self.transforms]
-            for transform, params in zip(self.transforms, drawn, strict=True):
-                if params is not None:
-                    transform._prefetch(batch, params)
+            # (children whose preparation runs on a native THREAD go first — Noise: the plan of its generator's stream takes
+            # 0.6 - 0.8 ms of wall time, and every other child's preparation, ~0.25 ms of host work, then runs beside it)
+            for early in (True, False):
+                for transform, params in zip(self.transforms, drawn, strict=True):
+                    if params is not None and bool(getattr(transform, "prefetch_is_threaded", False)) == early:
+                        transform._prefetch(batch, params)
             applying = [(transform, params) for transform, params in zip(self.transforms, drawn, strict=True) if params is not None]
             try:
                 for index, (transform, params) in enumerate(applying):
