@@ -219,7 +219,9 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
     tio.set_stencil_precision(precision)
     try:
         torch.manual_seed(seed)
-        for _ in range(2):
+        # (warm: a mode's first steps grow the caching allocator's pools — the reference-noise modes draw on a stream of their
+        # own, whose pool starts empty: their first steps are device allocations of 512 MiB each)
+        for _ in range(12):
             transform(batch)
         torch.cuda.synchronize()
         if timer is not None:
@@ -243,6 +245,28 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
         result["resample_launch_ms"] = launch_ms
         result["resample_frac_of_hbm_peak"] = launch_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     return result
+
+
+def multi_stream(transform, batch, steps: int, n_streams: int) -> dict:
+    """The headline step issued from this ONE host thread on *n_streams* alternating HIP streams (step n on stream n mod S):
+    consecutive steps are independent, so their kernels may overlap on the device — no single kernel saturates a unit of the
+    chip.  Reported next to `value`, never as `value`: under overlap a kernel's duration is no longer its own, and the
+    roofline of the line is measured on the single stream."""
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    outs = [None] * n_streams
+    for step in range(6 * n_streams):  # warm the allocator's per-stream pools
+        with torch.cuda.stream(streams[step % n_streams]):
+            outs[step % n_streams] = transform(batch)
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for step in range(steps):
+        with torch.cuda.stream(streams[step % n_streams]):
+            outs[step % n_streams] = transform(batch)
+    host = time.perf_counter() - start
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - start
+    del outs
+    return {"volumes_per_s": steps * batch.batch_size / elapsed, "ms_per_step": 1e3 * elapsed / steps, "host_enqueue_ms_per_step": 1e3 * host / steps, "steps": steps}
 
 
 def other_configs(batch, size: int, device, timer) -> dict:
@@ -479,7 +503,7 @@ def main() -> None:
             #   resample_precision "exact" = bit-identical coordinates / interpolation (default); "fast" = within 1e-4.
             out = None
             modes = {}
-            for rng_mode, prec, steps in (("philox", "exact", 10), ("philox", "fast", 10), ("reference", "exact", 10), ("reference", "fast", 10)):
+            for rng_mode, prec, steps in (("philox", "exact", 20), ("philox", "fast", 20), ("reference", "exact", 30), ("reference", "fast", 30)):
                 modes[f"noise={rng_mode},resample={prec}"] = time_mode(
                     transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77, timer=timer, launch_bytes=launch_bytes
                 )
@@ -490,8 +514,18 @@ def main() -> None:
             line["noise_modes"] = {
                 "philox": modes["noise=philox,resample=exact"]["volumes_per_s"],
                 "reference": modes["noise=reference,resample=exact"]["volumes_per_s"],
-                "note": "reference = bit-identical noise stream (mt19937 state chain on the host, draws on the device); philox = in-kernel draws, a different stream",
+                "note": "reference = bit-identical noise stream (mt19937 state chain on the host, draws made ahead on a low-priority draw stream of the device, summed on the stencil's stores); philox = in-kernel draws, a different stream",
             }
+        if args.gpus == 1 and not args.no_mode_matrix:
+            out = None
+            torch.manual_seed(78)
+            line["multi_stream"] = {
+                f"{n}_streams": multi_stream(transform, batch, 40, n) for n in (2, 3)
+            }
+            line["multi_stream"]["note"] = (
+                "the headline mode, consecutive steps on alternating HIP streams from ONE host thread (their kernels overlap on the "
+                "device); informational: `value` and `roofline` are the single-stream numbers"
+            )
         if args.gpus == 1 and not args.no_other_configs:
             out = None
             line["other_configs"] = other_configs(batch, args.size, device, timer)

@@ -7,4 +7,4 @@ if [ "$1" != "quick" ]; then
   timeout 300 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
   (cd tests/native/_build && timeout 200 ./resample_bench --cases parity 2>&1 | tail -1)
 fi
-timeout 200 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; tail -c 300 gpurun_out/final_bench.json; echo
+timeout 420 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; tail -c 300 gpurun_out/final_bench.json; echo

@@ -458,8 +458,10 @@ constexpr int kMarchMaxRadius = 8;
 #endif
 constexpr int kMarchAhead = TIO_MARCH_AHEAD;
 
+// (the fused J + K instantiations of the usual radii are held to 128 registers — four waves per SIMD: with explicit draws the
+// R = 6 one needed 130, one wave per SIMD less)
 template <int R, bool FUSE_K, bool PRE_BIAS, int POST_NOISE>
-__global__ __launch_bounds__(kBlock) void conv_march_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(kBlock, (FUSE_K && !PRE_BIAS && R <= 6) ? 4 : 1) void conv_march_kernel(const ConvArgs a) {
   constexpr int W = 2 * R + 1;
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(4))) const float* const_float_ptr;
