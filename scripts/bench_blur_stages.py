@@ -1,6 +1,6 @@
 """Stage timing of the Blur path (I pass, fused J+K pass, with / without BiasField and Noise) on 8 x 256^3 f32.
 
-    python scripts/bench_blur_stages.py [radius]      # on the GPU box; TIO_CONV_RING=1 selects the LDS-ring kernels
+    python scripts/bench_blur_stages.py [radius] [exact|fast]     # on the GPU box; TIO_CONV_RING=1 selects the LDS-ring kernels
 """
 from __future__ import annotations
 
@@ -30,6 +30,8 @@ def timed(fn, reps=10):
 
 def main():
     radius = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    precision = sys.argv[2] if len(sys.argv) > 2 else "exact"
+    ops.set_stencil_precision(precision)
     engine = ops.engine()
     data = torch.rand(8, 1, 256, 256, 256, device="cuda")
     sigma = radius / 3.0
@@ -47,7 +49,9 @@ def main():
         "bias + blur + noise": lambda: engine.blur_fused(data, taps, radii, bias_coarse=coarse, noise=(mean, std, 1234)),
         "separable_conv3d (same kernels, no pointwise)": lambda: engine.separable_conv3d(data, taps, radii),
     }
-    print(f"radius {list(radii)}  ring={'1' if os.environ.get('TIO_CONV_RING') else '0'}")
+    draws = torch.randn(data.shape, device="cuda")
+    rows["bias + blur + explicit draws (the reference's stream)"] = lambda: engine.blur_fused(data, taps, radii, bias_coarse=coarse, noise=(mean, std, draws))
+    print(f"radius {list(radii)}  ring={'1' if os.environ.get('TIO_CONV_RING') else '0'}  stencil precision {precision}")
     for name, fn in rows.items():
         print(f"{name:48s} {timed(fn):8.1f} us")
 

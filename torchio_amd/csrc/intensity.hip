@@ -262,6 +262,16 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
   const_float_ptr tc = (const_float_ptr)(t);
   const_float_ptr tk = (const_float_ptr)(a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + 2 * a.tap_stride);
   (void)s_taps; (void)tk; (void)s_krow;
+  float tkw[17];  // the K taps of the fused stage, once, at their window positions (see conv_march_kernel)
+  (void)tkw;
+  if constexpr (FUSE_K) {
+    const int rk0 = a.radius_k;
+#pragma unroll
+    for (int jj = 0; jj < 17; jj++) {
+      const int tt = jj - (8 - rk0);
+      tkw[jj] = (tt >= 0 && tt <= 2 * rk0) ? tk[tt] : 0.0f;
+    }
+  }
   float noise_mu = a.noise_mean, noise_sd = a.noise_std;  // scalar loads, once (see conv_march_kernel)
   if constexpr (POST_NOISE != 0) {
     if (a.noise_batched) {
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void conv_line_v4_kernel(const ConvArgs a) 
 #pragma unroll
             for (int jj = 0; jj < 17; jj++) {
               if (jj >= 8 - rk && jj <= 8 + rk) {
-                const float tw = tk[jj - (8 - rk)];
+                const float tw = tkw[jj];
                 out.x = __fadd_rn(out.x, __fmul_rn(tw, w[jj]));
                 out.y = __fadd_rn(out.y, __fmul_rn(tw, w[jj + 1]));
                 out.z = __fadd_rn(out.z, __fmul_rn(tw, w[jj + 2]));
@@ -460,7 +470,9 @@ constexpr int kMarchAhead = TIO_MARCH_AHEAD;
 
 // (the fused J + K instantiations of the usual radii are held to 128 registers — four waves per SIMD: with explicit draws the
 // R = 6 one needed 130, one wave per SIMD less)
-template <int R, bool FUSE_K, bool PRE_BIAS, int POST_NOISE>
+// FMA (tio_blur_fused(fast_math = 1)) is a template parameter: as a block-uniform branch both forms of every tap sat in the
+// W-times unrolled loop — 12 600 lines of assembly, more than the instruction cache holds.
+template <int R, bool FUSE_K, bool PRE_BIAS, int POST_NOISE, bool FMA>
 __global__ __launch_bounds__(kBlock, (FUSE_K && !PRE_BIAS && R <= 6) ? 4 : 1) void conv_march_kernel(const ConvArgs a) {
   constexpr int W = 2 * R + 1;
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -508,6 +520,19 @@ __global__ __launch_bounds__(kBlock, (FUSE_K && !PRE_BIAS && R <= 6) ? 4 : 1) vo
   float tw[W];  // scalar registers
 #pragma unroll
   for (int t = 0; t < W; t++) tw[t] = tc[t];
+  // The K taps as well, ONCE, at the positions the register window uses them (tap t of radius rk sits at jj = 8 - rk + t;
+  // zeros beyond the radius).  Until round 4 every tap was a scalar load INSIDE the marching loop — its address depends on the
+  // run-time radius — followed by s_waitcnt lgkmcnt(0): thirteen serialised round trips through the scalar cache per row.
+  float tkw[17];
+  (void)tkw;
+  if constexpr (FUSE_K) {
+    const int rk0 = a.radius_k;
+#pragma unroll
+    for (int jj = 0; jj < 17; jj++) {
+      const int t = jj - (8 - rk0);
+      tkw[jj] = (t >= 0 && t <= 2 * rk0) ? tk[t] : 0.0f;
+    }
+  }
   // noise parameters of this strip's element, once, through the scalar cache: as plain global loads inside
   // the marching loop they sit behind a branch, and the compiler's wait at the join is vmcnt(0) - it
   // drained the two prefetched rows (and the previous store) on every row
@@ -596,7 +621,7 @@ __global__ __launch_bounds__(kBlock, (FUSE_K && !PRE_BIAS && R <= 6) ? 4 : 1) vo
       (void)zrow;
       nxt[kMarchAhead - 1] = TIO_ROW_LOAD(p + R + kMarchAhead);
       float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (a.fma) {  // (block uniform)
+      if constexpr (FMA) {
 #pragma unroll
         for (int t = 0; t < W; t++) {
           const v4f v = win[(u + t) % W];
@@ -635,28 +660,50 @@ __global__ __launch_bounds__(kBlock, (FUSE_K && !PRE_BIAS && R <= 6) ? 4 : 1) vo
           w[4 * d] = c.x; w[4 * d + 1] = c.y; w[4 * d + 2] = c.z; w[4 * d + 3] = c.w;
         }
         float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (a.fma) {
-#pragma unroll
-          for (int jj = 0; jj < 17; jj++) {
-            if (jj >= 8 - rk && jj <= 8 + rk) {
-              const float tv = tk[jj - (8 - rk)];
-              out.x = __builtin_fmaf(tv, w[jj], out.x);
-              out.y = __builtin_fmaf(tv, w[jj + 1], out.y);
-              out.z = __builtin_fmaf(tv, w[jj + 2], out.z);
-              out.w = __builtin_fmaf(tv, w[jj + 3], out.w);
-            }
-          }
+        if constexpr (FMA) {
+          // fast taps: three branch-free tiers (radius <= 4 / <= 6 / <= 8) over the preloaded, zero-padded taps — a tap
+          // beyond the radius is fma(0, w, out) = out for every finite w (the fast mode's contract is float rounding on finite
+          // data; the exact mode below keeps the skipped taps skipped)
+#define TIO_K_TIER(T)                                              \
+  _Pragma("unroll") for (int jj = 8 - (T); jj <= 8 + (T); jj++) { \
+    const float tv = tkw[jj];                                      \
+    out.x = __builtin_fmaf(tv, w[jj], out.x);                      \
+    out.y = __builtin_fmaf(tv, w[jj + 1], out.y);                  \
+    out.z = __builtin_fmaf(tv, w[jj + 2], out.z);                  \
+    out.w = __builtin_fmaf(tv, w[jj + 3], out.w);                  \
+  }
+          if (rk <= 4) { TIO_K_TIER(4) } else if (rk <= 6) { TIO_K_TIER(6) } else { TIO_K_TIER(8) }
+#undef TIO_K_TIER
         } else {
+          // exact taps: the taps taken and their order are the oracle's (a skipped tap stays skipped: 0 * w is not nothing for
+          // a non-finite w).  Tiers of two radii — the inner taps of a tier unconditional, only its outermost pair (radii
+          // 6 / 8) or the taps beyond |d| = 1 (radii <= 4) behind a scalar branch: 2 - 6 branches per row instead of 17.
+#define TIO_K_TAP(JJ)                                       \
+  {                                                         \
+    const float tv = tkw[JJ];                               \
+    out.x = __fadd_rn(out.x, __fmul_rn(tv, w[(JJ)]));       \
+    out.y = __fadd_rn(out.y, __fmul_rn(tv, w[(JJ) + 1]));   \
+    out.z = __fadd_rn(out.z, __fmul_rn(tv, w[(JJ) + 2]));   \
+    out.w = __fadd_rn(out.w, __fmul_rn(tv, w[(JJ) + 3]));   \
+  }
+          if (rk <= 4) {
 #pragma unroll
-          for (int jj = 0; jj < 17; jj++) {
-            if (jj >= 8 - rk && jj <= 8 + rk) {
-              const float tv = tk[jj - (8 - rk)];
-              out.x = __fadd_rn(out.x, __fmul_rn(tv, w[jj]));
-              out.y = __fadd_rn(out.y, __fmul_rn(tv, w[jj + 1]));
-              out.z = __fadd_rn(out.z, __fmul_rn(tv, w[jj + 2]));
-              out.w = __fadd_rn(out.w, __fmul_rn(tv, w[jj + 3]));
+            for (int jj = 4; jj <= 12; jj++) {
+              if (jj >= 7 && jj <= 9) TIO_K_TAP(jj)
+              else if (jj >= 8 - rk && jj <= 8 + rk) TIO_K_TAP(jj)
             }
+          } else if (rk <= 6) {
+            if (rk == 6) TIO_K_TAP(2)
+#pragma unroll
+            for (int jj = 3; jj <= 13; jj++) TIO_K_TAP(jj)
+            if (rk == 6) TIO_K_TAP(14)
+          } else {
+            if (rk == 8) TIO_K_TAP(0)
+#pragma unroll
+            for (int jj = 1; jj <= 15; jj++) TIO_K_TAP(jj)
+            if (rk == 8) TIO_K_TAP(16)
           }
+#undef TIO_K_TAP
         }
         acc = out;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -725,6 +772,13 @@ __global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
   typedef __attribute__((address_space(4))) const float* const_float_ptr;  // taps are read-only for the whole launch
   const_float_ptr tc = (const_float_ptr)(t);  // scalar loads; every wave works on its own LDS rows, no block barrier
   (void)s_taps;
+  // the taps of the register-window path, once, at the window positions that use them (see conv_march_kernel)
+  float tkw[17];
+#pragma unroll
+  for (int jj = 0; jj < 17; jj++) {
+    const int tt = jj - (8 - r);
+    tkw[jj] = (r <= 8 && tt >= 0 && tt <= 2 * r) ? tc[tt] : 0.0f;
+  }
   const int span = min(kConvKSpan, a.K - k0);
   const float* in = s_row + r4 - r;
   // halo: lane q < 2r owns one replicate-clamped position outside the span (r on each side);
@@ -780,7 +834,7 @@ __global__ __launch_bounds__(kBlock) void conv_k_v4_kernel(const ConvArgs a) {
 #pragma unroll
           for (int jj = 0; jj < 17; jj++) {
             if (jj >= 8 - r && jj <= 8 + r) {
-              const float tw = tc[jj - (8 - r)];
+              const float tw = tkw[jj];
               acc.x = __fadd_rn(acc.x, __fmul_rn(tw, w[jj]));
               acc.y = __fadd_rn(acc.y, __fmul_rn(tw, w[jj + 1]));
               acc.z = __fadd_rn(acc.z, __fmul_rn(tw, w[jj + 2]));
@@ -921,11 +975,15 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
           if (a.tiles_a) std::swap(grid.x, grid.z);
 #define TIO_MARCH_VARIANT(RR)                                                                              \
   {                                                                                                        \
-    if (fused && noise_base) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 2>), grid, dim3(kBlock), lds, stream, a);     \
-    else if (fused && post_noise) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 1>), grid, dim3(kBlock), lds, stream, a); \
-    else if (fused) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 0>), grid, dim3(kBlock), lds, stream, a);              \
-    else if (pre_bias) hipLaunchKernelGGL((conv_march_kernel<RR, false, true, 0>), grid, dim3(kBlock), lds, stream, a);           \
-    else hipLaunchKernelGGL((conv_march_kernel<RR, false, false, 0>), grid, dim3(kBlock), lds, stream, a);                        \
+    if (fuse.fma) { TIO_MARCH_VARIANT_F(RR, true) } else { TIO_MARCH_VARIANT_F(RR, false) }                                      \
+  }
+#define TIO_MARCH_VARIANT_F(RR, FM)                                                                                                  \
+  {                                                                                                                                  \
+    if (fused && noise_base) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 2, FM>), grid, dim3(kBlock), lds, stream, a);     \
+    else if (fused && post_noise) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 1, FM>), grid, dim3(kBlock), lds, stream, a); \
+    else if (fused) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 0, FM>), grid, dim3(kBlock), lds, stream, a);              \
+    else if (pre_bias) hipLaunchKernelGGL((conv_march_kernel<RR, false, true, 0, FM>), grid, dim3(kBlock), lds, stream, a);           \
+    else hipLaunchKernelGGL((conv_march_kernel<RR, false, false, 0, FM>), grid, dim3(kBlock), lds, stream, a);                        \
   }
           switch (radius[axis]) {
             case 1: TIO_MARCH_VARIANT(1) break;
@@ -938,6 +996,7 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
             default: TIO_MARCH_VARIANT(8) break;
           }
 #undef TIO_MARCH_VARIANT
+#undef TIO_MARCH_VARIANT_F
           src = dst;
           continue;
         }
