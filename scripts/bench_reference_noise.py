@@ -41,6 +41,7 @@ def main():
     parser.add_argument("--steps", type=int, default=40)
     parser.add_argument("--rounds", type=int, default=2)
     parser.add_argument("--modes", default="reference,fast;reference,exact;philox,fast")
+    parser.add_argument("--toggle", default="TIO_NO_DRAW_STREAM", help="the Python-level switch that is alternated (unset / 1) inside the process")
     args = parser.parse_args()
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
@@ -58,17 +59,17 @@ def main():
             tio.set_stencil_precision(precision)
             # (one road per PROCESS for the stream's priority and the draw kernel's grid — TIO_DRAW_STREAM_PRIORITY, TIO_DRAW_BLOCKS_PER_CU:
             # a new stream has its own pool in the caching allocator, its first steps are device allocations)
-            for road, flag in (("draw stream", ""), ("one kernel behind the stencil", "1")):
-                if rng_mode != "reference" and flag == "1":
+            for road, flag in ((f"{args.toggle} unset", ""), (f"{args.toggle}=1", "1")):
+                if rng_mode != "reference" and flag == "1" and args.toggle == "TIO_NO_DRAW_STREAM":
                     continue
                 if flag == "1":
-                    os.environ["TIO_NO_DRAW_STREAM"] = flag
+                    os.environ[args.toggle] = flag
                 else:
-                    os.environ.pop("TIO_NO_DRAW_STREAM", None)
+                    os.environ.pop(args.toggle, None)
                 torch.manual_seed(7)
                 ms, host = timed(transform, batch, args.steps)
                 print(f"round {rep} noise={rng_mode},resample={precision} [{road}]: {8e3 / ms:8.1f} volumes/s  {ms:.3f} ms/step  host {host:.3f} ms/step", flush=True)
-    os.environ.pop("TIO_NO_DRAW_STREAM", None)
+    os.environ.pop(args.toggle, None)
 
 
 if __name__ == "__main__":
