@@ -951,7 +951,10 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         // whose bricks may be 8 planes thick (half the tile: twice the blocks per CU)
         const bool lean = env.planned_lean != 0;
         const int64_t items64 = blocks;
-        int cap_p = kLdsFloatsPerCU / kTileBlocksPerCU - 512;
+        // the largest tile three blocks of which fit a CU: LDS is handed out in granules of 1 280 bytes here (measured: 13 440
+        // floats keep three blocks resident, 13 568 drop to two — profiles/r04_tile_cap.log); 300 floats more than the round-3
+        // value, which is 1.5 % of a fused affine + elastic launch (fewer bricks on the per-voxel road)
+        int cap_p = (kLdsFloatsPerCU / kTileBlocksPerCU) / 320 * 320;
         if (env.tile_lds_floats > 0) cap_p = env.tile_lds_floats;
         if (cap_p < kTileMinCap) cap_p = kTileMinCap;
         if (cap_p > kLdsFloatsPerCU) cap_p = kLdsFloatsPerCU;
