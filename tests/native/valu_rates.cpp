@@ -71,6 +71,14 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, float seed, int i
       if constexpr (OP == 44) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pb));
       if constexpr (OP == 45) asm volatile("ds_read_b128 %0, %1" : "=v"(v4[i]) : "v"((n[i] & 255) * 16));
       if constexpr (OP == 46) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+      // selects: the VCC form, the SGPR-pair form, a compare + select pair, and the mask forms that avoid v_cndmask
+      if constexpr (OP == 47) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20", "s21");
+      if constexpr (OP == 48) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(n[i]) : "v"(iseed), "v"(n[(i + 1) & 7]));
+      if constexpr (OP == 49) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+      if constexpr (OP == 50) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20", "s21");
+      if constexpr (OP == 51) asm volatile("v_sub_u32 %1, %0, %2\n v_ashrrev_i32 %1, 31, %1\n v_and_b32 %0, %0, %1" : "+v"(n[i]), "+v"(n[(i + 1) & 7]) : "v"(iseed));
+      if constexpr (OP == 52) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if constexpr (OP == 53) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(b), "v"(c) : );
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)");
@@ -117,6 +125,8 @@ int main() {
     run<39>("v_mad_u64_u32", d_out, w); run<4>("v_mul_hi_u32", d_out, w); run<2>("v_mul_lo_u32", d_out, w); run<40>("v_xor_b32", d_out, w);
     run<41>("v_log_f32", d_out, w); run<42>("v_sin_f32", d_out, w); run<43>("v_sqrt_f32", d_out, w); run<46>("v_exp_f32", d_out, w);
     run<44>("v_pk_add_f32", d_out, w);
+    run<47>("v_cndmask_b32_e64 sgpr", d_out, w); run<53>("v_cndmask (no dep)", d_out, w); run<48>("v_bfi_b32", d_out, w);
+    run<49>("v_cmp+v_cndmask vcc", d_out, w); run<50>("v_cmp+v_cndmask sgpr", d_out, w); run<51>("sub+ashr+and (mask)", d_out, w);
   }
   return 0;
 }

@@ -973,10 +973,6 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
           a.tiles_a = 0;
           if (env_switches().march_order >= 0) a.tiles_a = env_switches().march_order != 0;  // experiments
           if (a.tiles_a) std::swap(grid.x, grid.z);
-#define TIO_MARCH_VARIANT(RR)                                                                              \
-  {                                                                                                        \
-    if (fuse.fma) { TIO_MARCH_VARIANT_F(RR, true) } else { TIO_MARCH_VARIANT_F(RR, false) }                                      \
-  }
 #define TIO_MARCH_VARIANT_F(RR, FM)                                                                                                  \
   {                                                                                                                                  \
     if (fused && noise_base) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 2, FM>), grid, dim3(kBlock), lds, stream, a);     \
@@ -984,6 +980,10 @@ static int launch_conv(const void* x, void* y, float* tmp0, float* tmp1, int32_t
     else if (fused) hipLaunchKernelGGL((conv_march_kernel<RR, true, false, 0, FM>), grid, dim3(kBlock), lds, stream, a);              \
     else if (pre_bias) hipLaunchKernelGGL((conv_march_kernel<RR, false, true, 0, FM>), grid, dim3(kBlock), lds, stream, a);           \
     else hipLaunchKernelGGL((conv_march_kernel<RR, false, false, 0, FM>), grid, dim3(kBlock), lds, stream, a);                        \
+  }
+#define TIO_MARCH_VARIANT(RR)                                                                              \
+  {                                                                                                        \
+    if (fuse.fma) { TIO_MARCH_VARIANT_F(RR, true) } else { TIO_MARCH_VARIANT_F(RR, false) }                                      \
   }
           switch (radius[axis]) {
             case 1: TIO_MARCH_VARIANT(1) break;

@@ -232,6 +232,8 @@ def on_draw_stream(device, make):
         # stream works it would run ahead without bound — one buffer of draws (as large as the image batch) per step.  Every
         # call marks the data stream ("the consumers of all earlier draws are enqueued before this point") and waits, on the
         # host, for the mark of `_DRAWS_IN_FLIGHT` calls ago.
+        if len(_DRAW_MARKS) > 64:  # (a caller that keeps creating data streams: forget the marks of the old ones)
+            _DRAW_MARKS.clear()
         marks = _DRAW_MARKS.setdefault((side.device.index, main.stream_id), collections.deque())
         mark = torch.cuda.Event()
         mark.record(main)
@@ -461,17 +463,12 @@ class HostNormalStream:
         and the stencil's first pass of this step, or, with the host running ahead, of the step before.  The current stream is
         ordered behind the draws (an event: no host wait) and the buffer is handed over to it.  ``None`` (nothing drawn, the
         state untouched) when this road does not apply; the caller then draws with :meth:`randn` / :meth:`add_noise`."""
+        if not self.can_draw_ahead(shape, device):
+            return None
         count = 1
         for extent in shape:
             count *= int(extent)
         device = torch.device(device)
-        side = draw_stream(device)
-        ahead = self._prefetched
-        if (
-            side is None or count < self.DEVICE_DRAW_MIN or os.environ.get("TIO_DEVICE_RNG", "1") == "0"
-            or (ahead is not None and (count != ahead[0] or device != ahead[1]))
-        ):
-            return None
         out = on_draw_stream(device, lambda: self._randn_on_device(count, device))
         return None if out is None else out.view(tuple(int(extent) for extent in shape))
 
