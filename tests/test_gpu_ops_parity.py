@@ -553,3 +553,37 @@ def test_unique_labels_wide_dtypes_keep_the_aten_path_and_full_size(hip):
     assert hip.unique_labels(data).tolist() == [-7.0, 5.0, 100000.0]
     labels = torch.randint(0, 40, (1, 1, 512, 512, 512), dtype=torch.int16, device=DEV)  # the config-5 label map size
     assert torch.equal(hip.unique_labels(labels), torch.unique(labels).double())
+
+
+@pytest.mark.parametrize("rk", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("rj", [2, 6, 8])
+def test_fused_jk_stage_every_k_radius(oracle, hip, rj, rk):
+    """The K stage of the fused J + K pass applies its taps in tiers of two radii (<= 4 / 6 / 8; round 4): every radius of
+    every tier, next to a small, the usual and the largest J radius — the exact launch bit for bit against the oracle (and the
+    same with a non-finite voxel just beyond the K radius: a skipped tap must stay skipped), the fast launch (zero-padded
+    taps inside a tier, fused multiply-adds) within float rounding of the exact one."""
+    import torchio_amd as tio
+
+    sigmas = (1.2, (rj - 0.5) / 3.0, (rk - 0.5) / 3.0)
+    data = _data((2, 1, 21, 37, 64), torch.float32, 70 + rj * 8 + rk)
+    taps, radius = _taps(1, [sigmas], 32)
+    assert radius == [4, rj, rk]
+    cpu, gpu = _both(oracle, hip, "separable_conv3d", (data, taps, radius))
+    assert torch.equal(cpu, gpu.cpu())
+    # a non-finite voxel: the outputs it reaches are the oracle's, no further (0 * inf would be NaN)
+    poisoned = data.clone()
+    poisoned[0, 0, 10, 18, 30] = float("inf")
+    cpu_p, gpu_p = _both(oracle, hip, "separable_conv3d", (poisoned, taps, radius))
+    assert torch.equal(torch.isfinite(cpu_p), torch.isfinite(gpu_p.cpu()))
+    assert torch.equal(cpu_p[torch.isfinite(cpu_p)], gpu_p.cpu()[torch.isfinite(cpu_p)])
+    previous = tio.get_stencil_precision()
+    try:
+        tio.set_stencil_precision("exact")
+        exact = hip.blur_fused(data.to(DEV), taps.to(DEV), radius)
+        tio.set_stencil_precision("fast")
+        fast = hip.blur_fused(data.to(DEV), taps.to(DEV), radius)
+    finally:
+        tio.set_stencil_precision(previous)
+    assert exact is not None and fast is not None  # (all three axes active, K = 64: the fused form exists)
+    assert torch.equal(exact.cpu(), cpu)
+    assert float((exact - fast).abs().max()) <= 2e-6 * float(exact.abs().max())

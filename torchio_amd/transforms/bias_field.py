@@ -50,7 +50,9 @@ class BiasField(IntensityTransform):
             return {"std": std, "seed": seed, "scale": self.scale}
         keep = self._keep_mask(batch, n)
         std = self._mask_identity(self.std.sample_1d(n), keep, identity=0.0)
-        seeds = [int(torch.randint(0, 2**31, (1,)).item()) for _ in range(n)]
+        # (one call for the n seeds: the CPU generator hands out the same 32-bit draws, and stands where it would stand, as
+        # with the reference's n calls of one — tests/test_host_logic.py holds the two forms against each other)
+        seeds = torch.randint(0, 2**31, (n,)).tolist()
         params = {"std": self._serialize_param(std), "seed": seeds, "scale": self.scale}
         self._tag_batched(params, batch, n, keep, ["std", "seed"])
         return params
@@ -107,12 +109,11 @@ def _defer_bias(img_batch, std, seed, scale: float, per_element: bool) -> bool:
         if any(s == 0 for s in std):
             return False  # identity rows are restored bit-exactly: plain path
         small = _coarse_shape(data.shape[2:], scale)
-        fields = []
-        for std_b, seed_b in zip(std, seed, strict=True):
-            generator = torch.Generator(device="cpu")
+        coarse = torch.empty((len(std), data.shape[1], *small), dtype=torch.float32)
+        generator = torch.Generator(device="cpu")  # (re-seeded per element: the state a fresh generator would have)
+        for index, (std_b, seed_b) in enumerate(zip(std, seed, strict=True)):
             generator.manual_seed(seed_b)
-            fields.append(torch.normal(mean=0.0, std=std_b, size=(1, data.shape[1], *small), generator=generator))
-        coarse = torch.cat(fields, dim=0)
+            torch.normal(mean=0.0, std=std_b, size=(1, data.shape[1], *small), generator=generator, out=coarse[index : index + 1])
     else:
         coarse = _sample_coarse_field(data.shape, std=std, scale=scale, seed=seed)
     img_batch._pending = _pending.Pending(bias_coarse=coarse)  # host tensor: uploaded by the flush, with its neighbours' blocks
