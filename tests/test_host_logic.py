@@ -796,3 +796,56 @@ def test_compose_prepares_threaded_children_first_and_applies_in_order(monkeypat
     assert [name for phase, name in events if phase == "_prefetch"] == ["Noise", "Affine", "BiasField", "Blur"]
     first_apply = next(i for i, (phase, _) in enumerate(events) if phase == "apply_transform")
     assert all(phase != "_prefetch" for phase, _ in events[first_apply:])  # every preparation before the first application
+
+
+def test_pending_flush_takes_explicit_draws_from_a_callable_and_keeps_the_plain_sequence_equivalent(monkeypatch):
+    """`_pending.flush(noise=(mean, std, source))`: *source* may be a Philox seed word, a tensor of explicit draws (the reference's
+    stream made ahead) or a callable returning one — called ONCE, after the parameter uploads; without a fused form the plain
+    sequence hands the draws to `add_noise` as `base1` (a stub engine records the calls: no device involved)."""
+    from torchio_amd import ops
+    from torchio_amd.data import _pending
+
+    calls = []
+
+    class Stub:
+        fused_answer = None
+
+        def blur_fused(self, data, taps, radius, *, bias_coarse=None, noise=None):
+            calls.append(("blur_fused", None if noise is None else type(noise[2]).__name__))
+            return self.fused_answer
+
+        def bias_field_apply(self, data, coarse):
+            calls.append(("bias",))
+            return data + 1
+
+        def separable_conv3d(self, data, taps, radius):
+            calls.append(("conv",))
+            return data * 2
+
+        def add_noise(self, data, mean, std, *, base1=None, philox_seed=0):
+            calls.append(("add_noise", "base1" if base1 is not None else "philox", None if base1 is None else tuple(base1.shape)))
+            return data + (0 if base1 is None else base1)
+
+    stub = Stub()
+    monkeypatch.setattr(ops, "engine", lambda: stub)
+    uploads = []
+    monkeypatch.setattr(ops, "h2d_packed", lambda tensors, device, **kw: (uploads.append(len(calls)), list(tensors))[1])
+    data = torch.zeros(2, 1, 4, 4, 8)
+    draws = torch.arange(data.numel(), dtype=torch.float32)
+    asked = []
+
+    def source():
+        asked.append(len(uploads))  # (the uploads were enqueued before the draws were asked for)
+        return draws
+
+    pending = _pending.Pending(bias_coarse=torch.zeros(2, 1, 4, 4, 4), blur=(torch.ones(1, 3, 3), [1, 1, 1]))
+    out = _pending.flush(data, pending, noise=(0.0, 1.0, source))
+    assert asked == [1]
+    assert calls == [("blur_fused", "Tensor"), ("bias",), ("conv",), ("add_noise", "base1", tuple(data.shape))]
+    assert torch.equal(out, (data + 1) * 2 + draws.view(data.shape))
+    # a Philox seed word keeps the in-kernel draws; a fused answer is returned as it is
+    calls.clear()
+    stub.fused_answer = torch.full_like(data, 7.0)
+    pending = _pending.Pending(blur=(torch.ones(1, 3, 3), [1, 1, 1]))
+    assert torch.equal(_pending.flush(data, pending, noise=(0.0, 1.0, 1234)), stub.fused_answer)
+    assert calls == [("blur_fused", "int")]
