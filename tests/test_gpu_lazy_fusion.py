@@ -266,3 +266,46 @@ def test_reference_noise_rides_on_the_stencil_stores(hip, size, batch, per_insta
     finally:
         tio.set_noise_rng(previous)
         tio.set_stencil_precision(previous_stencil)
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_ring_kernels_give_the_marching_kernels_fused_values(hip, monkeypatch, precision):
+    """`TIO_CONV_RING=1` sends the I and J passes to the LDS-ring kernels (the road of radii the register window does not hold):
+    bias on the loads, the fused K stage with its preloaded taps, Philox noise and explicit draws on the stores — the same values
+    as the marching kernels, bit for bit in the exact mode and in the fast mode's fused multiply-adds alike... the ring kernels
+    have no fast taps, so the fast launch is compared within float rounding."""
+    import numpy as np
+
+    from torchio_amd.transforms.blur import _stacked_gaussian_taps
+
+    data = torch.rand(2, 1, 40, 36, 64, generator=torch.Generator().manual_seed(31)).cuda()
+    taps, radius, _ = _stacked_gaussian_taps(np.array([[1.6, 1.1, 1.9], [1.2, 1.9, 0.8]]), per_element=True)
+    taps = taps.cuda()
+    coarse = (0.3 * torch.randn(2, 1, 4, 4, 4, generator=torch.Generator().manual_seed(32))).cuda()
+    mean = torch.zeros(2, device="cuda")
+    std = torch.full((2,), 0.25, device="cuda")
+    draws = torch.randn(data.shape, generator=torch.Generator().manual_seed(33)).cuda()
+    previous = tio.get_stencil_precision()
+    tio.set_stencil_precision(precision)
+    try:
+        results = {}
+        for ring in ("", "1"):
+            if ring:
+                monkeypatch.setenv("TIO_CONV_RING", ring)
+            else:
+                monkeypatch.delenv("TIO_CONV_RING", raising=False)
+            results[ring] = [
+                hip.blur_fused(data, taps, radius, bias_coarse=coarse),
+                hip.blur_fused(data, taps, radius, bias_coarse=coarse, noise=(mean, std, 4321)),
+                hip.blur_fused(data, taps, radius, bias_coarse=coarse, noise=(mean, std, draws)),
+            ]
+            torch.cuda.synchronize()
+        monkeypatch.delenv("TIO_CONV_RING", raising=False)
+    finally:
+        tio.set_stencil_precision(previous)
+    for marching, ringed in zip(results[""], results["1"], strict=True):
+        assert marching is not None and ringed is not None
+        if precision == "exact":
+            assert torch.equal(marching, ringed)
+        else:
+            assert float((marching - ringed).abs().max()) <= 2e-6 * float(marching.abs().max())
