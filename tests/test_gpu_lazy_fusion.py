@@ -309,3 +309,41 @@ def test_ring_kernels_give_the_marching_kernels_fused_values(hip, monkeypatch, p
             assert torch.equal(marching, ringed)
         else:
             assert float((marching - ringed).abs().max()) <= 2e-6 * float(marching.abs().max())
+
+
+def test_reference_noise_on_the_draw_stream_from_several_threads(hip):
+    """`Queue`'s workers call transforms from a thread pool (queue.py:119-123): the draw stream, its back-pressure marks and the
+    pinned staging rings are shared or per-thread state — three threads, each applying Blur + Noise (recorded parameters: the
+    result is a function of them alone) to its own batches, get the values the same calls give one after the other."""
+    import copy
+    from concurrent.futures import ThreadPoolExecutor
+
+    previous = tio.get_noise_rng()
+    tio.set_noise_rng("reference")
+    try:
+        subjects = make_subjects(72, 3, seed=41, with_label=False)
+        base = tio.SubjectsBatch.from_subjects(subjects).to("cuda")
+        blur, noise = tio.Blur(std=(0.5, 2)), tio.Noise()
+        jobs = []
+        for seed in range(6):
+            torch.manual_seed(100 + seed)
+            jobs.append((blur.make_params(base), noise.make_params(base)))
+
+        def run(job):
+            batch = copy.deepcopy(base)
+            batch = blur.apply_transform(batch, job[0])
+            assert batch.t1._pending is not None  # (the Blur is queued: the Noise call below rides on its stores)
+            batch = noise.apply_transform(batch, job[1])
+            out = batch.t1.data
+            torch.cuda.current_stream().synchronize()
+            return out
+
+        expected = [run(job) for job in jobs]
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            for _ in range(2):
+                got = list(pool.map(run, jobs))
+                for want, have in zip(expected, got, strict=True):
+                    assert torch.equal(want, have)
+        assert not torch.equal(expected[0], expected[1])
+    finally:
+        tio.set_noise_rng(previous)
