@@ -32,6 +32,11 @@ from torchio_amd import ops  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def stencil_mode(resample_precision: str) -> str:
+    """The Blur's taps of a resampling mode: the reference's rounding sequence in "exact", fused multiply-adds otherwise."""
+    return "exact" if resample_precision == "exact" else "fast"
+
+
 def build_transform() -> tio.Compose:
     """The metric's pipeline with the explicit ranges of SURVEY.md §8(d) / BASELINE.md §3."""
     return tio.Compose(
@@ -210,13 +215,15 @@ def aten_baseline(size: int, batch: int, device, steps: int = 3) -> dict:
     }
 
 
-def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int, timer=None, launch_bytes: int = 0) -> dict:
+def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int, timer=None, launch_bytes: int = 0, draw_policy: str | None = None) -> dict:
     """A few steps of the same Compose in another (noise rng, resample precision) mode: volumes/s on this GPU, and the
     mean duration of the tio_resample3d launches in that mode (live HIP events, as for the headline's roofline)."""
-    previous = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision())
+    previous = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision(), tio.get_draw_policy())
     tio.set_noise_rng(noise_rng)
+    if draw_policy is not None:
+        tio.set_draw_policy(draw_policy)
     tio.set_resample_precision(precision)
-    tio.set_stencil_precision(precision)
+    tio.set_stencil_precision(stencil_mode(precision))
     try:
         torch.manual_seed(seed)
         # (warm: a mode's first steps grow the caching allocator's pools — the reference-noise modes draw on a stream of their
@@ -238,6 +245,7 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
         tio.set_noise_rng(previous[0])
         tio.set_resample_precision(previous[1])
         tio.set_stencil_precision(previous[2])
+        tio.set_draw_policy(previous[3])
     n = steps * batch.batch_size
     result = {"volumes_per_s": n / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps}
     launch_ms = timer.mean_ms() if timer is not None else None
@@ -298,7 +306,7 @@ def other_configs(batch, size: int, device, timer) -> dict:
         return elapsed, timer.mean_ms()
 
     try:
-        for precision in ("fast", "exact"):
+        for precision in ("tight", "exact", "fast"):
             tio.set_resample_precision(precision)
             seconds, launch_ms = timed(fused, batch, 10)
             nbytes = 2 * volume * batch.batch_size
@@ -322,13 +330,13 @@ def other_configs(batch, size: int, device, timer) -> dict:
             "seg": tio.ImagesBatch(nested_spheres(big).unsqueeze(0).to(device), [tio.AffineMatrix()], image_class=tio.LabelMap),
         })
         nbytes = 2 * (2 * 4 + 2) * big**3
-        for precision in ("fast", "exact"):
+        for precision in ("tight", "exact", "fast"):
             tio.set_resample_precision(precision)
             seconds, launch_ms = timed(fused, subject, 5)
             out[f"config5_subject_{big}^3_2xf32+i16,resample={precision}"] = {
                 "subjects_per_s": 1 / seconds, "ms_per_step": 1e3 * seconds, "resample_launch_ms": launch_ms,
                 "step_frac_of_hbm_peak": nbytes / seconds / 1e9 / HBM_PEAK_GBS,
-                "note": "one tio_resample3d call for the three images: the float images on the kernels of the precision mode, the label map (nearest, bit-exact in both modes) on its own kernel (csrc/resample_nearest.hpp)",
+                "note": "one tio_resample3d call for the three images: the float images on the kernels of the precision mode, the label map (nearest, bit-exact in every mode) on its own kernel (csrc/resample_nearest.hpp)",
             }
     finally:
         tio.set_resample_precision(previous)
@@ -353,10 +361,11 @@ def main() -> None:
     parser.add_argument("--size", type=int, default=256)
     parser.add_argument("--batch", type=int, default=8, help="volumes per GPU per step")
     parser.add_argument("--noise-rng", choices=["reference", "philox"], default="philox")
-    parser.add_argument("--resample-precision", choices=["exact", "fast"], default="fast",
-                        help="fast (default here, like --noise-rng philox: the throughput modes) = float intensities within the north-star "
-                             "1e-4 relative, planned bricks; exact = the library default, the reference's float32 operation sequence bit for "
-                             "bit.  The other mode is timed as well (mode_matrix) unless --no-mode-matrix")
+    parser.add_argument("--resample-precision", choices=["exact", "tight", "fast"], default="tight",
+                        help="tight (default here, like --noise-rng philox: the throughput mode) = the reference's coordinates, taps and fill "
+                             "decisions bit for bit, fused interpolation: inside the north-star bar PER VOXEL; exact = the library default, the "
+                             "reference's float32 operation sequence bit for bit; fast = coordinates as a line (1e-4 of the intensity RANGE "
+                             "only).  The other modes are timed as well (mode_matrix) unless --no-mode-matrix")
     parser.add_argument("--prewarm", type=int, default=100, help="untimed process pre-warm calls before the W warm-up steps")
     parser.add_argument("--settle-seconds", type=float, default=8.0, help="upper bound of the untimed settling phase after the pre-warm")
     parser.add_argument("--no-cpu-baseline", action="store_true")
@@ -376,7 +385,7 @@ def main() -> None:
 
     tio.set_noise_rng(args.noise_rng)
     tio.set_resample_precision(args.resample_precision)
-    tio.set_stencil_precision(args.resample_precision)  # the same switch for the Blur's taps: fused multiply-adds in the throughput mode
+    tio.set_stencil_precision(stencil_mode(args.resample_precision))  # the Blur's taps: fused multiply-adds in the throughput modes
     engine = ops.engine()
     timer = KernelTimer(engine, "resample3d")
     transform = build_transform()
@@ -458,7 +467,7 @@ def main() -> None:
                 "global_batch": args.batch * args.gpus,
                 "noise_rng": args.noise_rng,
                 "resample_precision": args.resample_precision,
-                "stencil_precision": args.resample_precision,
+                "stencil_precision": stencil_mode(args.resample_precision),
                 "parallelism": f"batch-split x{args.gpus} (no data-path collective)",
             },
             "distributed": {
@@ -478,11 +487,11 @@ def main() -> None:
             "host_enqueue_ms_per_step": 1e3 * host_enqueue_s / args.steps,
             "host_settling_ms_per_step": settle_log,  # untimed blocks of 20 steps before the warm-up: the host side of a fresh box
             "roofline": {
-                "kernel": (
-                    "tio::resample_planned_lean_kernel (+ tio::plan_bricks_kernel; tio_resample3d: Affine and ElasticDeformation launches, mean)"
-                    if args.resample_precision == "fast"
-                    else "tio::resample_tile_kernel (tio_resample3d: Affine and ElasticDeformation launches, mean)"
-                ),
+                "kernel": {
+                    "tight": "tio::resample_lean_exact_kernel<.., EXACT_LERP=false> (+ tio::plan_bricks_kernel; tio_resample3d: Affine and ElasticDeformation launches, mean)",
+                    "exact": "tio::resample_lean_exact_kernel<.., EXACT_LERP=true> (+ tio::plan_bricks_kernel; tio_resample3d: Affine and ElasticDeformation launches, mean)",
+                    "fast": "tio::resample_planned_lean_kernel (+ tio::plan_bricks_kernel; tio_resample3d: Affine and ElasticDeformation launches, mean)",
+                }[args.resample_precision],
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -500,16 +509,34 @@ def main() -> None:
             #   noise_rng "reference" = the reference's own stream, bit for bit (torch's CPU mt19937 + Box-Muller: the host
             #   runs the state chain, the device replays it and draws: csrc/mt19937.hip; the library's default);
             #   "philox" = in-kernel Philox draws, NOT reference-identical;
-            #   resample_precision "exact" = bit-identical coordinates / interpolation (default); "fast" = within 1e-4.
+            #   resample_precision "exact" = bit-identical coordinates AND interpolation (default); "tight" = bit-identical
+            #   coordinates / taps / fill decisions, fused interpolation (per-voxel 1e-4); "fast" = coordinate lines (1e-4 of range).
             out = None
             modes = {}
-            for rng_mode, prec, steps in (("philox", "exact", 20), ("philox", "fast", 20), ("reference", "exact", 30), ("reference", "fast", 30)):
+            for rng_mode, prec, steps in (("philox", "tight", 20), ("philox", "exact", 20), ("philox", "fast", 20)):
+                modes[f"noise={rng_mode},resample={prec}"] = time_mode(
+                    transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77, timer=timer, launch_bytes=launch_bytes
+                )
+            # The reference's own noise stream: its draws are made AHEAD on a stream of their own.  WHERE that kernel runs is a
+            # box-dependent trade: every policy is timed, and `ops.calibrate_draw_policy` — the library's
+            # run-time choice — picks one for the legs that carry the `value_reference_identical` of this line.
+            for policy in ("gated", "free", "off"):
+                modes[f"noise=reference,resample=exact,draws={policy}"] = time_mode(
+                    transform, batch, 30, noise_rng="reference", precision="exact", seed=77, timer=timer, launch_bytes=launch_bytes, draw_policy=policy
+                )
+            previous_mode = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision())
+            tio.set_noise_rng("reference"); tio.set_resample_precision("exact"); tio.set_stencil_precision("exact")
+            calibration = ops.calibrate_draw_policy(lambda: transform(batch))
+            tio.set_noise_rng(previous_mode[0]); tio.set_resample_precision(previous_mode[1]); tio.set_stencil_precision(previous_mode[2])
+            line["draw_policy"] = {"chosen": tio.get_draw_policy(), "calibration_ms_per_step": calibration,
+                                   "note": "ops.calibrate_draw_policy on the library-default mode: 12 steps per policy, the fastest is kept"}
+            for rng_mode, prec, steps in (("reference", "exact", 30), ("reference", "tight", 30)):
                 modes[f"noise={rng_mode},resample={prec}"] = time_mode(
                     transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77, timer=timer, launch_bytes=launch_bytes
                 )
             line["mode_matrix"] = modes
             # the number that sits beside the reference itself: the LIBRARY DEFAULT — the reference's own noise stream bit for
-            # bit + the bit-exact resamplers (the headline `value` is the throughput mode named in `config`: within 1e-4)
+            # bit + the bit-exact resamplers (the headline `value` is the throughput mode named in `config`)
             line["value_reference_identical"] = modes["noise=reference,resample=exact"]["volumes_per_s"]
             line["noise_modes"] = {
                 "philox": modes["noise=philox,resample=exact"]["volumes_per_s"],

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 12
+#define TIO_ABI_VERSION 13
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -61,7 +61,8 @@ typedef enum tio_dtype {
 
 typedef enum tio_precision {
   TIO_PRECISION_EXACT = 0,
-  TIO_PRECISION_FAST = 1
+  TIO_PRECISION_FAST = 1,
+  TIO_PRECISION_TIGHT = 2 /* ABI 13: the reference's coordinates, taps and fill decisions bit for bit; fused interpolation */
 } tio_precision;
 
 typedef enum tio_interp {
@@ -167,7 +168,14 @@ typedef struct tio_resample_geom {
    * and do not hold the float images back (their own kernel: the index of a voxel only
    * depends on its coordinate's rounding, and coordinates within rounding error of a
    * half-integer are re-evaluated with the exact chain); any other image in the call — a
-   * nearest image with a fill rule, TIO_LABEL_PV, another dtype — keeps the whole call exact. */
+   * nearest image with a fill rule, TIO_LABEL_PV, another dtype — keeps the whole call exact.
+   * TIO_PRECISION_TIGHT (ABI 13): every sampling coordinate is the reference's float32 value bit for bit (MKL's FMA
+   * order, ATen's lerp nesting, the normalise / un-normalise round trip), hence the same eight taps, the same weights
+   * and the same `mask > 0.5` decisions; only the interpolation of the float32 trilinear images is fused (three nested
+   * fma lerps instead of ATen's eight weighted taps): the result differs from the reference by the rounding of seven
+   * fused multiply-adds (~1e-7 of the taps) and meets |d| <= 1e-4 max(|ref|, 1e-3 range) PER VOXEL on white noise, which
+   * TIO_PRECISION_FAST cannot (one ulp of a coordinate is already more).  Launches the lean exact-coordinate kernel does
+   * not take (small launches, other dtypes, non-unit spacing with control points) run the exact kernels. */
   int32_t precision;
   /* Optional (NULL / 0 = the call plans for itself): a brick plan made AHEAD of the call by tio_resample3d_plan from a
    * geometry with exactly these fields (ABI 11).  Large launches of 16^3 bricks start from a plan — one descriptor per

@@ -167,16 +167,23 @@ static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
   }
 }
 
-struct Paths { const char* name; const char* path; const char* variant; int fast; const char* kernel; const char* v2; };
+struct Paths { const char* name; const char* path; const char* variant; int precision; const char* kernel; const char* v2; };
 static const Paths kPaths[] = {
     {"gather", "gather", "0", 0, nullptr, nullptr}, {"tile16x16x16", "tile", "0", 0, nullptr, nullptr}, {"tile16x8x32", "tile", "1", 0, nullptr, nullptr},
     {"tile8x8x32", "tile", "2", 0, nullptr, nullptr}, {"tile8x16x32w8", "tile", "3", 0, nullptr, nullptr}, {"tile8x16x16", "tile", "4", 0, nullptr, nullptr},
-    // TIO_PRECISION_FAST (float32 trilinear launches only; compared within 1e-4 relative, not bit for bit): the planned
-    // bricks of resample_fast.hpp (the product path of large launches; forced here whatever the size) and the brick
-    // kernel's FAST instantiation (small launches, A/B)
+    // TIO_PRECISION_FAST (float32 trilinear launches only; held to 1e-4 OF THE INTENSITY RANGE, its contract — it cannot meet the
+    // per-voxel bar on white noise: resample_lean_exact.hpp): the planned bricks of resample_fast.hpp (forced here whatever the
+    // size) and the brick kernel's FAST instantiation (small launches, A/B)
     {"fast", "tile", "0", 1, "planned", "0"}, {"fast-brick", "tile", "0", 1, "brick", "0"},
     // round 3 A/B: the general planned kernel for a single-channel image too (TIO_PLANNED_LEAN=0)
-    {"fast-general", "tile", "0", 1, "planned", "nolean"}};
+    {"fast-general", "tile", "0", 1, "planned", "nolean"},
+    // round 5 (resample_lean_exact.hpp): the lean planned kernel with the reference's own coordinates, forced whatever the size.
+    // "lean-exact" = TIO_PRECISION_EXACT, ATen's interpolation order: compared BIT FOR BIT; "tight" = TIO_PRECISION_TIGHT, fused
+    // lerps: held per voxel to |d| <= 1e-4 max(|ref|, 1e-3 range), no exempt voxel.  "-seq": the box requested before phase A
+    // (TIO_LEAN_INTERLEAVE=0, A/B of the interleaved DMA issue)
+    {"lean-exact", "tile", "0", 0, "planned", "lean-exact"}, {"tight", "tile", "0", 2, "planned", "0"},
+    {"lean-exact-seq", "tile", "0", 0, "planned", "lean-exact-seq"}, {"tight-seq", "tile", "0", 2, "planned", "seq"},
+    {"tight-dma1st", "tile", "0", 2, "planned", "dmafirst"}};
 
 // --ablate 64: the lean kernel overwrites the first output row of every brick with its block's shader-clock stamps
 // (resample_fast.hpp); medians of the phases, and how many blocks of a CU were alive together
@@ -334,15 +341,18 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     if (kPaths[p].kernel) setenv("TIO_FAST_KERNEL", kPaths[p].kernel, 1); else unsetenv("TIO_FAST_KERNEL");
     const std::string mix = kPaths[p].v2 ? kPaths[p].v2 : "";
     setenv("TIO_PLANNED_LEAN", mix == "nolean" ? "0" : "1", 1);
+    setenv("TIO_EXACT_LEAN", mix.rfind("lean-exact", 0) == 0 ? "2" : "0", 1);  // the older exact paths stay on the brick kernel
+    setenv("TIO_LEAN_INTERLEAVE", (mix == "seq" || mix == "lean-exact-seq") ? "0" : (mix == "dmafirst" ? "2" : "1"), 1);
     setenv("TIO_NEAREST_KERNEL", p == 0 ? "0" : "1", 1);  // the baseline keeps nearest images on the gather kernel's exact chain
     tio_reload_env();  // (the library parses its switches once per process otherwise)
-    geom.precision = kPaths[p].fast ? TIO_PRECISION_FAST : TIO_PRECISION_EXACT;
+    geom.precision = kPaths[p].precision;
     // a FAST call samples its float32 trilinear images within 1e-4 when every other image of the call has a kernel of its
     // own (nearest without a fill rule: resample_nearest.hpp, bit-exact); any other image pins the exact kernels for all
     bool fast_set = true;
     for (const Image& im : cs.images)
       fast_set &= (im.dtype == TIO_F32 && im.interp == TIO_LINEAR) || (im.interp == TIO_NEAREST && p != 0);  // (round 4: with or without a fill rule)
-    const bool fast_call = kPaths[p].fast && fast_set;
+    const bool fast_call = kPaths[p].precision == TIO_PRECISION_FAST && fast_set;
+    const bool tight_call = kPaths[p].precision == TIO_PRECISION_TIGHT;  // (launches the lean kernel does not take are exact: inside the bar)
     for (Image& im : cs.images) HIP_CHECK(hipMemset(im.d_out, 0xCD, static_cast<size_t>(B) * im.channels * n_out * dtype_bytes(im.dtype)));
     int st = tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
     if (st != 0) { fprintf(stderr, "%s/%s: tio_resample3d failed %d: %s\n", cs.name.c_str(), kPaths[p].name, st, tio_last_error()); return 1; }
@@ -367,27 +377,37 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
       HIP_CHECK(hipMemcpy(got.data(), im.d_out, got.size(), hipMemcpyDeviceToHost));
       if (p == 0) first[i] = got;
       const bool tolerant = fast_call && im.dtype == TIO_F32 && im.interp == TIO_LINEAR;
-      if (tolerant) {  // |fast - exact| <= 1e-4 max(1, |exact|); a flipped fill decision (mask within rounding of 0.5) counts apart
-        // (this harness samples WHITE NOISE of range 4: a coordinate difference d is a value difference of up to ~4 d, and
-        // the FAST and the exact coordinates — both ~1e-7 S from the true one — differ by up to ~4e-5 at S = 512: the
-        // bar scales with the edge beyond 256)
-        const int s_max = std::max(cs.in_shape[0], std::max(cs.in_shape[1], cs.in_shape[2]));
-        const double tol = 1e-4 * std::max(1.0, s_max / 256.0 * 2.0 - 1.0);
+      if (tight_call && im.dtype == TIO_F32 && im.interp == TIO_LINEAR) {
+        // TIGHT: the north-star bar PER VOXEL, no exempt voxel: |d| <= 1e-4 max(|ref|, 1e-3 range); this harness samples white
+        // noise in [-1, 3): range 4.  (Same coordinates, taps and fill decisions as the reference: what differs is the rounding
+        // of seven fused multiply-adds.)
         const float* gf = reinterpret_cast<const float*>(got.data());
         const float* ff = reinterpret_cast<const float*>(first[i].data());
-        size_t flips = 0;
         for (size_t e = 0; e < got.size() / 4; e++) {
           const double ref = ff[e], val = gf[e];
-          const double rel = fabs(val - ref) / fmax(1.0, fabs(ref));
-          if (!(rel <= tol)) {
+          const double rel = fabs(val - ref) / fmax(fabs(ref), 1e-3 * 4.0);
+          if (!(rel <= 1e-4)) diff_first++;
+          else if (rel > max_rel) max_rel = rel;
+        }
+        continue;
+      }
+      if (tolerant) {  // FAST's contract: |fast - exact| <= 1e-4 of the intensity RANGE (4 here), every size, fill decisions included
+        const double tol = 1e-4 * 4.0;
+        const float* gf = reinterpret_cast<const float*>(got.data());
+        const float* ff = reinterpret_cast<const float*>(first[i].data());
+        size_t flips = 0, beyond_voxel = 0;
+        for (size_t e = 0; e < got.size() / 4; e++) {
+          const double ref = ff[e], val = gf[e];
+          const double ad = fabs(val - ref);
+          if (!(ad <= 1e-4 * fmax(fabs(ref), 1e-3 * 4.0))) beyond_voxel++;  // the per-voxel bar FAST is NOT held to (reported)
+          if (!(ad <= tol)) {
             const bool fill_flip = im.with_fill && (ff[e] == im.fill[(e / n_out) % im.channels] || gf[e] == im.fill[(e / n_out) % im.channels]);
             if (fill_flip) flips++; else diff_first++;
-          } else if (rel > max_rel) max_rel = rel;
+          } else if (ad / 4.0 > max_rel) max_rel = ad / 4.0;
         }
-        // (until round 4 up to 64 flipped fill decisions per image were tolerated here; the FAST kernels now take the decision of
-        // voxels within rounding of the threshold from the exact chain — resample_exact_chain.hpp —, so a flip is a failure)
         diff_first += flips;
         if (flips) printf("  [%zu fill flips]", flips);
+        printf("  [beyond the per-voxel bar: %zu]", beyond_voxel);
         continue;
       }
       const size_t before_first = diff_first;
@@ -406,7 +426,8 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     printf("%-34s %-13s", cs.name.c_str(), kPaths[p].name);
     if (time_it) printf(" %8.3f ms  %8.1f GB/s algorithmic (%5.1f%% of 8 TB/s)", ms, algorithmic / (ms * 1e6), algorithmic / (ms * 1e6) / 80.0);
     printf("  mismatch vs gather: %zu", diff_first);
-    if (fast_call) printf("  (max rel %.2e)", max_rel);
+    if (fast_call) printf("  (max |d| / range %.2e)", max_rel);
+    if (tight_call) printf("  (max |d| / max(|ref|, 1e-3 range) %.2e)", max_rel);
     if (check_oracle) printf("  vs oracle: %zu", diff_oracle);
     printf("\n");
     fflush(stdout);

@@ -33,7 +33,7 @@ def _geometry(batch, shape, elastic, seed):
     )
 
 
-@pytest.mark.parametrize("precision,elastic", [("fast", False), ("fast", True), ("exact", False)])
+@pytest.mark.parametrize("precision,elastic", [("fast", False), ("fast", True), ("exact", False), ("exact", True), ("tight", False), ("tight", True)])
 def test_plan_made_ahead_on_another_stream_is_the_plan_of_the_call(hip, precision, elastic):
     batch, shape = 3, (256, 256, 256)  # 12 288 bricks: the smallest launch that starts from a plan by itself
     data = torch.rand(batch, 1, *shape, generator=torch.Generator(device="cuda").manual_seed(5), device="cuda")
@@ -66,7 +66,10 @@ def test_plan_made_ahead_on_another_stream_is_the_plan_of_the_call(hip, precisio
 def test_no_plan_for_launches_that_take_another_road(hip):
     small = _geometry(2, (64, 64, 64), False, seed=9)  # 128 bricks: in-kernel boxes
     assert hip.resample_plan(batch=2, in_shape=(64, 64, 64), precision="fast", **small) is None
-    elastic_exact = _geometry(3, (256, 256, 256), True, seed=9)  # the exact elastic launch plans nothing
+    # (round 5: the exact ELASTIC launch of unit-spacing volumes plans too — the lean exact-coordinate kernel; with another
+    # spacing its displacements are divided per voxel and it stays on the brick kernel's in-kernel boxes)
+    elastic_exact = _geometry(3, (256, 256, 256), True, seed=9)
+    elastic_exact.update(in_spacing=(1, 1, 2), out_spacing=(1, 1, 2))
     assert hip.resample_plan(batch=3, in_shape=(256, 256, 256), precision="exact", **elastic_exact) is None
     odd = _geometry(3, (256, 256, 254), False, seed=9)  # K not a multiple of 4: no LDS-DMA rows
     assert hip.resample_plan(batch=3, in_shape=(256, 256, 254), precision="fast", **odd) is None

@@ -119,14 +119,18 @@ def test_fast_precision_256_within_tolerance_of_the_oracle(oracle, hip):
         tio.set_resample_precision(previous)
     assert torch.equal(expected.seg.data, actual.seg.data.cpu()), "labels must never take the fast path"
     want, got = expected.t1.data.double(), actual.t1.data.cpu().double()
-    # unit-range data: |ref| < 1 almost everywhere, so this bar is 1e-4 OF THE INTENSITY RANGE (absolute in those units),
-    # not 1e-4 of each value; test_headline_mode_256_matches_oracle repeats it on data scaled to a 12-bit range
-    rel = (want - got).abs() / want.abs().clamp_min(1.0)
-    # a voxel whose in-bounds weight sits within rounding of 0.5 may take the fill value in one path and not in the
-    # other (measure zero; the reference has the same sensitivity to its own rounding): count those apart
-    flipped = rel > 1e-4
-    assert int(flipped.sum()) <= 64, f"{int(flipped.sum())} voxels beyond 1e-4"
-    assert float(rel[~flipped].max()) <= 1e-4
+    # FAST's contract is 1e-4 OF THE INTENSITY RANGE (unit-range data: an absolute 1e-4), for EVERY voxel — the 64-voxel
+    # exemption of rounds 1 - 4 is gone (the fill decisions are the exact chain's since round 4).  It does
+    # NOT meet the per-voxel bar on white noise (one ulp of a coordinate is already more): that is `precision="tight"`
+    # (tests/test_gpu_tight.py); the count is recorded here, not asserted.
+    value_range = float(want.max() - want.min())
+    err = (want - got).abs()
+    assert int((err > 1e-4 * value_range).sum()) == 0, f"{int((err > 1e-4 * value_range).sum())} voxels beyond 1e-4 of the range"
+    per_voxel_beyond = int((err / want.abs().clamp_min(1e-3 * value_range) > 1e-4).sum())
+    import json, os  # noqa: E401, PLC0415
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/fast_precision_256.json", "w") as handle:
+            json.dump({"max_over_range": float(err.max()) / value_range, "beyond_per_voxel_bar": per_voxel_beyond, "voxels": err.numel()}, handle)
 
 
 class _Calls:
@@ -155,13 +159,16 @@ class _Calls:
         del self.engine._call, self.engine.blur_fused
 
 
+@pytest.mark.parametrize("precision", ["tight", "fast"])
 @pytest.mark.parametrize("intensity_scale", [1.0, 4095.0])
-def test_headline_mode_256_matches_oracle(oracle, hip, intensity_scale):
-    """The EXACT configuration bench.py's headline is quoted on: `noise=philox` +
-    `resample=fast` + the lazily fused BiasField / Blur / Noise, per-instance parameters, 256^3 float32, a batch large enough
-    (3 x 4096 bricks) for the planned-brick kernel.  The oracle runs the same Philox stream, so the whole pipeline is
-    comparable: every float within 1e-4 OF THE INTENSITY RANGE of the oracle (range = max - min of the input; the bar is
-    absolute in those units, stated as such), on unit-range data and on data scaled to a 12-bit scanner range."""
+def test_headline_mode_256_matches_oracle(oracle, hip, intensity_scale, precision):
+    """The EXACT configuration bench.py's headline is quoted on: `noise=philox` + `resample=tight` (round 5; `fast` = the
+    headline of rounds 2 - 4, still timed in the bench's mode matrix) + fused multiply-adds in the stencil + the lazily fused
+    BiasField / Blur / Noise, per-instance parameters, 256^3 float32, a batch large enough (3 x 4096 bricks) for the planned
+    kernels.  The oracle runs the same Philox stream, so the whole pipeline is comparable, on unit-range data and on data
+    scaled to a 12-bit scanner range.  `tight`: EVERY voxel inside |d| <= 1e-4 max(|ref|, 1e-3 range) — the north-star
+    bar per voxel (the same metric as the default mode's test).  `fast`: every voxel within 1e-4 OF THE
+    INTENSITY RANGE (its contract); its per-voxel count is recorded, not asserted — it cannot be zero on white noise."""
     from parity_harness import benchmark_compose  # noqa: PLC0415
 
     size, batch = 256, 3
@@ -173,7 +180,7 @@ def test_headline_mode_256_matches_oracle(oracle, hip, intensity_scale):
     previous = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision())
     try:
         tio.set_noise_rng("philox")
-        tio.set_resample_precision("fast")
+        tio.set_resample_precision(precision)
         tio.set_stencil_precision("fast")  # bench.py's headline: fused multiply-adds in the Blur's taps
         torch.manual_seed(32)
         with use_engine(oracle):
@@ -198,20 +205,21 @@ def test_headline_mode_256_matches_oracle(oracle, hip, intensity_scale):
     value_range = float(want.max() - want.min())
     err = (want - got).abs() / value_range
     beyond = err > 1e-4
+    rel = (want - got).abs() / want.abs().clamp_min(1e-3 * value_range)
     stats = {
-        "intensity_scale": intensity_scale, "value_range": value_range, "voxels": err.numel(), "beyond_1e-4": int(beyond.sum()),
+        "precision": precision, "intensity_scale": intensity_scale, "value_range": value_range, "voxels": err.numel(), "beyond_1e-4": int(beyond.sum()),
         "beyond_2e-4": int((err > 2e-4).sum()), "beyond_5e-4": int((err > 5e-4).sum()), "max": float(err.max()),
         "mean": float(err.mean()), "p99.99": float(err.flatten()[:: 7].kthvalue(int(0.9999 * err.flatten()[:: 7].numel())).values),
+        "per_voxel_max": float(rel.max()), "per_voxel_beyond_1e-4": int((rel > 1e-4).sum()),
     }
     import json, os  # noqa: E401, PLC0415
     if os.path.isdir("gpurun_out"):
-        with open(f"gpurun_out/headline_parity_{int(intensity_scale)}.json", "w") as handle:
+        with open(f"gpurun_out/headline_parity_{precision}_{int(intensity_scale)}.json", "w") as handle:
             json.dump(stats, handle)
-    # Round 3 measured 1.1 - 1.8 k of 50 M voxels beyond 1e-4 (up to 5e-3 of the range): fill-rule flips — a voxel whose
-    # in-bounds weight is within float rounding of 0.5 took the fill value in one path and the sample in the other, and the
-    # Blur spread each flip over its (2r + 1)^3 neighbourhood.  Since round 4 the FAST kernels re-decide exactly those voxels
-    # with the reference's own coordinate chain (csrc/resample_exact_chain.hpp), so there is no exemption any more:
-    # EVERY voxel within 1e-4 of the intensity range (north_star: "float intensity within 1e-4 rel").
+    # every voxel within 1e-4 of the intensity range, both modes, no exemption (round 4: the FAST kernels take the fill decision of
+    # voxels within rounding of the threshold from the exact chain; tight: the reference's decisions by construction)
     assert stats["beyond_1e-4"] == 0, stats
     assert stats["max"] <= 1e-4, stats
     assert stats["p99.99"] <= 2e-5, stats
+    if precision == "tight":  # the per-voxel bar, no exempt voxel
+        assert stats["per_voxel_beyond_1e-4"] == 0 and stats["per_voxel_max"] <= 1e-4, stats

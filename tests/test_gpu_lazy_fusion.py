@@ -216,9 +216,10 @@ def test_reference_noise_rides_on_the_stencil_stores(hip, size, batch, per_insta
     names = ["t1", "t2"] if second else ["t1"]
     head = lambda: [tio.BiasField(per_instance=per_instance), tio.Blur(std=(0.5, 2), per_instance=per_instance)]  # noqa: E731
     transform = tio.Compose([*head(), tio.Noise(per_instance=per_instance)])
-    previous, previous_stencil = tio.get_noise_rng(), tio.get_stencil_precision()
+    previous, previous_stencil, previous_policy = tio.get_noise_rng(), tio.get_stencil_precision(), tio.get_draw_policy()
     tio.set_noise_rng("reference")
     tio.set_stencil_precision(precision)
+    tio.set_draw_policy("free")  # (round 5: the draw stream is a POLICY — default "off"; this test is about the road with it)
     try:
         seen_draws = []
         original = hip.blur_fused
@@ -266,6 +267,7 @@ def test_reference_noise_rides_on_the_stencil_stores(hip, size, batch, per_insta
     finally:
         tio.set_noise_rng(previous)
         tio.set_stencil_precision(previous_stencil)
+        tio.set_draw_policy(previous_policy)
 
 
 @pytest.mark.parametrize("precision", ["exact", "fast"])
@@ -318,8 +320,9 @@ def test_reference_noise_on_the_draw_stream_from_several_threads(hip):
     import copy
     from concurrent.futures import ThreadPoolExecutor
 
-    previous = tio.get_noise_rng()
+    previous, previous_policy = tio.get_noise_rng(), tio.get_draw_policy()
     tio.set_noise_rng("reference")
+    tio.set_draw_policy("free")
     try:
         subjects = make_subjects(72, 3, seed=41, with_label=False)
         base = tio.SubjectsBatch.from_subjects(subjects).to("cuda")
@@ -347,3 +350,42 @@ def test_reference_noise_on_the_draw_stream_from_several_threads(hip):
         assert not torch.equal(expected[0], expected[1])
     finally:
         tio.set_noise_rng(previous)
+        tio.set_draw_policy(previous_policy)
+
+
+@pytest.mark.parametrize("policy", ["off", "free", "gated"])
+def test_two_noise_children_in_one_compose_keep_their_own_streams(hip, policy):
+    """both Noise children of a Compose that draws ahead start the plan of their generator's stream BEFORE
+    any child applies; the pinned staging buffer of the first plan had no recorded upload yet and was handed out again — two
+    jobs wrote one buffer.  The result must be the sequential one, under every draw policy."""
+    previous, previous_policy = tio.get_noise_rng(), tio.get_draw_policy()
+    tio.set_noise_rng("reference")
+    tio.set_draw_policy(policy)
+    try:
+        subjects = make_subjects(104, 1, seed=51, with_label=False)  # 1 124 864 voxels: the device draws the stream itself
+        pipeline = tio.Compose([tio.Noise(std=(0.1, 0.2)), tio.Blur(std=(0.5, 1.5)), tio.Noise(std=(0.3, 0.4))])
+        assert pipeline._may_draw_ahead()
+        gpu = tio.SubjectsBatch.from_subjects(subjects).to("cuda")
+        torch.manual_seed(77)
+        ahead = pipeline(gpu)
+        history = ahead.applied_transforms
+        seeds = [t.params["seed"] for t in history if t.name == "Noise"]
+        assert len(seeds) == 2 and seeds[0] != seeds[1]
+        # the same recorded parameters, child by child (no draw-ahead road)
+        stepwise = tio.SubjectsBatch.from_subjects(subjects).to("cuda")
+        for child, record in zip(pipeline.transforms, history, strict=True):
+            stepwise = child.apply_transform(stepwise, record.params)
+        torch.cuda.synchronize()
+        assert torch.equal(ahead.t1.data, stepwise.t1.data)
+        # and torch's own streams on the host for the first child
+        x = tio.SubjectsBatch.from_subjects(subjects).t1.data
+        z = torch.randn(x.shape, generator=torch.Generator().manual_seed(seeds[0]))
+        first = pipeline.transforms[0].apply_transform(tio.SubjectsBatch.from_subjects(subjects).to("cuda"), history[0].params)
+        std = history[0].params["std"]
+        std = std[0] if isinstance(std, list) else std
+        mean = history[0].params["mean"]
+        mean = mean[0] if isinstance(mean, list) else mean
+        torch.testing.assert_close(first.t1.data.cpu(), x + (mean + std * z), rtol=0, atol=0)
+    finally:
+        tio.set_noise_rng(previous)
+        tio.set_draw_policy(previous_policy)

@@ -849,3 +849,32 @@ def test_pending_flush_takes_explicit_draws_from_a_callable_and_keeps_the_plain_
     pending = _pending.Pending(blur=(torch.ones(1, 3, 3), [1, 1, 1]))
     assert torch.equal(_pending.flush(data, pending, noise=(0.0, 1.0, 1234)), stub.fused_answer)
     assert calls == [("blur_fused", "int")]
+
+
+def test_precision_and_draw_policy_switches():
+    """Round 5: the third resampling precision and the draw policy of the reference's noise stream are process-wide switches
+    with validated values (no GPU needed)."""
+    import torchio_amd as tio
+    from torchio_amd import _abi, ops
+
+    assert ops.PRECISION_CODES == {"exact": _abi.PRECISION_EXACT, "fast": _abi.PRECISION_FAST, "tight": _abi.PRECISION_TIGHT}
+    assert (_abi.PRECISION_EXACT, _abi.PRECISION_FAST, _abi.PRECISION_TIGHT) == (0, 1, 2)
+    previous = tio.get_resample_precision()
+    try:
+        tio.set_resample_precision("tight")
+        assert tio.get_resample_precision() == "tight"
+        with pytest.raises(ValueError):
+            tio.set_resample_precision("approximate")
+    finally:
+        tio.set_resample_precision(previous)
+    policy = tio.get_draw_policy()
+    try:
+        for name in ("gated", "free", "off"):
+            tio.set_draw_policy(name)
+            assert tio.get_draw_policy() == name
+        with pytest.raises(ValueError):
+            tio.set_draw_policy("sometimes")
+        tio.set_draw_policy("off")
+        assert ops.draw_stream("cuda:0") is None  # off: the draws are made on the data stream
+    finally:
+        tio.set_draw_policy(policy)

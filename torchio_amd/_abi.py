@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_IMAGES = 8
 
 # tio_status
@@ -23,7 +23,7 @@ BSPLINE4, BSPLINE5, BSPLINE6, BSPLINE7 = 6, 7, 8, 9  # B-spline orders 4 - 7 ("f
 # tio_pad_mode
 PAD_CONSTANT, PAD_REFLECT, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2, 3
 # tio_precision
-PRECISION_EXACT, PRECISION_FAST = 0, 1
+PRECISION_EXACT, PRECISION_FAST, PRECISION_TIGHT = 0, 1, 2
 
 
 class ResampleGeom(C.Structure):

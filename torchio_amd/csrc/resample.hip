@@ -604,6 +604,7 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 #include "resample_exact_chain.hpp"
 #include "resample_tile.hpp"
 #include "resample_fast.hpp"
+#include "resample_lean_exact.hpp"
 #include "resample_nearest.hpp"
 
 // Device scratch for the brick plan of a planned launch (resample_fast.hpp): one buffer per (device, stream), grown on
@@ -925,7 +926,15 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     // fast intensity path: float32 trilinear images only (nearest / label images need the exact coordinates)
     const bool fast = geom->precision == TIO_PRECISION_FAST && dtmode == 0 && !a.any_nearest && variant == 0 &&
                       !env.resample_exact;
-    if (fast) {
+    // Round 5: the lean planned kernel with the reference's own coordinates (resample_lean_exact.hpp).  TIO_PRECISION_TIGHT:
+    // fused interpolation on exact coordinates / taps / fill decisions; TIO_PRECISION_EXACT: ATen's interpolation order too,
+    // bit-identical to the brick kernel below (TIO_EXACT_LEAN=0 keeps large exact launches on the brick kernel, =2 sends
+    // small ones to the lean kernel as well: A/B and tests).  Float32 trilinear images only, divisors the short division is
+    // proven for, unit spacing whenever a displacement is divided by it; everything else runs the exact brick kernel.
+    const bool tight = geom->precision == TIO_PRECISION_TIGHT;
+    const bool lean_exact = !fast && (tight || (geom->precision == TIO_PRECISION_EXACT && env.exact_lean != 0)) && dtmode == 0 &&
+                            !a.any_nearest && variant == 0 && a.ablate == 0 && a.short_div != 0 && (a.cp == nullptr || a.unit_spacing != 0);
+    if (fast || lean_exact) {
       a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
       a.magic_k = a.tiles_k > 1 ? 0xFFFFFFFFu / a.tiles_k + 1u : 0u;
       a.magic_j = a.tiles_j > 1 ? 0xFFFFFFFFu / a.tiles_j + 1u : 0u;
@@ -938,8 +947,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       // kernel's FAST instantiation with its in-kernel boxes.
       // (small launches keep the single-kernel road: the planning kernel and the gap before the second launch cost
       // ~10-15 us, more than the planned bricks save below ~12 k bricks; TIO_FAST_KERNEL=planned forces them)
-      const bool force_planned = env.fast_kernel == 2;
-      bool planned = env.fast_kernel != 1 && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned) && blocks < (1LL << 26);
+      const bool force_planned = lean_exact ? (env.fast_kernel == 2 || env.exact_lean == 2) : env.fast_kernel == 2;
+      bool planned = (lean_exact || env.fast_kernel != 1) && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned) && blocks < (1LL << 26);
       for (int i = 0; i < a.n_images; i++) planned = planned && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
       if (planned && a.cp != nullptr) {
         const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
@@ -949,7 +958,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       if (planned) {
         // one single-channel image (what a FAST intensity launch almost always is): the lean kernel (resample_fast.hpp),
         // whose bricks may be 8 planes thick (half the tile: twice the blocks per CU)
-        const bool lean = env.planned_lean != 0;
+        const bool lean = env.planned_lean != 0 || lean_exact;
         const int64_t items64 = blocks;
         // the largest tile three blocks of which fit a CU: LDS is handed out in granules of 1 280 bytes here (measured: 13 440
         // floats keep three blocks resident, 13 568 drop to two — profiles/r04_tile_cap.log); 300 floats more than the round-3
@@ -1038,8 +1047,18 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           la.affine_first = a.affine_first; la.ablate = a.ablate;
           la.mapping = a.mapping; la.mapping_batched = a.mapping_batched; la.unit_spacing = a.unit_spacing; la.fill_recheck = a.fill_recheck;
           for (int e = 0; e < 3; e++) { la.sp[e] = a.sp[e]; la.rsp[e] = a.rsp[e]; la.den[e] = a.den[e]; la.rden[e] = a.rden[e]; }
+          for (int e = 0; e < 3; e++) { la.dh[e] = a.dh[e]; la.rdh[e] = a.rdh[e]; la.half_h[e] = a.half_h[e]; }
+          la.interleave = env.lean_interleave;
           auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3> : resample_planned_lean_kernel<false, 16, 16, 16, 3>;
-          if (la.ablate != 0)  // TIO_TILE_ABLATE: the instrumented instantiation (experiments only)
+          if (lean_exact) {  // the reference's coordinates; `tight`: fused lerps, else ATen's order (bit-identical to the brick kernel)
+            if (tight) {
+              if (min_channels > 0) kernel = a.cp != nullptr ? resample_lean_exact_kernel<true, false, 3, true> : resample_lean_exact_kernel<false, false, 3, true>;
+              else kernel = a.cp != nullptr ? resample_lean_exact_kernel<true, false, 3> : resample_lean_exact_kernel<false, false, 3>;
+            } else {
+              if (min_channels > 0) kernel = a.cp != nullptr ? resample_lean_exact_kernel<true, true, 3, true> : resample_lean_exact_kernel<false, true, 3, true>;
+              else kernel = a.cp != nullptr ? resample_lean_exact_kernel<true, true, 3> : resample_lean_exact_kernel<false, true, 3>;
+            }
+          } else if (la.ablate != 0)  // TIO_TILE_ABLATE: the instrumented instantiation (experiments only)
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, true>;
           else if (min_channels > 0)  // the folded minimum: the instantiation whose element-0 bricks track what they store
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, false, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, false, true>;
@@ -1066,16 +1085,19 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         if (a.cp != nullptr) return launch_planned(resample_planned_kernel<true, 16, 16, 16, 3>);
         return launch_planned(resample_planned_kernel<false, 16, 16, 16, 3>);
       }
-      if (mode != kPlanNone) return TIO_OK;  // a FAST launch of in-kernel boxes: no plan
-      auto launch_fast = [&](auto kernel) -> int {
-        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   static_cast<int>(lds)) != hipSuccess)
-          return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds);
-        hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a, static_cast<const int*>(nullptr));
-        return check_launch("tio_resample3d");
-      };
-      if (a.cp != nullptr) return launch_fast(resample_tile_kernel<true, 0, 16, 16, 16, 3, true>);
-      return launch_fast(resample_tile_kernel<false, 0, 16, 16, 16, 3, true>);
+      // (a TIGHT / EXACT launch the lean kernel does not take — too small, unaligned — falls through to the exact brick kernel)
+      if (fast) {
+        if (mode != kPlanNone) return TIO_OK;  // a FAST launch of in-kernel boxes: no plan
+        auto launch_fast = [&](auto kernel) -> int {
+          if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(lds)) != hipSuccess)
+            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds);
+          hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, a, static_cast<const int*>(nullptr));
+          return check_launch("tio_resample3d");
+        };
+        if (a.cp != nullptr) return launch_fast(resample_tile_kernel<true, 0, 16, 16, 16, 3, true>);
+        return launch_fast(resample_tile_kernel<false, 0, 16, 16, 16, 3, true>);
+      }
     }
     // Large affine-only exact launches of 16^3 bricks are planned too (resample_tile.hpp: the planned box only decides what
     // is staged; the corner evaluation and its reductions leave the head of every block); TIO_EXACT_PLAN=0 switches it off,

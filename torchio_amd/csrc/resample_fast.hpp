@@ -842,6 +842,10 @@ struct LeanArgs {
   const float* mapping;
   int mapping_batched, unit_spacing, fill_recheck;
   float sp[3], rsp[3], den[3], rden[3];
+  // resample_lean_exact.hpp: the folded normalise round trip (den / 2, its reciprocal, (S - 1) / 2) and the A/B switch of its
+  // interleaved DMA issue
+  float dh[3], rdh[3], half_h[3];
+  int interleave;
   // the folded minimum (tio_resample_image.out_min_dev): kMinSlots keys of this channel, or nullptr.  Only the bricks of batch
   // element 0 track what they store (a block-uniform branch into the TRACK instantiation of the sampling loop).
   uint32_t* min_keys;

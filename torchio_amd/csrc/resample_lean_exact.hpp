@@ -1,0 +1,460 @@
+// resample_lean_exact.hpp — round 5: the lean planned brick kernel with the REFERENCE'S OWN COORDINATES.
+//
+// Why it exists (VERDICT r4, weak #1 / next #1 / next #3d).  The north-star tolerance, read per voxel
+// (|d| <= 1e-4 max(|ref|, 1e-3 range)) on the white-noise volumes SURVEY 8(d) prescribes, leaves no room for a
+// coordinate that is not the reference's float32 value bit for bit: one ulp of a coordinate near 128 is 1.5e-5 voxel,
+// white noise turns that into a value difference of the same size, and a voxel whose reference value is below ~0.15
+// is then beyond the bar.  TIO_PRECISION_FAST (resample_fast.hpp: the coordinate as a line per control cell) therefore
+// cannot pass on such data whatever its fill-decision recheck does — the cause is structural.  What CAN be cheap is
+// everything else.  This kernel keeps the reference's coordinate chain, operation for operation (MKL's FMA order of the
+// affine row, ATen's lerp nesting of the displacement field, the normalise / un-normalise round trip with its correctly
+// rounded division: the sequence of resample_tile_kernel and resample_kernel, spatial.py:1504-1648 + ATen
+// grid_sampler_unnormalize), on the lean structure of resample_fast.hpp (one planned descriptor per brick, one float32
+// channel per launch, the first LDS-DMA instruction a few hundred instructions after entry), and it puts the chain
+// WHERE IT COSTS NOTHING: round 3's stamps showed a wave spending ~3 700 ticks issuing its 11 - 12 DMA instructions
+// (330 ticks each: the CU's vector-memory path pushes back) and another ~1 450 waiting for the box — the 16 planes x 30
+// vector instructions of the exact chain are issued BETWEEN the DMA instructions and while the box lands.  What is left
+// behind the barrier is floor / weights / address / 8 taps / interpolation: fewer vector instructions per voxel than the
+// FAST line kernel's sampling loop (no line evaluation, no run logic).
+//
+// Two instantiations of the interpolation:
+//   EXACT_LERP = true  — ATen's grid_sampler_3d weights and accumulation order (tile_finish): the launch is bit-identical
+//                        to resample_tile_kernel / the oracle.  TIO_PRECISION_EXACT takes it for large float32 launches.
+//   EXACT_LERP = false — TIO_PRECISION_TIGHT: three nested fma lerps on the SAME coordinates, taps and fill decisions
+//                        (the in-bounds weight is evaluated in ATen's order on ATen's weights wherever a tap can leave
+//                        the volume, so `mask > 0.5` is the reference's decision by construction — no recheck tail).
+//                        Differs from the reference by the rounding of seven fused multiply-adds: ~1e-7 of the taps.
+//
+// Included by resample.hip after resample_fast.hpp (planner, LeanArgs, StreamBox, StageLanes) and resample_tile.hpp
+// (TapSet, TileAddr, tile_issue_interior, tile_finish*, tile_mask, cp_plane, normalise_roundtrip_folded).
+#pragma once
+
+namespace tio {
+
+// ---- the packed LDS-DMA of one box as a STEPPER: the same instruction sequence as stream_stage_packed (resample_fast.hpp),
+// one instruction per call, so that the caller can put arithmetic between two of them ------------------------------------
+template <int NW>
+struct BoxDmaStepper {
+  typedef __attribute__((address_space(1))) const char* global_byte_ptr;
+  global_byte_ptr origin;
+  float* lp;
+  unsigned off, step_b, wrap_b;
+  int row, p, r;
+  int step, step_p, step_r, total_rows, Ly, lp_step;
+  int bx0, by0, I, J;
+  int left;  // DMA instructions this wave has not issued yet (wave uniform)
+  bool ch_ok, lane_ok;
+
+  __device__ __forceinline__ void init(float* tile, const float* src, const StreamBox& bx, int I_, int J_, int K, int wave, int lane) {
+    StageLanes sl;
+    sl.cpr = -1; sl.rpi = 1; sl.row_l = 0; sl.gz_rel = 0; sl.goff = 0; sl.lane_ok = false;
+    stage_lanes(sl, bx.cpr, K, lane);
+    const int rpi = sl.rpi;
+    total_rows = bx.Lx * bx.Ly;
+    // (uniform float divisions of small integers: exact after the half-step nudge — as in stream_stage_packed)
+    const int n_instr = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(total_rows + rpi - 1) + 0.5f) * __builtin_amdgcn_rcpf(static_cast<float>(rpi))));
+    step = NW * rpi;
+    const float rcp_ly = __builtin_amdgcn_rcpf(static_cast<float>(bx.Ly));
+    step_p = __builtin_amdgcn_readfirstlane(static_cast<int>((static_cast<float>(step) + 0.5f) * rcp_ly));
+    step_r = step - step_p * bx.Ly;
+    row = wave * rpi + sl.row_l;
+    p = static_cast<int>((static_cast<float>(row) + 0.5f) * rcp_ly);
+    r = row - p * bx.Ly;
+    const unsigned plane_b = static_cast<unsigned>(J_) * static_cast<unsigned>(K) * 4u, row_b = static_cast<unsigned>(K) * 4u;
+    off = static_cast<unsigned>(p) * plane_b + static_cast<unsigned>(r) * row_b + static_cast<unsigned>(sl.gz_rel) * 4u;
+    step_b = static_cast<unsigned>(step_p) * plane_b + static_cast<unsigned>(step_r) * row_b;
+    wrap_b = plane_b - static_cast<unsigned>(bx.Ly) * row_b;
+    origin = (global_byte_ptr)(src) + ((static_cast<int64_t>(bx.bx0) * J_ + bx.by0) * K + bx.za) * 4;
+    const int dgroup = rpi * bx.cpr * 4;  // LDS floats per instruction
+    lp = tile + wave * dgroup;
+    lp_step = NW * dgroup;
+    ch_ok = static_cast<unsigned>(bx.za + sl.gz_rel) < static_cast<unsigned>(K);
+    lane_ok = sl.lane_ok;
+    Ly = bx.Ly; bx0 = bx.bx0; by0 = bx.by0; I = I_; J = J_;
+    left = n_instr > wave ? (n_instr - wave + NW - 1) / NW : 0;
+  }
+
+  // one DMA instruction; INTERIOR: the box lies inside the volume (no per-row checks, nothing to zero)
+  template <bool INTERIOR>
+  __device__ __forceinline__ void issue(int lane) {
+    const bool in_box = lane_ok & (row < total_rows);
+    if constexpr (INTERIOR) {
+      if (in_box) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
+    } else {
+      const bool in_vol = in_box & ch_ok & (static_cast<unsigned>(bx0 + p) < static_cast<unsigned>(I)) &
+                          (static_cast<unsigned>(by0 + r) < static_cast<unsigned>(J));
+      if (in_vol) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
+      else if (in_box) *reinterpret_cast<float4*>(lp + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    row += step; p += step_p; r += step_r; off += step_b;
+    if (r >= Ly) { r -= Ly; p += 1; off += wrap_b; }
+    lp += lp_step;
+    left -= 1;
+  }
+};
+
+// ---- the reference's coordinate chain for one voxel, by composition mode (block uniform; literals fold the branches) ----
+//   MODE 0: no displacement (Affine; elements of an elastic launch whose control points are skipped)
+//   MODE 1: displacement on an identity mapping (ElasticDeformation alone): c + d either way round
+//   MODE 2: affine first (spatial.py:1570-1573)      MODE 3: elastic first (spatial.py:1574-1577)
+// UNIT: all three spacings are 1.0f (d / 1 is the identity); SHORT: one Markstein refinement is the correctly rounded
+// quotient for this launch's divisors (resample_tile.hpp: normalise_roundtrip_folded, tests/native/divtest.c)
+template <int MODE, bool UNIT, bool SHORT>
+__device__ __forceinline__ void lean_exact_coord(const float (&m)[12], const LeanArgs& a, float ci, float cj, float ck, float di, float dj,
+                                                 float dk, float& x, float& y, float& z) {
+#define TIO_LE_ROW(R, A, B, C) \
+  __builtin_fmaf(1.0f, m[4 * R + 3], __builtin_fmaf(C, m[4 * R + 2], __builtin_fmaf(B, m[4 * R + 1], __fmul_rn(A, m[4 * R]))))
+  float vi, vj, vk;
+  if constexpr (MODE == 0) {
+    vi = TIO_LE_ROW(0, ci, cj, ck); vj = TIO_LE_ROW(1, ci, cj, ck); vk = TIO_LE_ROW(2, ci, cj, ck);
+  } else {
+    float qi = di, qj = dj, qk = dk;
+    if constexpr (!UNIT) {
+      qi = exact_div(qi, a.sp[0], a.rsp[0]);
+      qj = exact_div(qj, a.sp[1], a.rsp[1]);
+      qk = exact_div(qk, a.sp[2], a.rsp[2]);
+    }
+    if constexpr (MODE == 1) {
+      vi = __fadd_rn(ci, qi); vj = __fadd_rn(cj, qj); vk = __fadd_rn(ck, qk);
+    } else if constexpr (MODE == 2) {
+      vi = __fadd_rn(TIO_LE_ROW(0, ci, cj, ck), qi);
+      vj = __fadd_rn(TIO_LE_ROW(1, ci, cj, ck), qj);
+      vk = __fadd_rn(TIO_LE_ROW(2, ci, cj, ck), qk);
+    } else {
+      const float ei = __fadd_rn(ci, qi), ej = __fadd_rn(cj, qj), ek = __fadd_rn(ck, qk);
+      vi = TIO_LE_ROW(0, ei, ej, ek); vj = TIO_LE_ROW(1, ei, ej, ek); vk = TIO_LE_ROW(2, ei, ej, ek);
+    }
+  }
+#undef TIO_LE_ROW
+  x = normalise_roundtrip_folded<SHORT>(vi, a.dh[0], a.rdh[0], a.half_h[0]);
+  y = normalise_roundtrip_folded<SHORT>(vj, a.dh[1], a.rdh[1], a.half_h[1]);
+  z = normalise_roundtrip_folded<SHORT>(vk, a.dh[2], a.rdh[2], a.half_h[2]);
+}
+
+// (j, k)-lerped control planes ia, ia + 1, ia + 2 of this thread's column, three components each.  NAMED members, not an
+// array: the optimiser turns `e == 0 ? P[0] : (e == 3 ? P[3] : P[6])` into a dynamically indexed load of a stack object
+// (first build of this kernel: 48 bytes of scratch per lane and a scratch_load per component per plane).
+struct CtlPlanes {
+  float a_i, a_j, a_k, b_i, b_j, b_k, c_i, c_j, c_k;
+};
+
+// The 16 planes of this thread's column (phase A), one DMA instruction of an interior box between two planes.
+//   li_lane: lane t of the wave holds ATen's lerp of plane i_begin + t along the control grid's first axis (block uniform
+//   per plane: read back as scalars)
+template <int MODE, bool UNIT, bool SHORT, bool INTERLEAVE, int NW>
+__device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const LeanArgs& a, int i0, int i_last, float cj, float ck,
+                                                  const Lerp1D& li_lane, int ia, const CtlPlanes& P, BoxDmaStepper<NW>& dma, int lane,
+                                                  float (&X)[16], float (&Y)[16], float (&Z)[16]) {
+  float pa_i = 0.f, pa_j = 0.f, pa_k = 0.f, pb_i = 0.f, pb_j = 0.f, pb_k = 0.f;
+  int cur0 = -1, cur1 = -1;
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    if constexpr (INTERLEAVE) {
+      // ONE DMA instruction, then ONE plane (fenced: left alone the scheduler hoists a group's four DMA instructions in front
+      // of its four planes, and a wave that waits at the vector-memory queue issues no arithmetic; a wave issues one
+      // vector instruction per ~5 clocks on this chip whatever its ILP — profiles/r02_resample_sq.md — so nothing is lost)
+      if (dma.left > 0) dma.template issue<true>(lane);  // (wave-uniform branch)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float ci = static_cast<float>(min(i0 + t, i_last));  // (scalar unit, one conversion)
+    float di = 0.0f, dj = 0.0f, dk = 0.0f;
+    if constexpr (MODE != 0) {
+      // the two control planes a voxel lerps between change once or twice per brick: named registers that a SCALAR branch
+      // refreshes (resample_tile.hpp: indexing by the plane number costs an s_set_gpr_idx sequence per access)
+      const int e0 = __builtin_amdgcn_readlane(li_lane.i0, t) - ia;
+      const int e1 = __builtin_amdgcn_readlane(li_lane.i1, t) - ia;
+      const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l0), t));
+      const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l1), t));
+      if (e0 != cur0) {
+        if (e0 == 0) { pa_i = P.a_i; pa_j = P.a_j; pa_k = P.a_k; }
+        else if (e0 == 1) { pa_i = P.b_i; pa_j = P.b_j; pa_k = P.b_k; }
+        else { pa_i = P.c_i; pa_j = P.c_j; pa_k = P.c_k; }
+        cur0 = e0;
+      }
+      if (e1 != cur1) {
+        if (e1 == 0) { pb_i = P.a_i; pb_j = P.a_j; pb_k = P.a_k; }
+        else if (e1 == 1) { pb_i = P.b_i; pb_j = P.b_j; pb_k = P.b_k; }
+        else { pb_i = P.c_i; pb_j = P.c_j; pb_k = P.c_k; }
+        cur1 = e1;
+      }
+      di = lerp2(pa_i, l0, pb_i, l1);
+      dj = lerp2(pa_j, l0, pb_j, l1);
+      dk = lerp2(pa_k, l0, pb_k, l1);
+    }
+    lean_exact_coord<MODE, UNIT, SHORT>(m, a, ci, cj, ck, di, dj, dk, X[t], Y[t], Z[t]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ATen's grid_sampler_3d for ONE voxel straight from global memory (bricks whose box does not fit the tile, non-finite
+// geometry): per-tap bounds, zero padding, the in-bounds weight mask and the fill rule in ATen's accumulation order —
+// gather_voxel's arithmetic (resample_tile.hpp) for one float32 channel.  Bit-identical to the exact kernels in both
+// instantiations (these bricks are rare; the fused lerps are not worth a second copy).
+__device__ __forceinline__ float lean_exact_gather(const float* __restrict__ chan, int J, int K, float x, float y, float z, bool has_fill,
+                                                   float fillv, float hx, float hy, float hz) {
+  const float x0 = floorf(x), y0 = floorf(y), z0 = floorf(z);
+  const float x1 = x0 + 1.0f, y1 = y0 + 1.0f, z1 = z0 + 1.0f;
+  const float wx0 = x1 - x, wx1 = x - x0, wy0 = y1 - y, wy1 = y - y0, wz0 = z1 - z, wz1 = z - z0;
+  const bool bx0 = (x0 >= 0.0f) & (x0 <= hx), bx1 = (x1 >= 0.0f) & (x1 <= hx);
+  const bool by0 = (y0 >= 0.0f) & (y0 <= hy), by1 = (y1 >= 0.0f) & (y1 <= hy);
+  const bool bz0 = (z0 >= 0.0f) & (z0 <= hz), bz1 = (z1 >= 0.0f) & (z1 <= hz);
+  const int ix0 = static_cast<int>(fminf(fmaxf(x0, 0.0f), hx)), ix1 = static_cast<int>(fminf(fmaxf(x1, 0.0f), hx));
+  const int iy0 = static_cast<int>(fminf(fmaxf(y0, 0.0f), hy)), iy1 = static_cast<int>(fminf(fmaxf(y1, 0.0f), hy));
+  const int iz0 = static_cast<int>(fminf(fmaxf(z0, 0.0f), hz)), iz1 = static_cast<int>(fminf(fmaxf(z1, 0.0f), hz));
+  float val = 0.0f, mask = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const float w = __fmul_rn(__fmul_rn((k & 1) ? wx1 : wx0, (k & 2) ? wy1 : wy0), (k & 4) ? wz1 : wz0);
+    const bool ok = ((k & 1) ? bx1 : bx0) & ((k & 2) ? by1 : by0) & ((k & 4) ? bz1 : bz0);
+    const int off = (((k & 1) ? ix1 : ix0) * J + ((k & 2) ? iy1 : iy0)) * K + ((k & 4) ? iz1 : iz0);
+    const float v = chan[off];
+    const float next_v = __fadd_rn(val, __fmul_rn(v, w));
+    const float next_m = __fadd_rn(mask, w);
+    val = ok ? next_v : val;
+    mask = ok ? next_m : mask;
+  }
+  if (has_fill) val = (mask > 0.5f) ? val : fillv;
+  return val;
+}
+
+// Four planes [4 q, 4 q + 4) of this thread's column from the staged box.  MASKED: a tap of this wave's group can leave the
+// volume and the image has a fill rule — the in-bounds weight on ATen's weights in ATen's order (tile_mask).
+// GUARD: a partial brick (stores predicated).  TRACK: the folded minimum of batch element 0.
+template <bool EXACT_LERP, bool MASKED, bool GUARD, bool TRACK>
+__device__ __forceinline__ void lean_exact_group(const float (&X4)[4], const float (&Y4)[4], const float (&Z4)[4], const TileAddr& ta, char*& out_generic,
+                                                 unsigned urow, int64_t slab_b, int t0, int i_count, bool col_active, float hx, float hy,
+                                                 float hz, bool has_fill, float fillv, uint32_t& kmin) {
+  typedef __attribute__((address_space(1))) char* global_char_ptr;   // (typed global: a flat store would count on lgkmcnt too —
+  typedef __attribute__((address_space(1))) float* global_float_ptr;  //  resample_fast.hpp: fast_sample_run)
+  global_char_ptr out_t = (global_char_ptr)out_generic;
+  TapSet ts[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) tile_issue_interior<false>(ts[u], X4[u], Y4[u], Z4[u], ta, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    float val = EXACT_LERP ? tile_finish(ts[u]) : tile_finish_fast(ts[u]);
+    if constexpr (MASKED) val = (!has_fill || tile_mask(ts[u], X4[u], Y4[u], Z4[u], hx, hy, hz) > 0.5f) ? val : fillv;
+    const bool live = !GUARD || (col_active && (t0 + u) < i_count);
+    if (live) {
+      *(global_float_ptr)(out_t + urow) = val;
+      if constexpr (TRACK) kmin = min(kmin, float_to_key(val));
+    }
+    out_t += slab_b;
+    asm volatile("" : "+s"(out_t));  // one running pointer (2 scalar adds per plane)
+  }
+  out_generic = (char*)out_t;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// can a tap of these four voxels lie outside the volume?  (first taps in [0, S - 2] on every axis <=> all eight inside)
+__device__ __forceinline__ bool lean_exact_group_leaves(const float (&X4)[4], const float (&Y4)[4], const float (&Z4)[4], float hx, float hy, float hz) {
+  const float xl = fminf(fminf(X4[0], X4[1]), fminf(X4[2], X4[3])), xh = fmaxf(fmaxf(X4[0], X4[1]), fmaxf(X4[2], X4[3]));
+  const float yl = fminf(fminf(Y4[0], Y4[1]), fminf(Y4[2], Y4[3])), yh = fmaxf(fmaxf(Y4[0], Y4[1]), fmaxf(Y4[2], Y4[3]));
+  const float zl = fminf(fminf(Z4[0], Z4[1]), fminf(Z4[2], Z4[3])), zh = fmaxf(fmaxf(Z4[0], Z4[1]), fmaxf(Z4[2], Z4[3]));
+  // (a NaN coordinate compares false: the group is "leaving" and takes the masked code, whose bounds tests are ATen's)
+  const bool inside = (xl >= 0.0f) & (xh < hx) & (yl >= 0.0f) & (yh < hy) & (zl >= 0.0f) & (zh < hz);
+  return !inside;
+}
+
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, int WAVES_PER_SIMD, bool FOLD_MIN = false>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kernel(const LeanArgs a) {
+  constexpr int TI = 16, TJ = 16, TK = 16, NW = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_tile = smem;
+  typedef __attribute__((address_space(4))) const int* const_int_ptr;
+  typedef __attribute__((address_space(4))) const float* const_float_ptr;
+
+  // every argument the road to the first DMA needs, in scalar registers NOW (resample_planned_lean_kernel)
+  {
+    const int* plan_p = a.plan; const float* in_p = a.in; const float* map_p = a.mapping;
+    asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(map_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K));
+  }
+  const unsigned brick = xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items));
+  const int b = static_cast<int>(fastdiv_exact(brick, a.bpe_magic, a.bricks_per_element));
+  // descriptor and the element's UNSCALED mapping (the planner's copy is scaled by the axis ratios), requested together
+  const_int_ptr d = (const_int_ptr)(a.plan + a.B * 16) + static_cast<size_t>(brick) * kDescInts;
+  const_float_ptr mp = (const_float_ptr)(a.mapping) + (a.mapping_batched ? b * 12 : 0);
+  const int kind_w = d[0];
+  StreamBox bx;
+  bx.bx0 = d[1]; bx.by0 = d[2]; bx.za = d[3]; bx.Lx = d[4]; bx.Ly = d[5]; bx.cpr = d[6];
+  const int i_begin = d[11], j_lo = d[12], k_lo = d[13];
+  const bool elastic = ELASTIC_POSSIBLE && d[14] != 0;
+  float m[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) m[q] = mp[q];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tk = tid & (TK - 1), tj = tid / TK;
+  const int slab = a.Jo * a.Ko;
+  const int64_t slab_b = static_cast<int64_t>(slab) * 4;
+  const float* in_chan = a.in + static_cast<int64_t>(b) * a.in_stride;
+  char* out_chan = reinterpret_cast<char*>(a.out + static_cast<int64_t>(b) * a.out_stride);
+
+  const int kind = kind_w & 0xFF;
+  bx.kind = kind; bx.interior = kind_w >> 8;
+  BoxDmaStepper<NW> dma;
+  dma.left = 0;
+  if (kind == kDescStaged) dma.init(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane);
+
+  const int i_count = min(TI, a.Io - i_begin), nv = min(TJ, a.Jo - j_lo), nw = min(TK, a.Ko - k_lo);
+  const bool col_active = (tj < nv) & (tk < nw);
+  const bool full = (i_count == TI) & (nv == TJ) & (nw == TK);  // block uniform
+  // out-of-range threads shadow the last valid column (coordinates of real voxels: the planned box covers them) and never store
+  const int jv = min(tj, nv - 1), kw = min(tk, nw - 1);
+  const int col_off = (j_lo + jv) * a.Ko + (k_lo + kw);
+  const unsigned urow = static_cast<unsigned>(col_off) * 4u;
+  const bool has_fill = a.fill != nullptr;
+  const float fillv = has_fill ? ((const_float_ptr)a.fill)[0] : 0.0f;
+  const float hx = a.hx, hy = a.hy, hz = a.hz;
+
+  const bool track = FOLD_MIN && a.min_keys != nullptr && b == 0;  // block uniform
+  uint32_t kmin = 0xFFFFFFFFu;
+  auto publish_min = [&]() {  // (one returnless atomic per wave, spread over kMinSlots addresses by brick: resample_planned_kernel)
+    const uint32_t wmin = wave_min_u32(kmin);
+    if (lane == 0 && wmin != 0xFFFFFFFFu)
+      __hip_atomic_fetch_min(a.min_keys + (brick & (kMinSlots - 1)), wmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (kind == kDescGated || kind == kDescOutside) {  // gated-out element: bit-exact copy; nothing of the volume in sight: fill (or 0)
+    if (col_active) {
+      for (int t = i_begin; t < i_begin + i_count; t++) {
+        const float val = kind == kDescGated ? in_chan[static_cast<int64_t>(t) * slab + col_off] : fillv;
+        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
+        kmin = min(kmin, float_to_key(val));
+      }
+    }
+    if (track) publish_min();
+    return;
+  }
+
+  const float cj = static_cast<float>(j_lo + jv), ck = static_cast<float>(k_lo + kw);
+  const float* cp = elastic ? a.cp + (a.cp_batched ? static_cast<int64_t>(b) * (a.ni * a.nj * a.nk * 3) : 0) : nullptr;
+  Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
+  if constexpr (ELASTIC_POSSIBLE) {
+    if (elastic) {
+      lj = lerp_index(j_lo + jv, a.nj, a.Jo, a.scj);
+      lk = lerp_index(k_lo + kw, a.nk, a.Ko, a.sck);
+    }
+  }
+  const int i_last = i_begin + i_count - 1;
+  // the plane lerps of the control grid: lane t computes plane t's (block uniform per plane)
+  Lerp1D li_lane{0, 0, 1.0f, 0.0f};
+  int ia = 0, ib = 0;
+  if constexpr (ELASTIC_POSSIBLE) {
+    if (elastic) {
+      li_lane = lerp_index(min(i_begin + (lane & (TI - 1)), i_last), a.ni, a.Io, a.sci);
+      ia = __builtin_amdgcn_readlane(li_lane.i0, 0);
+      ib = __builtin_amdgcn_readlane(li_lane.i1, TI - 1);
+    }
+  }
+
+  // Bricks the planner could not stage (box beyond the LDS budget, non-finite geometry) and — never on the planned road,
+  // whose gate asks for control cells at least a brick wide — bricks over more than three control planes: per-voxel
+  // evaluation of the exact chain, global gathers.
+  if (kind == kDescSlow || (elastic && ib - ia > 2)) {
+    if (kind == kDescStaged) { tile_dma_wait(); }  // (the box was requested: let it land before the block ends)
+    ExactChainArgs ea;
+    ea.ni = a.ni; ea.nj = a.nj; ea.nk = a.nk; ea.Io = a.Io; ea.unit_spacing = a.unit_spacing; ea.affine_first = a.affine_first;
+    ea.scale_i = a.sci;
+#pragma unroll
+    for (int e = 0; e < 3; e++) { ea.sp[e] = a.sp[e]; ea.rsp[e] = a.rsp[e]; ea.den[e] = a.den[e]; ea.rden[e] = a.rden[e]; }
+    ea.size_m1[0] = hx; ea.size_m1[1] = hy; ea.size_m1[2] = hz;
+    if (col_active) {
+      for (int t = i_begin; t < i_begin + i_count; t++) {
+        float x, y, z;
+        exact_voxel_coords<ELASTIC_POSSIBLE>(ea, m, elastic, cp, lj, lk, t, cj, ck, x, y, z);
+        const float val = lean_exact_gather(in_chan, a.J, a.K, x, y, z, has_fill, fillv, hx, hy, hz);
+        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
+        kmin = min(kmin, float_to_key(val));
+      }
+    }
+    if (track) publish_min();
+    return;
+  }
+
+  // ---- phase A: the reference's coordinates of this column's 16 planes, between the DMA instructions ------------------
+  if (a.interleave == 2 && bx.interior) {  // A/B (TIO_LEAN_INTERLEAVE=2): the box first, the control points behind it
+    while (dma.left > 0) dma.template issue<true>(lane);
+  }
+  CtlPlanes P{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (ELASTIC_POSSIBLE) {
+    if (elastic) {  // <= 3 control planes under the brick, lerped along J and K once per column (36 control values, cache resident)
+      const int s_i = a.nj * a.nk * 3, s_j = a.nk * 3;
+      float pl[3];
+      cp_plane(cp, ia, s_i, s_j, lj, lk, pl);
+      P.a_i = pl[0]; P.a_j = pl[1]; P.a_k = pl[2];
+      if (ib - ia >= 1) { cp_plane(cp, ia + 1, s_i, s_j, lj, lk, pl); P.b_i = pl[0]; P.b_j = pl[1]; P.b_k = pl[2]; }
+      if (ib - ia >= 2) { cp_plane(cp, ia + 2, s_i, s_j, lj, lk, pl); P.c_i = pl[0]; P.c_j = pl[1]; P.c_k = pl[2]; }
+    }
+  }
+  // a box that sticks out of the volume: per-row checks and zeroed chunks — all of it now, nothing interleaved (behind the
+  // control-point loads: a wave's vector-memory operations return in order, and phase A needs the control planes first)
+  if (!bx.interior) {
+    while (dma.left > 0) dma.template issue<false>(lane);
+  }
+  if (!a.interleave) {  // A/B (TIO_LEAN_INTERLEAVE=0): the whole box requested before the first coordinate is formed
+    while (dma.left > 0) dma.template issue<true>(lane);
+  }
+  float X[TI], Y[TI], Z[TI];
+  const bool ident = (m[0] == 1.0f) & (m[1] == 0.0f) & (m[2] == 0.0f) & (m[3] == 0.0f) & (m[4] == 0.0f) & (m[5] == 1.0f) &
+                     (m[6] == 0.0f) & (m[7] == 0.0f) & (m[8] == 0.0f) & (m[9] == 0.0f) & (m[10] == 1.0f) & (m[11] == 0.0f);
+  // (the launch gate guarantees short_div, and unit spacing whenever control points are present)
+  bool done = false;
+  if constexpr (ELASTIC_POSSIBLE) {
+    if (elastic) {
+      if (ident) lean_exact_planes<1, true, true, true, NW>(m, a, i_begin, i_last, cj, ck, li_lane, ia, P, dma, lane, X, Y, Z);
+      else if (a.affine_first) lean_exact_planes<2, true, true, true, NW>(m, a, i_begin, i_last, cj, ck, li_lane, ia, P, dma, lane, X, Y, Z);
+      else lean_exact_planes<3, true, true, true, NW>(m, a, i_begin, i_last, cj, ck, li_lane, ia, P, dma, lane, X, Y, Z);
+      done = true;
+    }
+  }
+  if (!done) lean_exact_planes<0, true, true, true, NW>(m, a, i_begin, i_last, cj, ck, li_lane, ia, P, dma, lane, X, Y, Z);
+  while (dma.left > 0) dma.template issue<true>(lane);  // (interior boxes with more instructions per wave than planes)
+
+  TileAddr ta;
+  ta.ox = static_cast<float>(bx.bx0); ta.oy = static_cast<float>(bx.by0); ta.oz = static_cast<float>(bx.za);
+  ta.sYb = bx.cpr * 16; ta.sXb = bx.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
+  ta.sYbf = static_cast<float>(ta.sYb); ta.sXbf = static_cast<float>(ta.sXb);
+  ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
+
+  tile_dma_wait();
+  __syncthreads();
+
+  // ---- phase B: sample.  The fill rule only matters where a tap can leave the volume: interior boxes never, the others
+  // group by group and wave by wave (the masked code runs only in waves one of whose four voxels has a tap outside)
+  char* out_t = out_chan + static_cast<int64_t>(i_begin) * slab_b;
+  const bool may_leave = has_fill & !bx.interior;  // block uniform
+#define TIO_LE_COORDS4                                                          \
+  const float x4[4] = {X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]};     \
+  const float y4[4] = {Y[4 * q], Y[4 * q + 1], Y[4 * q + 2], Y[4 * q + 3]};     \
+  const float z4[4] = {Z[4 * q], Z[4 * q + 1], Z[4 * q + 2], Z[4 * q + 3]};
+#define TIO_LE_GROUPS(TRACK)                                                                                                              \
+  _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                                         \
+    TIO_LE_COORDS4                                                                                                                        \
+    bool masked = false;                                                                                                                  \
+    if (may_leave) masked = __builtin_amdgcn_ballot_w64(lean_exact_group_leaves(x4, y4, z4, hx, hy, hz)) != 0ull;                         \
+    if (masked)                                                                                                                           \
+      lean_exact_group<EXACT_LERP, true, false, TRACK>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, true, fillv, kmin);   \
+    else                                                                                                                                  \
+      lean_exact_group<EXACT_LERP, false, false, TRACK>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, false, fillv, kmin); \
+  }
+  // partial bricks (a volume edge that is not a multiple of 16: rare): one copy, predicated stores, the mask wherever the image has a fill rule
+#define TIO_LE_GROUPS_GUARDED(TRACK)                                                                                                      \
+  _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                                         \
+    TIO_LE_COORDS4                                                                                                                        \
+    lean_exact_group<EXACT_LERP, true, true, TRACK>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, has_fill, fillv, kmin); \
+  }
+  if (FOLD_MIN && track) {
+    if (full) { TIO_LE_GROUPS(true) } else { TIO_LE_GROUPS_GUARDED(true) }
+    publish_min();
+  } else {
+    if (full) { TIO_LE_GROUPS(false) } else { TIO_LE_GROUPS_GUARDED(false) }
+  }
+#undef TIO_LE_GROUPS_GUARDED
+#undef TIO_LE_COORDS4
+#undef TIO_LE_GROUPS
+}
+
+}  // namespace tio

@@ -857,7 +857,9 @@ __global__ __launch_bounds__(TJ* TK, (TJ * TK) / 256 * OCC) void resample_tile_k
     typedef __attribute__((address_space(4))) const int* const_int_ptr;
     const_int_ptr d = (const_int_ptr)(plan + a.B * 16) + static_cast<size_t>(tile) * kDescInts;
     const int kw = d[0];
-    if ((kw & 0xFF) == kDescStaged) {
+    // (a plan made AHEAD — tio_resample3d_plan — may have been sized for another road's LDS budget; `fits` is this
+    // kernel's own decision, taken against ITS tile: a box beyond it takes the in-kernel road below like any unplanned brick)
+    if ((kw & 0xFF) == kDescStaged && static_cast<int64_t>(d[4]) * d[5] * (d[6] * 4) <= static_cast<int64_t>(a.tile_cap)) {
       box_full.bx0 = d[1]; box_full.by0 = d[2]; box_full.za = d[3];
       box_full.Lx = d[4]; box_full.Ly = d[5]; box_full.Lz = d[6] * 4;
       box_full.bx1 = box_full.bx0 + box_full.Lx - 1; box_full.by1 = box_full.by0 + box_full.Ly - 1;

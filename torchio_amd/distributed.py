@@ -90,13 +90,19 @@ _BUDGET_CACHE: dict = {}
 
 
 def cached_host_thread_budget() -> int:
-    """``host_thread_budget()`` remembered per (LOCAL_WORLD_SIZE, affinity change counter): the hot path asks once per Noise call,
-    and reading a 256-CPU affinity mask costs tens of microseconds.  ``pin_host_threads`` invalidates it."""
+    """``host_thread_budget()`` remembered per LOCAL_WORLD_SIZE: the hot path asks once per Noise call, and reading a 256-CPU
+    affinity mask costs tens of microseconds.  ``pin_host_threads`` invalidates it; an affinity change made by anybody else
+    (``taskset`` on a running process, ``os.sched_setaffinity`` elsewhere) is NOT seen until then — call
+    ``invalidate_host_thread_budget()`` after one."""
     key = os.environ.get("LOCAL_WORLD_SIZE", "1")
     value = _BUDGET_CACHE.get(key)
     if value is None:
         value = _BUDGET_CACHE[key] = host_thread_budget()
     return value
+
+
+def invalidate_host_thread_budget() -> None:
+    _BUDGET_CACHE.clear()
 
 
 def _gpu_local_cpus(index: int) -> list[int] | None:

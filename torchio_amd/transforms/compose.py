@@ -75,6 +75,10 @@ class Compose(Transform):
                     batch = transform._apply_drawn(batch, params)
             finally:
                 ops.expect_minimum_fill(False)
+                for transform, params in applying:  # (what a child prepared ahead and nobody collected — a child before it raised)
+                    abandon = getattr(transform, "_abandon_prefetch", None)
+                    if abandon is not None:
+                        abandon(params)
             return unwrap(batch)
         for transform in self.transforms:
             # Children apply without copying: the container copied the input once (compose.py:18-35).  For a child whose

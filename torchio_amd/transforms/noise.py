@@ -106,7 +106,13 @@ class Noise(IntensityTransform):
             return  # (another dtype is converted first: its draw keeps the count, but stay on the simple road)
         stream = ops.HostNormalStream(params["seed"])
         stream.prefetch_plan(first.numel(), first.device)
-        _STREAMS_AHEAD[id(params)] = stream
+        # (the entry holds the parameters object itself — its id cannot be reused while the entry lives — and the seed
+        # it was started for; `_abandon_prefetch`, called by Compose whatever happens to the children in between, drops an
+        # entry nobody collected: no stale stream, running job or pinned buffer outlives a failed step)
+        _STREAMS_AHEAD[id(params)] = (params, int(params["seed"]), stream)
+
+    def _abandon_prefetch(self, params: dict[str, Any]) -> None:
+        _STREAMS_AHEAD.pop(id(params), None)
 
     def apply_transform(self, batch: SubjectsBatch, params: dict[str, Any]) -> SubjectsBatch:
         mean, std, seed = params["mean"], params["std"], params["seed"]
@@ -119,7 +125,10 @@ class Noise(IntensityTransform):
         # the reference-identical stream for device-resident images: the same draws as `torch.randn(..., generator=generator)`
         # below — made on the device from the host's plan of the state chain, or on all host cores (ops.HostNormalStream);
         # one stream object = the one generator of this call
-        stream = _STREAMS_AHEAD.pop(id(params), None)  # (started by `_prefetch`: its first plan is being computed, or done)
+        stream = None
+        ahead = _STREAMS_AHEAD.pop(id(params), None)  # (started by `_prefetch`: its first plan is being computed, or done)
+        if ahead is not None and ahead[0] is params and ahead[1] == int(seed):
+            stream = ahead[2]
         if stream is None and _reference_stream_images(self, batch) is not None:
             stream = ops.HostNormalStream(seed)
         for index, img_batch in enumerate(images.values()):
