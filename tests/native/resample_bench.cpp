@@ -183,7 +183,9 @@ static const Paths kPaths[] = {
     // (TIO_LEAN_INTERLEAVE=0, A/B of the interleaved DMA issue)
     {"lean-exact", "tile", "0", 0, "planned", "lean-exact"}, {"tight", "tile", "0", 2, "planned", "0"},
     {"lean-exact-seq", "tile", "0", 0, "planned", "lean-exact-seq"}, {"tight-seq", "tile", "0", 2, "planned", "seq"},
-    {"tight-dma1st", "tile", "0", 2, "planned", "dmafirst"}};
+    {"tight-dma1st", "tile", "0", 2, "planned", "dmafirst"},
+    // the persistent double-buffered form (resample_lean_persist.hpp; affine launches): one block of 1 024 threads per CU
+    {"lean-exact-pdb", "tile", "0", 0, "planned", "lean-exact-pdb"}, {"tight-pdb", "tile", "0", 2, "planned", "pdb"}};
 
 // --ablate 64: the lean kernel overwrites the first output row of every brick with its block's shader-clock stamps
 // (resample_fast.hpp); medians of the phases, and how many blocks of a CU were alive together
@@ -342,6 +344,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     const std::string mix = kPaths[p].v2 ? kPaths[p].v2 : "";
     setenv("TIO_PLANNED_LEAN", mix == "nolean" ? "0" : "1", 1);
     setenv("TIO_EXACT_LEAN", mix.rfind("lean-exact", 0) == 0 ? "2" : "0", 1);  // the older exact paths stay on the brick kernel
+    setenv("TIO_LEAN_PERSIST", (mix == "pdb" || mix == "lean-exact-pdb") ? "1" : "0", 1);
     setenv("TIO_LEAN_INTERLEAVE", (mix == "seq" || mix == "lean-exact-seq") ? "0" : (mix == "dmafirst" ? "2" : "1"), 1);
     setenv("TIO_NEAREST_KERNEL", p == 0 ? "0" : "1", 1);  // the baseline keeps nearest images on the gather kernel's exact chain
     tio_reload_env();  // (the library parses its switches once per process otherwise)

@@ -253,12 +253,15 @@ def test_philox_stream_and_fast_noise(oracle, hip):
     n = 4 * 1000 + 3
     cpu = oracle.philox_normal((n,), 1234567890123, 0, "cpu")
     gpu = hip.philox_normal((n,), 1234567890123, 0, DEV)
-    torch.testing.assert_close(gpu.cpu(), cpu, rtol=0, atol=2e-5)
+    # (round 5: sin / cos by the same IEEE polynomial on both sides — what is left is the radius: hardware log2 / sqrt vs libm)
+    torch.testing.assert_close(gpu.cpu(), cpu, rtol=4e-7, atol=1e-7)
     big = hip.philox_normal((1 << 22,), 42, 1, DEV)
+    wide = oracle.philox_normal((1 << 22,), 42, 1, "cpu")
+    assert float((big.cpu() - wide).abs().max()) <= 2e-6 and float(((big.cpu() - wide).abs() / wide.abs().clamp_min(1.0)).max()) <= 5e-7
     assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1.0) < 3e-3
     data = _data((2, 1, 8, 8, 64), torch.float32, 22)
     cpu, gpu = _both(oracle, hip, "add_noise", (data, 0.0, 0.25), philox_seed=99)
-    torch.testing.assert_close(gpu.cpu(), cpu, rtol=0, atol=1e-5)
+    torch.testing.assert_close(gpu.cpu(), cpu, rtol=0, atol=1e-6)
     z = hip.philox_normal(data.shape, 99, 0, DEV)
     torch.testing.assert_close(gpu, data.to(DEV) + 0.25 * z, rtol=0, atol=1e-6)
 

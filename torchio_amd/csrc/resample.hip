@@ -605,6 +605,7 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 #include "resample_tile.hpp"
 #include "resample_fast.hpp"
 #include "resample_lean_exact.hpp"
+#include "resample_lean_persist.hpp"
 #include "resample_nearest.hpp"
 
 // Device scratch for the brick plan of a planned launch (resample_fast.hpp): one buffer per (device, stream), grown on
@@ -627,6 +628,19 @@ struct PlanLease {
   int* ptr = nullptr;
 };
 }  // namespace
+
+// blocks of a persistent launch: one per CU of the current device, a multiple of 8 (the XCDs; resample_lean_persist.hpp)
+static int persist_blocks() {
+  static int cached[64] = {0};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return 0;
+  if (cached[device] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+    cached[device] = cus >= 8 ? cus / 8 * 8 : -1;
+  }
+  return cached[device] > 0 ? cached[device] : 0;
+}
 
 static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
   static std::mutex registry_mu;
@@ -964,6 +978,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         // floats keep three blocks resident, 13 568 drop to two — profiles/r04_tile_cap.log); 300 floats more than the round-3
         // value, which is 1.5 % of a fused affine + elastic launch (fewer bricks on the per-voxel road)
         int cap_p = (kLdsFloatsPerCU / kTileBlocksPerCU) / 320 * 320;
+        // the persistent form (resample_lean_persist.hpp): ONE block of 1 024 threads per CU, three tiles of the same size
+        const bool persist = lean_exact && a.cp == nullptr && env.lean_persist != 0 && persist_blocks() >= 8;
         if (env.tile_lds_floats > 0) cap_p = env.tile_lds_floats;
         if (cap_p < kTileMinCap) cap_p = kTileMinCap;
         if (cap_p > kLdsFloatsPerCU) cap_p = kLdsFloatsPerCU;
@@ -1049,6 +1065,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           for (int e = 0; e < 3; e++) { la.sp[e] = a.sp[e]; la.rsp[e] = a.rsp[e]; la.den[e] = a.den[e]; la.rden[e] = a.rden[e]; }
           for (int e = 0; e < 3; e++) { la.dh[e] = a.dh[e]; la.rdh[e] = a.rdh[e]; la.half_h[e] = a.half_h[e]; }
           la.interleave = env.lean_interleave;
+          la.tile_floats = cap_p;
           auto kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3> : resample_planned_lean_kernel<false, 16, 16, 16, 3>;
           if (lean_exact) {  // the reference's coordinates; `tight`: fused lerps, else ATen's order (bit-identical to the brick kernel)
             if (tight) {
@@ -1062,9 +1079,17 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, true>;
           else if (min_channels > 0)  // the folded minimum: the instantiation whose element-0 bricks track what they store
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, false, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, false, true>;
-          if (lds_p > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_p)) != hipSuccess)
-            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_p);
+          size_t lds_launch = lds_p;
+          unsigned grid_launch = static_cast<unsigned>(n_items), block_launch = 256;
+          if (persist) {
+            if (tight) kernel = min_channels > 0 ? resample_lean_exact_persistent_kernel<false, true> : resample_lean_exact_persistent_kernel<false, false>;
+            else kernel = min_channels > 0 ? resample_lean_exact_persistent_kernel<true, true> : resample_lean_exact_persistent_kernel<true, false>;
+            lds_launch = 3 * lds_p;
+            grid_launch = static_cast<unsigned>(persist_blocks()); block_launch = 1024;
+          }
+          if (lds_launch > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      static_cast<int>(lds_launch)) != hipSuccess)
+            return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_launch);
           // one plan, one launch per channel of every image (the geometry, hence the plan, is shared)
           for (int i = 0; i < a.n_images; i++) {
             const ImgArgs& g = a.img[i];
@@ -1075,7 +1100,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
               la.out = static_cast<float*>(g.out) + static_cast<int64_t>(c) * n_out;
               la.fill = g.fill != nullptr ? g.fill + c : nullptr;
               la.min_keys = (min_channels > 0 && g.min_keys != nullptr) ? g.min_keys + c * kMinSlots : nullptr;
-              hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_items)), dim3(256), lds_p, s, la);
+              hipLaunchKernelGGL(kernel, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
             }
           }
           if (min_channels > 0)

@@ -846,6 +846,7 @@ struct LeanArgs {
   // interleaved DMA issue
   float dh[3], rdh[3], half_h[3];
   int interleave;
+  int tile_floats;  // floats of ONE staging tile of this launch (the planner's tile_cap)
   // the folded minimum (tio_resample_image.out_min_dev): kMinSlots keys of this channel, or nullptr.  Only the bricks of batch
   // element 0 track what they store (a block-uniform branch into the TRACK instantiation of the sampling loop).
   uint32_t* min_keys;

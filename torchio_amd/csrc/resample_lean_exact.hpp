@@ -217,16 +217,13 @@ __device__ __forceinline__ float lean_exact_gather(const float* __restrict__ cha
   return val;
 }
 
-// Four planes [4 q, 4 q + 4) of this thread's column from the staged box.  MASKED: a tap of this wave's group can leave the
-// volume and the image has a fill rule — the in-bounds weight on ATen's weights in ATen's order (tile_mask).
-// GUARD: a partial brick (stores predicated).  TRACK: the folded minimum of batch element 0.
-template <bool EXACT_LERP, bool MASKED, bool GUARD, bool TRACK>
-__device__ __forceinline__ void lean_exact_group(const float (&X4)[4], const float (&Y4)[4], const float (&Z4)[4], const TileAddr& ta, char*& out_generic,
-                                                 unsigned urow, int64_t slab_b, int t0, int i_count, bool col_active, float hx, float hy,
-                                                 float hz, bool has_fill, float fillv, uint32_t& kmin) {
-  typedef __attribute__((address_space(1))) char* global_char_ptr;   // (typed global: a flat store would count on lgkmcnt too —
-  typedef __attribute__((address_space(1))) float* global_float_ptr;  //  resample_fast.hpp: fast_sample_run)
-  global_char_ptr out_t = (global_char_ptr)out_generic;
+// Four planes of this thread's column from the staged box: the VALUES (taps in flight for all four before the first
+// interpolation starts).  MASKED: a tap of this wave's group can leave the volume and the image has a fill rule — the
+// in-bounds weight on ATen's weights in ATen's order (tile_mask); `has_fill` false (partial bricks reuse the masked code
+// for images without a fill rule): the sample stands.
+template <bool EXACT_LERP, bool MASKED>
+__device__ __forceinline__ void lean_exact_group_values(const float (&X4)[4], const float (&Y4)[4], const float (&Z4)[4], const TileAddr& ta, float hx,
+                                                        float hy, float hz, bool has_fill, float fillv, float (&vals)[4]) {
   TapSet ts[4];
 #pragma unroll
   for (int u = 0; u < 4; u++) tile_issue_interior<false>(ts[u], X4[u], Y4[u], Z4[u], ta, 0);
@@ -235,15 +232,37 @@ __device__ __forceinline__ void lean_exact_group(const float (&X4)[4], const flo
   for (int u = 0; u < 4; u++) {
     float val = EXACT_LERP ? tile_finish(ts[u]) : tile_finish_fast(ts[u]);
     if constexpr (MASKED) val = (!has_fill || tile_mask(ts[u], X4[u], Y4[u], Z4[u], hx, hy, hz) > 0.5f) ? val : fillv;
+    vals[u] = val;
+  }
+}
+
+// ... and their stores.  GUARD: a partial brick (stores predicated).  TRACK: the folded minimum of batch element 0.
+template <bool GUARD, bool TRACK>
+__device__ __forceinline__ void lean_exact_group_store(const float (&vals)[4], char*& out_generic, unsigned urow, int64_t slab_b, int t0, int i_count,
+                                                       bool col_active, uint32_t& kmin) {
+  typedef __attribute__((address_space(1))) char* global_char_ptr;   // (typed global: a flat store would count on lgkmcnt too —
+  typedef __attribute__((address_space(1))) float* global_float_ptr;  //  resample_fast.hpp: fast_sample_run)
+  global_char_ptr out_t = (global_char_ptr)out_generic;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
     const bool live = !GUARD || (col_active && (t0 + u) < i_count);
     if (live) {
-      *(global_float_ptr)(out_t + urow) = val;
-      if constexpr (TRACK) kmin = min(kmin, float_to_key(val));
+      *(global_float_ptr)(out_t + urow) = vals[u];
+      if constexpr (TRACK) kmin = min(kmin, float_to_key(vals[u]));
     }
     out_t += slab_b;
     asm volatile("" : "+s"(out_t));  // one running pointer (2 scalar adds per plane)
   }
   out_generic = (char*)out_t;
+}
+
+template <bool EXACT_LERP, bool MASKED, bool GUARD, bool TRACK>
+__device__ __forceinline__ void lean_exact_group(const float (&X4)[4], const float (&Y4)[4], const float (&Z4)[4], const TileAddr& ta, char*& out_generic,
+                                                 unsigned urow, int64_t slab_b, int t0, int i_count, bool col_active, float hx, float hy,
+                                                 float hz, bool has_fill, float fillv, uint32_t& kmin) {
+  float vals[4];
+  lean_exact_group_values<EXACT_LERP, MASKED>(X4, Y4, Z4, ta, hx, hy, hz, has_fill, fillv, vals);
+  lean_exact_group_store<GUARD, TRACK>(vals, out_generic, urow, slab_b, t0, i_count, col_active, kmin);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -293,7 +312,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   const float* in_chan = a.in + static_cast<int64_t>(b) * a.in_stride;
   char* out_chan = reinterpret_cast<char*>(a.out + static_cast<int64_t>(b) * a.out_stride);
 
-  const int kind = kind_w & 0xFF;
+  int kind = kind_w & 0xFF;
+  // (a plan made AHEAD may have been sized for another road's tile: a box beyond THIS launch's tile takes the per-voxel road)
+  if (kind == kDescStaged && static_cast<int64_t>(bx.Lx) * bx.Ly * (bx.cpr * 4) > static_cast<int64_t>(a.tile_floats)) kind = kDescSlow;
   bx.kind = kind; bx.interior = kind_w >> 8;
   BoxDmaStepper<NW> dma;
   dma.left = 0;
