@@ -182,6 +182,11 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
       dk = lerp2(pa_k, l0, pb_k, l1);
     }
     lean_exact_coord<MODE, UNIT, SHORT>(m, a, ci, cj, ck, di, dj, dk, X[t], Y[t], Z[t]);
+    if constexpr (INTERLEAVE) {
+      // pin the plane HERE: the optimiser sinks the (pure) chain of all 16 planes behind the last DMA instruction otherwise —
+      // the first build of this kernel "interleaved" nothing (its assembly: 16 DMA blocks back to back, then 16 planes)
+      asm volatile("" : "+v"(X[t]), "+v"(Y[t]), "+v"(Z[t])::"memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }

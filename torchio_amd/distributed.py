@@ -73,6 +73,29 @@ def _usable_cpus() -> list[int]:
         return list(range(os.cpu_count() or 1))
 
 
+def _core_groups(cpus: list[int]) -> list[list[int]]:
+    """*cpus* grouped by PHYSICAL core (sysfs ``thread_siblings_list``), cores in the order of their first logical CPU.  Without
+    sysfs every CPU is its own core."""
+    allowed, seen, groups = set(cpus), set(), []
+    for cpu in cpus:
+        if cpu in seen:
+            continue
+        siblings = [cpu]
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as handle:
+                text = handle.read().strip()
+            found: list[int] = []
+            for part in text.split(","):
+                lo, _, hi = part.partition("-")
+                found.extend(range(int(lo), int(hi or lo) + 1))
+            siblings = [c for c in found if c in allowed] or [cpu]
+        except (OSError, ValueError):
+            pass
+        seen.update(siblings)
+        groups.append(siblings)
+    return groups
+
+
 def host_thread_budget(cap: int = 32) -> int:
     """Host threads ONE rank may keep busy (the mt19937 jump-ahead workers of the reference-identical noise stream,
     ``csrc/host_rng*.cpp``): the CPUs this process may run on, minus one per rank for its Python enqueue thread, divided by
@@ -80,9 +103,16 @@ def host_thread_budget(cap: int = 32) -> int:
     One rank on a 128-core host: 32.  Eight ranks: (128 - 8) / 8 = 15 each — 120 workers + 8 enqueue threads on 128 cores
     instead of the 256 + 8 the per-process default asked for (VERDICT r3 weak #8)."""
     ranks = local_world_size()
-    cpus, host = len(_usable_cpus()), os.cpu_count() or 1
-    if ranks > 1 and cpus >= host:  # not pinned: an even share of the host (pinned: the mask already is this rank's share)
-        cpus = host // ranks
+    usable = _usable_cpus()
+    cpus, host = len(usable), os.cpu_count() or 1
+    if ranks > 1:
+        # Round 5 (scripts/host_stress_ranks.py on the MI355X box's 128-core / 256-thread host): with one worker per LOGICAL CPU
+        # of a rank's share the plan of the noise stream took 6.4 - 7.3 ms per step under eight ranks against 1.1 ms alone — two
+        # compute-bound workers per physical core, and cores shared between ranks.  Workers are counted in PHYSICAL cores.
+        cores = len(_core_groups(usable))
+        if cpus >= host:  # not pinned: an even share of the host (pinned: the mask already is this rank's share)
+            cores = cores // ranks
+        return max(1, min(cap, cores - 1))
     return max(1, min(cap, cpus - 1))
 
 
@@ -126,16 +156,19 @@ def _gpu_local_cpus(index: int) -> list[int] | None:
 def plan_host_cpus(local_rank: int, n_local: int, usable: list[int], gpu_cpus: list[list[int] | None]) -> list[int]:
     """The CPUs rank *local_rank* of *n_local* should run on: the ranks whose GPUs share a NUMA node split that node's
     CPUs evenly (in rank order); a rank whose GPU reports no node — or an empty share — gets an even slice of *usable*."""
-    even = len(usable) // max(n_local, 1)
-    fallback = usable[local_rank * even : (local_rank + 1) * even] if even > 0 else usable
+    # (the even slice is made of whole PHYSICAL cores: logical CPUs n and n + cores are siblings on the usual numbering, and a plain
+    # slice of the sorted ids gave every core to two ranks)
+    cores = _core_groups(usable)
+    even = len(cores) // max(n_local, 1)
+    fallback = [c for group in cores[local_rank * even : (local_rank + 1) * even] for c in group] if even > 0 else usable
     mine = gpu_cpus[local_rank] if local_rank < len(gpu_cpus) else None
     if not mine:
         return fallback or usable
-    node = [c for c in mine if c in set(usable)]
+    node = _core_groups([c for c in mine if c in set(usable)])  # whole physical cores, as above
     sharers = [r for r in range(n_local) if r < len(gpu_cpus) and gpu_cpus[r] == mine]
     share = len(node) // max(len(sharers), 1)
     position = sharers.index(local_rank)
-    chosen = node[position * share : (position + 1) * share]
+    chosen = [c for group in node[position * share : (position + 1) * share] for c in group]
     return chosen or fallback or usable
 
 
@@ -148,6 +181,8 @@ def pin_host_threads(info: RankInfo | None = None) -> list[int] | None:
         return None
     usable = _usable_cpus()
     gpu_cpus = [_gpu_local_cpus(r) for r in range(n_local)] if torch.cuda.is_available() else [None] * n_local
+    if any(c is None for c in gpu_cpus):  # a topology that is known for some ranks only: even slices for everybody (no overlap)
+        gpu_cpus = [None] * n_local
     cpus = plan_host_cpus(info.local_rank, n_local, usable, gpu_cpus)
     try:
         os.sched_setaffinity(0, cpus)
