@@ -39,7 +39,7 @@ ops.h2d = lambda tensor, device: tensor
 from torchio_amd.transforms import spatial as _sp
 _sp._folding_grid_spacing = lambda extent, mesh: float("inf")  # (16^3 stand-in volumes: the 256^3 bench never trips the folding warning)
 tio.set_noise_rng("philox")
-tio.set_resample_precision("fast")
+tio.set_resample_precision("tight")
 transform = bench.build_transform()
 batch = bench.make_batch(16, 8, 0, "cpu")
 for _ in range(200):

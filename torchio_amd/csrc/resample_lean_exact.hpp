@@ -143,7 +143,7 @@ struct CtlPlanes {
 //   per plane: read back as scalars)
 template <int MODE, bool UNIT, bool SHORT, bool INTERLEAVE, int NW>
 __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const LeanArgs& a, int i0, int i_last, float cj, float ck,
-                                                  const Lerp1D& li_lane, int ia, const CtlPlanes& P, BoxDmaStepper<NW>& dma, int lane,
+                                                  const Lerp1D& li_lane, int ia, const CtlPlanes P, BoxDmaStepper<NW>& dma, int lane,
                                                   float (&X)[16], float (&Y)[16], float (&Z)[16]) {
   float pa_i = 0.f, pa_j = 0.f, pa_k = 0.f, pb_i = 0.f, pb_j = 0.f, pb_k = 0.f;
   int cur0 = -1, cur1 = -1;
@@ -165,16 +165,20 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
       const int e1 = __builtin_amdgcn_readlane(li_lane.i1, t) - ia;
       const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l0), t));
       const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l1), t));
+      // (ONE rarely taken scalar branch per operand plane, branch-free selects inside: the nested if / else form compiled into
+      // ~45 scalar instructions per plane — and a CU has one scalar unit for its twelve resident waves)
       if (e0 != cur0) {
-        if (e0 == 0) { pa_i = P.a_i; pa_j = P.a_j; pa_k = P.a_k; }
-        else if (e0 == 1) { pa_i = P.b_i; pa_j = P.b_j; pa_k = P.b_k; }
-        else { pa_i = P.c_i; pa_j = P.c_j; pa_k = P.c_k; }
+        const bool z0 = e0 == 0, z1 = e0 == 1;
+        pa_i = z0 ? P.a_i : (z1 ? P.b_i : P.c_i);
+        pa_j = z0 ? P.a_j : (z1 ? P.b_j : P.c_j);
+        pa_k = z0 ? P.a_k : (z1 ? P.b_k : P.c_k);
         cur0 = e0;
       }
       if (e1 != cur1) {
-        if (e1 == 0) { pb_i = P.a_i; pb_j = P.a_j; pb_k = P.a_k; }
-        else if (e1 == 1) { pb_i = P.b_i; pb_j = P.b_j; pb_k = P.b_k; }
-        else { pb_i = P.c_i; pb_j = P.c_j; pb_k = P.c_k; }
+        const bool z0 = e1 == 0, z1 = e1 == 1;
+        pb_i = z0 ? P.a_i : (z1 ? P.b_i : P.c_i);
+        pb_j = z0 ? P.a_j : (z1 ? P.b_j : P.c_j);
+        pb_k = z0 ? P.a_k : (z1 ? P.b_k : P.c_k);
         cur1 = e1;
       }
       di = lerp2(pa_i, l0, pb_i, l1);
@@ -407,12 +411,18 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   CtlPlanes P{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if constexpr (ELASTIC_POSSIBLE) {
     if (elastic) {  // <= 3 control planes under the brick, lerped along J and K once per column (36 control values, cache resident)
+      // (all three planes UNCONDITIONALLY — a plane beyond the last one the brick touches is clamped and never selected — and
+      // every member passed through an empty asm: members written under a branch keep the struct in memory, and the optimiser
+      // then turns the selects of phase A into a dynamically indexed load of that stack object: 40 bytes of scratch per lane)
       const int s_i = a.nj * a.nk * 3, s_j = a.nk * 3;
-      float pl[3];
-      cp_plane(cp, ia, s_i, s_j, lj, lk, pl);
-      P.a_i = pl[0]; P.a_j = pl[1]; P.a_k = pl[2];
-      if (ib - ia >= 1) { cp_plane(cp, ia + 1, s_i, s_j, lj, lk, pl); P.b_i = pl[0]; P.b_j = pl[1]; P.b_k = pl[2]; }
-      if (ib - ia >= 2) { cp_plane(cp, ia + 2, s_i, s_j, lj, lk, pl); P.c_i = pl[0]; P.c_j = pl[1]; P.c_k = pl[2]; }
+      float pa[3], pb[3], pc[3];
+      cp_plane(cp, ia, s_i, s_j, lj, lk, pa);
+      cp_plane(cp, min(ia + 1, a.ni - 1), s_i, s_j, lj, lk, pb);
+      cp_plane(cp, min(ia + 2, a.ni - 1), s_i, s_j, lj, lk, pc);
+      P.a_i = pa[0]; P.a_j = pa[1]; P.a_k = pa[2];
+      P.b_i = pb[0]; P.b_j = pb[1]; P.b_k = pb[2];
+      P.c_i = pc[0]; P.c_j = pc[1]; P.c_k = pc[2];
+      asm volatile("" : "+v"(P.a_i), "+v"(P.a_j), "+v"(P.a_k), "+v"(P.b_i), "+v"(P.b_j), "+v"(P.b_k), "+v"(P.c_i), "+v"(P.c_j), "+v"(P.c_k));
     }
   }
   // a box that sticks out of the volume: per-row checks and zeroed chunks — all of it now, nothing interleaved (behind the
