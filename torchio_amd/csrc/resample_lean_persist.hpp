@@ -21,7 +21,7 @@
 // helper waves, two barriers).  What is different here: the planner (a descriptor per brick, nothing to search), the
 // constant-count wait, one barrier, and a kernel whose arithmetic is large enough to be worth hiding.
 //
-// MEASURED (round 5, 8 x 256^3 affine launch, profiles/r05_persistent_kernel.md): correct on the first run (every parity case
+// MEASURED (round 5, 8 x 256^3 affine launch, profiles/r05_resample.md): correct on the first run (every parity case
 // of tests/native/resample_bench bit for bit / inside the per-voxel bar) and SLOWER — two tiles 0.665 ms, three tiles
 // 0.705 ms against 0.424 - 0.430 for one block per brick; the exact and the tight instantiation take the same time, so it
 // is neither the interpolation's arithmetic nor (three tiles: a box has two bricks' time) the box's latency.  What its
