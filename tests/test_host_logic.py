@@ -878,3 +878,29 @@ def test_precision_and_draw_policy_switches():
         assert ops.draw_stream("cuda:0") is None  # off: the draws are made on the data stream
     finally:
         tio.set_draw_policy(policy)
+
+
+def test_rank_shares_are_whole_physical_cores(monkeypatch):
+    """Round 5 (scripts/host_stress_ranks.py on the MI355X host): a rank's CPU share is made of WHOLE physical cores — with the
+    usual numbering (logical CPU n and n + cores are siblings) a plain slice of the sorted ids gave every core to two ranks —
+    and its worker budget is counted in physical cores."""
+    from torchio_amd import distributed as tdist
+
+    cores = 16
+    usable = list(range(2 * cores))  # 16 cores x 2 threads: cpu n and n + 16 are siblings
+    monkeypatch.setattr(tdist, "_core_groups", lambda cpus: [[c, c + cores] for c in sorted(set(c % cores for c in cpus)) if c in cpus and c + cores in cpus] or [[c] for c in cpus])
+    shares = [tdist.plan_host_cpus(rank, 4, usable, [None] * 4) for rank in range(4)]
+    assert sorted(c for share in shares for c in share) == usable  # a partition of the host
+    for share in shares:
+        assert len(share) == 8 and {c % cores for c in share} == {c % cores for c in share if c < cores}  # both siblings of each core
+        assert len({c % cores for c in share}) == 4
+    # four GPUs of one NUMA node (all 32 CPUs local to each): the node is split the same way
+    node = [usable] * 4
+    numa = [tdist.plan_host_cpus(rank, 4, usable, node) for rank in range(4)]
+    assert sorted(c for share in numa for c in share) == usable
+    assert all(len({c % cores for c in share}) == 4 for share in numa)
+    # budget: physical cores of the rank's share minus the enqueue thread
+    monkeypatch.setattr(tdist, "_usable_cpus", lambda: shares[0])
+    monkeypatch.setattr(tdist, "local_world_size", lambda: 4)
+    monkeypatch.setattr(tdist.os, "cpu_count", lambda: 2 * cores)
+    assert tdist.host_thread_budget() == 3  # 4 physical cores - 1 (pinned: the mask already is this rank's share)
