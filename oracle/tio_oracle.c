@@ -22,6 +22,12 @@
  *   - grid_sampler_3d(bilinear|nearest, zeros, align_corners=True)
  *   - replication_pad3d + conv3d (cross-correlation)
  *
+ * Not the reference's: the Philox normal stream (tio_oracle_philox_normal, the philox road of tio_oracle_add_noise and
+ * tio_oracle_blur_fused) — the engine's own throughput-mode generator, defined HERE and in csrc/intensity.hip by the same
+ * arithmetic (Philox4x32-10, Box-Muller with sin / cos of 2 pi u as an IEEE float32 polynomial, round 5) — and
+ * geom.precision: this file always computes the reference's sequence (TIO_PRECISION_EXACT); the TIGHT and FAST modes of the
+ * engine are held to it within their stated tolerances (tests/test_gpu_tight.py, tests/test_gpu_full_size.py).
+ *
  * Build: see oracle/Makefile (gcc -O2 -fopenmp -mfma -ffp-contract=off).
  * Floating-point contraction MUST stay off: where the reference fuses
  * (BLAS FMA) this file calls fmaf() explicitly, everywhere else products and
