@@ -33,6 +33,10 @@ namespace tio {
 
 // ---- the packed LDS-DMA of one box as a STEPPER: the same instruction sequence as stream_stage_packed (resample_fast.hpp),
 // one instruction per call, so that the caller can put arithmetic between two of them ------------------------------------
+// every vector-memory AND LDS operation of this wave done (the zero chunks of BoxDmaStepper::issue<false> are LDS stores the
+// compiler does not know about)
+__device__ __forceinline__ void tile_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
 template <int NW>
 struct BoxDmaStepper {
   typedef __attribute__((address_space(1))) const char* global_byte_ptr;
@@ -84,7 +88,17 @@ struct BoxDmaStepper {
       const bool in_vol = in_box & ch_ok & (static_cast<unsigned>(bx0 + p) < static_cast<unsigned>(I)) &
                           (static_cast<unsigned>(by0 + r) < static_cast<unsigned>(J));
       if (in_vol) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
-      else if (in_box) *reinterpret_cast<float4*>(lp + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      else if (in_box) {
+        // zeros for the chunks outside the volume — as an instruction the compiler does not see: a plain LDS store here is
+        // preceded by `s_waitcnt vmcnt(0)` (it may alias an LDS-DMA in flight, for all the compiler knows), so that every DMA
+        // instruction with a lane outside the volume waited for ALL the box's earlier DMA to land — the issue phase of the
+        // third of the bricks that touch the volume's surface became a chain of memory round trips.  The chunks are disjoint
+        // from every DMA destination by construction; callers wait with tile_dma_wait_all() (lgkmcnt too) before the barrier.
+        typedef float zero4_t __attribute__((ext_vector_type(4)));
+        const zero4_t zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)(lp + 4 * lane)));
+        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(zero) : "memory");
+      }
     }
     row += step; p += step_p; r += step_r; off += step_b;
     if (r >= Ly) { r -= Ly; p += 1; off += wrap_b; }
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   // whose gate asks for control cells at least a brick wide — bricks over more than three control planes: per-voxel
   // evaluation of the exact chain, global gathers.
   if (kind == kDescSlow || (elastic && ib - ia > 2)) {
-    if (kind == kDescStaged) { tile_dma_wait(); }  // (the box was requested: let it land before the block ends)
+    if (kind == kDescStaged) { tile_dma_wait_all(); }  // (the box was requested: let it land before the block ends)
     ExactChainArgs ea;
     ea.ni = a.ni; ea.nj = a.nj; ea.nk = a.nk; ea.Io = a.Io; ea.unit_spacing = a.unit_spacing; ea.affine_first = a.affine_first;
     ea.scale_i = a.sci;
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   ta.sYbf = static_cast<float>(ta.sYb); ta.sXbf = static_cast<float>(ta.sXb);
   ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
 
-  tile_dma_wait();
+  tile_dma_wait_all();
   __syncthreads();
 
   // ---- phase B: sample.  The fill rule only matters where a tap can leave the volume: interior boxes never, the others

@@ -86,6 +86,9 @@ __device__ __forceinline__ void wait_vmcnt_at_most(int n) {
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // 0, or more than the cases above: everything
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the zero chunks of boxes that stick out of the volume are LDS stores)
+  {
+  }
 }
 
 // issue this wave's share of a brick's box into `tile`; returns the number of DMA instructions issued (wave uniform)
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(1024) void resample_lean_exact_persistent_kernel(co
 
     // ---- the next box has landed (every wave waited for its own DMA instructions) and every wave is done with this tile ----
     if (have_next) {
-      if (!waited) tile_dma_wait();  // (paths with loads / stores of their own: everything)
+      if (!waited) tile_dma_wait_all();  // (paths with loads / stores of their own: everything)
       __syncthreads();
     }
     dc = d1; d1 = d2; d2 = d3;
