@@ -308,9 +308,17 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   typedef __attribute__((address_space(4))) const float* const_float_ptr;
 
   // every argument the road to the first DMA needs, in scalar registers NOW (resample_planned_lean_kernel)
+  // (round 5: the first build of this kernel fetched mapping_batched, tile_floats, the strides and the output shape one by one,
+  // each behind its own `s_waitcnt lgkmcnt(0)` — nine scalar round trips between entry and the first DMA instruction)
   {
-    const int* plan_p = a.plan; const float* in_p = a.in; const float* map_p = a.mapping;
-    asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(map_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K));
+    const int* plan_p = a.plan; const float* in_p = a.in; const float* map_p = a.mapping; float* out_p = a.out; const float* fill_p = a.fill;
+    asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(map_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K),
+                 "s"(a.mapping_batched), "s"(a.tile_floats), "s"(a.in_stride), "s"(a.out_stride), "s"(a.Io), "s"(a.Jo), "s"(a.Ko), "s"(a.interleave),
+                 "s"(out_p), "s"(fill_p), "s"(a.hx), "s"(a.hy), "s"(a.hz), "s"(a.affine_first));
+    if constexpr (ELASTIC_POSSIBLE) {  // (what the control-point prelude reads: ten more round trips in the first build)
+      const float* cp_p = a.cp;
+      asm volatile("" ::"s"(cp_p), "s"(a.cp_batched), "s"(a.ni), "s"(a.nj), "s"(a.nk), "s"(a.sci), "s"(a.scj), "s"(a.sck));
+    }
   }
   const unsigned brick = xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items));
   const int b = static_cast<int>(fastdiv_exact(brick, a.bpe_magic, a.bricks_per_element));
@@ -321,10 +329,12 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   StreamBox bx;
   bx.bx0 = d[1]; bx.by0 = d[2]; bx.za = d[3]; bx.Lx = d[4]; bx.Ly = d[5]; bx.cpr = d[6];
   const int i_begin = d[11], j_lo = d[12], k_lo = d[13];
-  const bool elastic = ELASTIC_POSSIBLE && d[14] != 0;
+  const int elastic_w = d[14];
   float m[12];
 #pragma unroll
   for (int q = 0; q < 12; q++) m[q] = mp[q];
+  asm volatile("" ::"s"(kind_w), "s"(i_begin), "s"(j_lo), "s"(k_lo), "s"(elastic_w));  // (the whole descriptor behind ONE wait)
+  const bool elastic = ELASTIC_POSSIBLE && elastic_w != 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
