@@ -249,7 +249,7 @@ __device__ __forceinline__ void lean_exact_group_values(const float (&X4)[4], co
                                                         float hy, float hz, bool has_fill, float fillv, float (&vals)[4]) {
   TapSet ts[4];
 #pragma unroll
-  for (int u = 0; u < 4; u++) tile_issue_interior<false>(ts[u], X4[u], Y4[u], Z4[u], ta, 0);
+  for (int u = 0; u < 4; u++) tile_issue_folded(ts[u], X4[u], Y4[u], Z4[u], ta);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < 4; u++) {
@@ -266,11 +266,15 @@ __device__ __forceinline__ void lean_exact_group_store(const float (&vals)[4], c
   typedef __attribute__((address_space(1))) char* global_char_ptr;   // (typed global: a flat store would count on lgkmcnt too —
   typedef __attribute__((address_space(1))) float* global_float_ptr;  //  resample_fast.hpp: fast_sample_run)
   global_char_ptr out_t = (global_char_ptr)out_generic;
+  // (the row offset re-enters the block as a 32-bit register: instruction selection works block by block, and only a zero
+  // extension it can SEE lets the store take the `scalar base + 32-bit vector offset` form — otherwise one 64-bit vector add per store)
+  unsigned row_off = urow;
+  asm volatile("" : "+v"(row_off));
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const bool live = !GUARD || (col_active && (t0 + u) < i_count);
     if (live) {
-      *(global_float_ptr)(out_t + urow) = vals[u];
+      *(global_float_ptr)(out_t + row_off) = vals[u];
       if constexpr (TRACK) kmin = min(kmin, float_to_key(vals[u]));
     }
     out_t += slab_b;
@@ -347,7 +351,11 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
 
   int kind = kind_w & 0xFF;
   // (a plan made AHEAD may have been sized for another road's tile: a box beyond THIS launch's tile takes the per-voxel road)
-  if (kind == kDescStaged && static_cast<int64_t>(bx.Lx) * bx.Ly * (bx.cpr * 4) > static_cast<int64_t>(a.tile_floats)) kind = kDescSlow;
+  // ... and so does a box whose taps' LDS addresses cannot be formed from absolute indices in float32 (box_address_fits: a
+  // volume thousands of voxels long)
+  if (kind == kDescStaged && (static_cast<int64_t>(bx.Lx) * bx.Ly * (bx.cpr * 4) > static_cast<int64_t>(a.tile_floats) ||
+                              !box_address_fits(bx.bx0, bx.by0, bx.za, bx.Lx, bx.Ly, bx.cpr)))
+    kind = kDescSlow;
   bx.kind = kind; bx.interior = kind_w >> 8;
   BoxDmaStepper<NW> dma;
   dma.left = 0;
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   ta.sYb = bx.cpr * 16; ta.sXb = bx.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
   ta.sYbf = static_cast<float>(ta.sYb); ta.sXbf = static_cast<float>(ta.sXb);
   ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
+  ta.c_f = ta.base_f - ta.ox * ta.sXbf - ta.oy * ta.sYbf - 4.0f * ta.oz;  // (exact: box_address_fits held above)
 
   tile_dma_wait_all();
   __syncthreads();

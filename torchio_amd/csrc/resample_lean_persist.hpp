@@ -57,7 +57,8 @@ __device__ __forceinline__ BrickDesc load_brick_desc(const int* plan_bricks, uns
 // kind of a planned brick for a launch whose tiles hold `cap` floats (a plan made ahead may have been sized for another road)
 __device__ __forceinline__ int brick_kind(const BrickDesc& d, int cap) {
   const int kind = d.kind_w & 0xFF;
-  return (kind == kDescStaged && static_cast<int64_t>(d.Lx) * d.Ly * (d.cpr * 4) > static_cast<int64_t>(cap)) ? static_cast<int>(kDescSlow) : kind;
+  const bool staged_ok = static_cast<int64_t>(d.Lx) * d.Ly * (d.cpr * 4) <= static_cast<int64_t>(cap) && box_address_fits(d.bx0, d.by0, d.za, d.Lx, d.Ly, d.cpr);
+  return (kind == kDescStaged && !staged_ok) ? static_cast<int>(kDescSlow) : kind;
 }
 
 struct BrickWalk {
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(1024) void resample_lean_exact_persistent_kernel(co
         ta.sYb = dc.cpr * 16; ta.sXb = dc.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
         ta.sYbf = static_cast<float>(ta.sYb); ta.sXbf = static_cast<float>(ta.sXb);
         ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)cur)));
+        ta.c_f = ta.base_f - ta.ox * ta.sXbf - ta.oy * ta.sYbf - 4.0f * ta.oz;  // (brick_kind demotes the boxes this is not exact for)
         char* out_t = out_chan + static_cast<int64_t>(p0) * slab_b;
         const bool may_leave = has_fill & !interior;
         const int t0 = PL * pg;
