@@ -8,7 +8,7 @@ make -s -C "$ROOT/torchio_amd/csrc"
 make -s -C "$ROOT/oracle"
 mkdir -p "$HERE/_build"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 "$HERE/resample_bench.cpp" -o "$HERE/_build/resample_bench" \
-  -L"$ROOT/torchio_amd/csrc" -ltio_hip -L"$ROOT/oracle" -ltio_oracle \
+  -L"$ROOT/torchio_amd/csrc" -ltio_hip -L"$ROOT/oracle" -ltio_oracle -ldl \
   -Wl,-rpath,'$ORIGIN/../../../torchio_amd/csrc' -Wl,-rpath,'$ORIGIN/../../../oracle'
 for tool in valu_rates dpp_check lds_rates; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 "$HERE/$tool.cpp" -o "$HERE/_build/$tool"

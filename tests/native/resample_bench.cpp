@@ -10,6 +10,7 @@
 // parity : awkward shapes / dtypes / fills / flags, every path vs the CPU oracle.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +25,10 @@
 #include "../../include/tio_hip.h"
 
 extern "C" int tio_oracle_resample3d(const tio_resample_geom*, int32_t, const tio_resample_image*, void*);
+// only in libraries built with -DTIO_LE_TIMELINE (csrc/resample_lean_exact.hpp): per-phase clock sums of the exact-coordinate kernel
+// (looked up at run time: a weak reference of a non-PIC executable is settled — to null — when the executable is linked)
+typedef int (*tio_debug_le_timeline_fn)(unsigned long long* out8, int reset);
+static tio_debug_le_timeline_fn tio_debug_le_timeline = nullptr;
 
 #define HIP_CHECK(x)                                                                  \
   do {                                                                                \
@@ -363,12 +368,24 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     float ms = 0.0f;
     if (time_it) {
       for (int w = 0; w < 2; w++) tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
+      HIP_CHECK(hipDeviceSynchronize());
+      if (tio_debug_le_timeline) tio_debug_le_timeline(nullptr, 1);
       HIP_CHECK(hipEventRecord(e0, nullptr));
       for (int r = 0; r < reps; r++) tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
       HIP_CHECK(hipEventRecord(e1, nullptr));
       HIP_CHECK(hipEventSynchronize(e1));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       ms /= reps;
+      unsigned long long tl[8] = {0};
+      const int tl_status = tio_debug_le_timeline ? tio_debug_le_timeline(tl, 1) : -1;
+      if (tl_status > 0) fprintf(stderr, "tio_debug_le_timeline failed: %d\n", tl_status);
+      if (tl_status == 0 && tl[5] != 0) {
+        // a library built with -DTIO_LE_TIMELINE: the mean shader-clock ticks a block of the exact-coordinate kernel spends per phase
+        const double n = static_cast<double>(tl[5]);
+        const double total = static_cast<double>(tl[0] + tl[1] + tl[2] + tl[3] + tl[4]);
+        printf("  [timeline %s: %.0f blocks; ticks per block: entry->descriptor %.0f, ->box requested + coordinates %.0f, ->box landed %.0f, ->sampled %.0f, ->stores acknowledged %.0f; total %.0f]\n",
+               kPaths[p].name, n, tl[0] / n, tl[1] / n, tl[2] / n, tl[3] / n, tl[4] / n, total / n);
+      }
     }
     if (p != 0 && getenv("TIO_TILE_ABLATE") && (atoi(getenv("TIO_TILE_ABLATE")) & 64)) report_stamps(cs, B, n_out);
     size_t diff_first = 0, diff_oracle = 0;
@@ -464,6 +481,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--ablate") && i + 1 < argc) setenv("TIO_TILE_ABLATE", argv[++i], 1);
     else if (!strcmp(argv[i], "--lds") && i + 1 < argc) setenv("TIO_TILE_LDS_FLOATS", argv[++i], 1);
   }
+  tio_debug_le_timeline = reinterpret_cast<tio_debug_le_timeline_fn>(dlsym(RTLD_DEFAULT, "tio_debug_le_timeline"));
+  if (tio_debug_le_timeline) fprintf(stderr, "library built with TIO_LE_TIMELINE: per-phase block timeline follows the lean-exact / tight lines\n");
   if (tio_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
   int failures = 0;
   if (cases == "calib") return run_calibration();

@@ -23,6 +23,7 @@
 
 #include <mutex>
 #include <vector>
+#include <algorithm>
 
 #include "common.hpp"
 
@@ -1237,3 +1238,22 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images, c
   }
   return TIO_OK;
 }
+
+#ifdef TIO_LE_TIMELINE
+// measurement builds only (resample_lean_exact.hpp: TIO_LE_TIMELINE): the per-phase clock sums of the exact-coordinate kernel
+extern "C" __attribute__((visibility("default"))) int tio_debug_le_timeline(unsigned long long* out8, int reset) {
+  static std::vector<unsigned long long> table(tio::kTimelineSlots * 8);
+  const size_t bytes = table.size() * sizeof(unsigned long long);
+  if (out8 != nullptr) {
+    if (hipMemcpyFromSymbol(table.data(), HIP_SYMBOL(tio::g_le_timeline), bytes) != hipSuccess) return 1;
+    for (int q = 0; q < 8; q++) out8[q] = 0;
+    for (int slot = 0; slot < tio::kTimelineSlots; slot++)
+      for (int q = 0; q < 8; q++) out8[q] += table[slot * 8 + q];
+  }
+  if (reset) {
+    std::fill(table.begin(), table.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tio::g_le_timeline), table.data(), bytes) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
