@@ -4,6 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
 timeout 90 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python -m pytest tests -m gpu -q --maxfail=10 > gpurun_out/r5_gpu_tests_full.txt 2>&1; tail -3 gpurun_out/r5_gpu_tests_full.txt; grep -E "^(FAILED|ERROR)" gpurun_out/r5_gpu_tests_full.txt | head
 (timeout 300 tests/native/_build/resample_bench --cases parity > gpurun_out/r5_native_parity_full.txt 2>&1; tail -1 gpurun_out/r5_native_parity_full.txt)
+(timeout 300 tests/native/_build/resample_bench --cases perf --reps 20 > gpurun_out/r5_native_perf_full.txt 2>&1; grep -c "ms " gpurun_out/r5_native_perf_full.txt)
 timeout 600 python bench.py > gpurun_out/r5_bench_full.json 2> gpurun_out/r5_bench_full.err; echo "bench rc $?"
 python - <<'PY'
 import json

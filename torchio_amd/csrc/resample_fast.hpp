@@ -385,7 +385,7 @@ __device__ __forceinline__ int stream_stage(float* __restrict__ tile, const floa
       const bool in_vol = in_box & plane_ok & ch_ok & (static_cast<unsigned>(bx.by0 + r0 + sl.row_l) < static_cast<unsigned>(J));
       if (__builtin_amdgcn_ballot_w64(in_vol) != 0ull) issued++;
       if (in_vol) __builtin_amdgcn_global_load_lds(g + sl.goff, (fast_lds_wptr)(l), 16, 0, 0);
-      else if (in_box) *reinterpret_cast<float4*>(l + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      else if (in_box) lds_zero_chunk(l + 4 * lane);
       g += group_b; l += dgroup;
     }
     gp += NW * plane_b; lp += NW * dplane;
@@ -440,7 +440,7 @@ __device__ __forceinline__ int stream_stage_packed(float* __restrict__ tile, con
                           (static_cast<unsigned>(bx.by0 + r) < static_cast<unsigned>(J));
       if (__builtin_amdgcn_ballot_w64(in_vol) != 0ull) issued++;
       if (in_vol) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, AUX);
-      else if (in_box) *reinterpret_cast<float4*>(lp + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      else if (in_box) lds_zero_chunk(lp + 4 * lane);
     }
     row += step; p += step_p; r += step_r; off += step_b;
     if (r >= bx.Ly) { r -= bx.Ly; p += 1; off += wrap_b; }

@@ -89,15 +89,10 @@ struct BoxDmaStepper {
                           (static_cast<unsigned>(by0 + r) < static_cast<unsigned>(J));
       if (in_vol) __builtin_amdgcn_global_load_lds(origin + off, (fast_lds_wptr)(lp), 16, 0, 0);
       else if (in_box) {
-        // zeros for the chunks outside the volume — as an instruction the compiler does not see: a plain LDS store here is
-        // preceded by `s_waitcnt vmcnt(0)` (it may alias an LDS-DMA in flight, for all the compiler knows), so that every DMA
-        // instruction with a lane outside the volume waited for ALL the box's earlier DMA to land — the issue phase of the
-        // third of the bricks that touch the volume's surface became a chain of memory round trips.  The chunks are disjoint
-        // from every DMA destination by construction; callers wait with tile_dma_wait_all() (lgkmcnt too) before the barrier.
-        typedef float zero4_t __attribute__((ext_vector_type(4)));
-        const zero4_t zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)(lp + 4 * lane)));
-        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(zero) : "memory");
+        // zeros for the chunks outside the volume — as an instruction the compiler does not see (lds_zero_chunk, resample_tile.hpp:
+        // a plain LDS store here is preceded by `s_waitcnt vmcnt(0)`, and the issue phase of the third of the bricks that touch
+        // the volume's surface became a chain of memory round trips); callers wait with tile_dma_wait_all() before the barrier.
+        lds_zero_chunk(lp + 4 * lane);
       }
     }
     row += step; p += step_p; r += step_r; off += step_b;

@@ -374,6 +374,19 @@ __device__ __forceinline__ void stage_brick_f32x4(float* __restrict__ tile, cons
   }
 }
 
+// Sixteen zero bytes for a chunk of the box that lies outside the volume — as an instruction the compiler does not see (round 5,
+// first found in resample_lean_exact.hpp; used by every staging loop that mixes DMA and zero chunks): in front of a plain LDS
+// store it puts `s_waitcnt vmcnt(0)`, because the store may alias an LDS-DMA in flight for all it knows, and every DMA
+// instruction with a lane outside the volume then waited for ALL the box's earlier DMA to land.  The chunks are disjoint from
+// every DMA destination by construction; tile_dma_wait() waits for the LDS counter as well before the barrier.
+__device__ __forceinline__ void lds_zero_chunk(float* chunk) {
+  typedef __attribute__((address_space(3))) float* lds_wfloat_ptr;
+  typedef float zero4_t __attribute__((ext_vector_type(4)));
+  const zero4_t zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_wfloat_ptr)(chunk)));
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(zero) : "memory");
+}
+
 // float32, K % 4 == 0, 16-byte aligned base: global → LDS directly
 // (global_load_lds_dwordx4: each lane names one 16-byte chunk, a wave fills 1 KiB of
 // consecutive LDS), so the brick never passes through VGPRs.  Chunks outside the volume are
@@ -412,7 +425,7 @@ __device__ __forceinline__ void stage_brick_dma_loop(float* __restrict__ tile, c
         lds_float_ptr dst = (lds_float_ptr)(tile) + 4 * (base + static_cast<unsigned>(wave_base));
         __builtin_amdgcn_global_load_lds((global_byte_ptr)(src) + 4u * off, dst, 16, 0, 0);
       } else {
-        *reinterpret_cast<float4*>(tile + 4 * id) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        lds_zero_chunk(tile + 4 * id);
       }
     }
   }
@@ -427,7 +440,8 @@ __device__ __forceinline__ void stage_brick_dma(float* __restrict__ tile, const 
     stage_brick_dma_loop<NT, false>(tile, src, tid, bx, I, J, K);
 }
 
-__device__ __forceinline__ void tile_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// (lgkmcnt too: the zero chunks of boxes that leave the volume are LDS stores the compiler does not see — lds_zero_chunk above)
+__device__ __forceinline__ void tile_dma_wait() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 template <int NT, int DTMODE>
 __device__ __forceinline__ void stage_brick_generic(float* __restrict__ tile, const void* __restrict__ src, int dtype,
