@@ -190,10 +190,16 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
         if constexpr (TRACK) redo |= again ? (1u << q) : 0u;
       }
     }
+    // (the row offset re-enters the block as a 32-bit register: instruction selection works block by block, and only a zero
+    // extension it can SEE lets the store take the `scalar base + 32-bit vector offset` form — one 64-bit vector add per store less)
+    unsigned row_off = urow;
+#ifndef TIO_AB_NO_SADDR
+    asm volatile("" : "+v"(row_off));
+#endif
     if (tg + G <= n) {
 #pragma unroll
       for (int q = 0; q < G; q++) {
-        if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + urow) = vals[q];
+        if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + row_off) = vals[q];
         if constexpr (TRACK) kmin = ((redo >> q) & 1u) ? kmin : min(kmin, float_to_key(vals[q]));
         out_t += slab_b;
         asm volatile("" : "+s"(out_t));  // one running pointer (2 scalar adds per plane), not G precomputed ones
@@ -202,7 +208,11 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
 #pragma unroll
       for (int q = 0; q < G; q++) {
         if (tg + q < n) {
-          if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + urow) = vals[q];
+          unsigned tail_off = row_off;  // (its own block)
+#ifndef TIO_AB_NO_SADDR
+          asm volatile("" : "+v"(tail_off));
+#endif
+          if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + tail_off) = vals[q];
           if constexpr (TRACK) kmin = ((redo >> q) & 1u) ? kmin : min(kmin, float_to_key(vals[q]));
         }
         out_t += slab_b;
