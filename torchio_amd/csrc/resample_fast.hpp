@@ -193,9 +193,7 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
     // (the row offset re-enters the block as a 32-bit register: instruction selection works block by block, and only a zero
     // extension it can SEE lets the store take the `scalar base + 32-bit vector offset` form — one 64-bit vector add per store less)
     unsigned row_off = urow;
-#ifndef TIO_AB_NO_SADDR
     asm volatile("" : "+v"(row_off));
-#endif
     if (tg + G <= n) {
 #pragma unroll
       for (int q = 0; q < G; q++) {
@@ -209,9 +207,7 @@ __device__ __forceinline__ void fast_sample_run(int n, float ax, float ay, float
       for (int q = 0; q < G; q++) {
         if (tg + q < n) {
           unsigned tail_off = row_off;  // (its own block)
-#ifndef TIO_AB_NO_SADDR
           asm volatile("" : "+v"(tail_off));
-#endif
           if (!NOSTORE || vals[q] == 1.2345e37f) *(global_float_ptr)(out_t + tail_off) = vals[q];
           if constexpr (TRACK) kmin = ((redo >> q) & 1u) ? kmin : min(kmin, float_to_key(vals[q]));
         }
