@@ -904,3 +904,68 @@ def test_rank_shares_are_whole_physical_cores(monkeypatch):
     monkeypatch.setattr(tdist, "local_world_size", lambda: 4)
     monkeypatch.setattr(tdist.os, "cpu_count", lambda: 2 * cores)
     assert tdist.host_thread_budget() == 3  # 4 physical cores - 1 (pinned: the mask already is this rank's share)
+
+
+def _rotation_mapping(degrees, zoom=1.0) -> np.ndarray:
+    from torchio_amd.transforms.spatial import _euler_to_rotation_matrix
+
+    rotation = _euler_to_rotation_matrix(np.asarray(degrees, dtype=np.float64)) * zoom
+    return np.concatenate([rotation, np.zeros((3, 1))], axis=1)[None].astype(np.float32)
+
+
+def test_large_box_hint_follows_the_planner_arithmetic():
+    """transforms/spatial.py `_expects_large_boxes` (TIO_GEOM_LARGE_BOXES, ABI 14): the box of a 16^3 brick under the mapping, in
+    floats, against the planned roads' staging tile — False over the bench's parameter ranges (calibrated against the planner's
+    own descriptors on the GPU: scripts/r5_box_estimate.py), True where most bricks of a quarter of the elements cannot be staged."""
+    from torchio_amd.transforms.spatial import _expects_large_boxes
+
+    shape, spacing = (256, 256, 256), (1.0, 1.0, 1.0)
+    assert not _expects_large_boxes(None, None, None, shape, spacing)  # (the identity mapping is not even materialised)
+    assert not _expects_large_boxes(_rotation_mapping((0, 0, 0)), None, None, shape, spacing)
+    assert not _expects_large_boxes(_rotation_mapping((10, 10, 10)), None, None, shape, spacing)  # the bench's largest rotation (measured: staged)
+    assert _expects_large_boxes(_rotation_mapping((25, 25, 25)), None, None, shape, spacing)
+    assert _expects_large_boxes(_rotation_mapping((0, 0, 0), 2.0), None, None, shape, spacing)  # downsampling by two: 31-voxel boxes
+    # a launch-level choice: one large element in eight stays on the planned road, two do not
+    small, large = _rotation_mapping((5, 5, 5)), _rotation_mapping((25, 25, 25))
+    assert not _expects_large_boxes(np.concatenate([large] + [small] * 7), None, None, shape, spacing)
+    assert _expects_large_boxes(np.concatenate([large] * 2 + [small] * 6), None, None, shape, spacing)
+    # the displacement field's share: the bench's 7^3 control points / 7.5 mm do not tip a 10-degree launch over
+    assert not _expects_large_boxes(_rotation_mapping((10, 10, 10)), [(7.5, 7.5, 7.5)], (7, 7, 7), shape, spacing)
+    # the bench's draws: never
+    transform = tio.Spatial(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5), max_displacement=7.5, per_instance=True)
+    batch = tio.SubjectsBatch.from_subjects(make_subjects(16, 8, 1, with_label=False))
+    from torchio_amd.transforms import spatial as sp
+
+    for seed in range(20):
+        torch.manual_seed(seed)
+        params = transform.make_params(batch)
+        matrix, field, displacement, per_sample = sp._resolve_spatial_params(params)
+        matrices = np.stack([np.linalg.inv(np.asarray(m, dtype=np.float64))[:3] for m in per_sample.affine_matrices]).astype(np.float32)
+        assert not _expects_large_boxes(matrices, per_sample.max_displacements, (7, 7, 7), shape, spacing), seed
+
+
+def test_large_box_hint_reaches_the_geometry_struct():
+    """ops.Engine: `large_boxes=True` sets TIO_GEOM_LARGE_BOXES in tio_resample_geom.flags of the launch AND of the plan query."""
+    from torchio_amd import _abi
+    from torchio_amd import ops
+
+    seen = []
+
+    class Fake(dict):
+        def __missing__(self, key):
+            def call(*args):
+                seen.append((key, args[0]._obj.flags if hasattr(args[0], "_obj") else None))
+                return 0
+
+            return call
+
+        def __contains__(self, key):
+            return key != "last_error"
+
+    engine = ops.Engine(Fake(), "cpu", "fake")
+    data = torch.zeros(1, 1, 4, 4, 4)
+    mapping = torch.eye(4)[:3].unsqueeze(0)
+    for hint in (False, True):
+        engine.resample3d([data], out_shape=(4, 4, 4), mapping=mapping, control_points=None, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1),
+                          affine_first=True, interps=["linear"], fills=[None], large_boxes=hint)
+    assert [flags for name, flags in seen if name == "resample3d"] == [0, _abi.GEOM_LARGE_BOXES]

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_IMAGES = 8
 
 # tio_status
@@ -24,6 +24,7 @@ BSPLINE4, BSPLINE5, BSPLINE6, BSPLINE7 = 6, 7, 8, 9  # B-spline orders 4 - 7 ("f
 PAD_CONSTANT, PAD_REFLECT, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2, 3
 # tio_precision
 PRECISION_EXACT, PRECISION_FAST, PRECISION_TIGHT = 0, 1, 2
+GEOM_LARGE_BOXES = 1  # tio_resample_geom.flags (ABI 14)
 
 
 class ResampleGeom(C.Structure):
@@ -47,6 +48,7 @@ class ResampleGeom(C.Structure):
         ("precision", C.c_int32),
         ("plan_dev", C.c_void_p),
         ("plan_bytes", C.c_int64),
+        ("flags", C.c_int32),
     ]
 
 

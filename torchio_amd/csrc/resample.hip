@@ -965,6 +965,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       const bool force_planned = lean_exact ? (env.fast_kernel == 2 || env.exact_lean == 2) : env.fast_kernel == 2;
       bool planned = (lean_exact || env.fast_kernel != 1) && (a.K & 3) == 0 && (blocks >= kPlannedMinBricks || force_planned) && blocks < (1LL << 26);
       for (int i = 0; i < a.n_images; i++) planned = planned && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
+      // the caller expects boxes beyond the staging tile (tio_hip.h: TIO_GEOM_LARGE_BOXES): a planned brick whose box does not fit
+      // samples voxel by voxel from global memory, the brick kernels below split it into passes over its planes
+      if ((geom->flags & TIO_GEOM_LARGE_BOXES) != 0 && !force_planned) planned = false;
       if (planned && a.cp != nullptr) {
         const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
         for (int d = 0; d < 3; d++)

@@ -828,6 +828,7 @@ class Engine:
     def _resample_geom(
         self, batch: int, in_shape, out_shape, mapping: Tensor, control_points: Tensor | None, in_spacing, out_spacing,
         affine_first: bool, cp_skip: Tensor | None, passthrough: Tensor | None, norm_shape, precision: str | None,
+        large_boxes: bool = False,
     ):
         """``tio_resample_geom`` of one launch and the tensors it points into (mapping, control points, flags — keep them alive)."""
         if mapping.dtype != torch.float32 or not mapping.is_contiguous():
@@ -858,13 +859,14 @@ class Engine:
         if norm_shape is not None:  # the shape the coordinates are normalised with, when it is not the images' own
             geom.norm_shape = _i32x3(norm_shape)
         geom.precision = PRECISION_CODES[precision if precision is not None else _RESAMPLE_PRECISION]
+        geom.flags = _abi.GEOM_LARGE_BOXES if large_boxes else 0
         self._check("resample3d", mapping, control_points, cp_skip, passthrough)
         return geom, [mapping, control_points, cp_skip, passthrough]
 
     def resample_plan(
         self, *, batch: int, in_shape, out_shape, mapping: Tensor, control_points: Tensor | None, in_spacing, out_spacing,
         affine_first: bool, cp_skip: Tensor | None = None, passthrough: Tensor | None = None, norm_shape=None,
-        precision: str | None = None,
+        precision: str | None = None, large_boxes: bool = False,
     ) -> Tensor | None:
         """The brick plan of the launch ``resample3d`` would make for this geometry with float32 trilinear images, enqueued on
         the CURRENT stream of the mapping's device (``tio_resample3d_plan``, ABI 11) — or ``None`` when that launch takes a
@@ -874,7 +876,7 @@ class Engine:
             return None
         geom, keep_alive = self._resample_geom(
             batch, tuple(in_shape), tuple(int(s) for s in out_shape), mapping, control_points, in_spacing, out_spacing,
-            affine_first, cp_skip, passthrough, norm_shape, precision,
+            affine_first, cp_skip, passthrough, norm_shape, precision, large_boxes,
         )
         reference = keep_alive[0]
         if reference.device.index != torch.cuda.current_device():
@@ -908,6 +910,7 @@ class Engine:
         norm_shape: Sequence[int] | None = None,
         precision: str | None = None,
         plan: Tensor | None = None,
+        large_boxes: bool = False,
         _adjoint_of: Sequence[Tensor] | None = None,
     ) -> list[Tensor]:
         """Resample every ``(B, C, I, J, K)`` tensor in *images* through one coordinate pass.
@@ -920,6 +923,8 @@ class Engine:
         fused partial-volume mode: ``label_tables[n]`` is ``torch.unique(images[n])`` as
         float64 on the data's device (or ``None``: exact for fewer than 16 labels) and
         ``pad_labels[n]`` the out-of-bounds label; ``fills[n]`` is ignored for them.
+        ``large_boxes``: the caller's hint that most bricks' input boxes exceed the staging tile (``TIO_GEOM_LARGE_BOXES``,
+        transforms/spatial.py: ``_expects_large_boxes``) — a choice of road, never of values.
         """
         if not images:
             return []
@@ -933,7 +938,7 @@ class Engine:
         out_shape = tuple(int(s) for s in out_shape)
         geom, keep_alive = self._resample_geom(
             batch, in_shape, out_shape, mapping, control_points, in_spacing, out_spacing, affine_first, cp_skip, passthrough,
-            norm_shape, precision,
+            norm_shape, precision, large_boxes,
         )
         mapping, control_points, cp_skip, passthrough = keep_alive[:4]
         if plan is not None and plan.device == first.device:  # made ahead by `resample_plan` for exactly this geometry

@@ -401,6 +401,7 @@ class Spatial(SpatialTransform):
                         batch=first.batch_size, in_shape=geometry.in_shape, out_shape=geometry.out_shape, mapping=geometry.mapping_dev,
                         control_points=geometry.field_tensor, in_spacing=geometry.in_affine.spacing, out_spacing=geometry.out_affine.spacing,
                         affine_first=params["affine_first"], cp_skip=geometry.cp_skip, passthrough=geometry.passthrough_all,
+                        large_boxes=geometry.large_boxes,
                     )
                 ahead.event = side.record_event()
             ahead.tensors = [
@@ -630,12 +631,55 @@ class _LaunchGeometry:
     """What every launch of one `_apply_spatial_to_batch` call shares, on the device: grids, mapping, control points, flags
     (+ the brick plan of the fused launch when it was made ahead, `Spatial._prefetch`)."""
 
-    __slots__ = ("in_shape", "in_affine", "out_shape", "out_affine", "mapping_dev", "field_tensor", "cp_skip", "passthrough_all", "flags", "plan")
+    __slots__ = ("in_shape", "in_affine", "out_shape", "out_affine", "mapping_dev", "field_tensor", "cp_skip", "passthrough_all", "flags", "plan",
+                 "large_boxes")
 
-    def __init__(self, in_shape, in_affine, out_shape, out_affine, mapping_dev, field_tensor, cp_skip, passthrough_all, flags) -> None:
+    def __init__(self, in_shape, in_affine, out_shape, out_affine, mapping_dev, field_tensor, cp_skip, passthrough_all, flags, large_boxes=False) -> None:
         self.in_shape, self.in_affine, self.out_shape, self.out_affine = in_shape, in_affine, out_shape, out_affine
         self.mapping_dev, self.field_tensor, self.cp_skip, self.passthrough_all, self.flags = mapping_dev, field_tensor, cp_skip, passthrough_all, flags
         self.plan = None
+        self.large_boxes = large_boxes  # most bricks' input boxes exceed the planned roads' staging tile (`_expects_large_boxes`)
+
+
+# floats of ONE staging tile of the planned roads (csrc/resample.hip: 160 KB of LDS per CU, three blocks, granules of 1 280 bytes)
+_PLANNED_TILE_FLOATS = 13440
+# elements of a launch whose bricks exceed it from which on the brick kernels (in-kernel boxes, a large brick in two / four passes over
+# its planes) are the faster road for the WHOLE launch: a brick without a box costs a planned kernel ~3.5 x, the brick kernels cost
+# every brick ~1.2 - 1.7 x (profiles/r05_large_rotation.json: break-even near a quarter of the elements)
+_LARGE_BOX_FRACTION = 0.25
+# how much of `d (15 / cell)` per output axis a displacement component typically varies over a brick (calibrated against the planner's
+# own boxes: scripts/r5_box_estimate.py)
+_FIELD_VARIATION = 0.2
+# ... and how far beyond the tile the ESTIMATE (the largest box of the element: worst fractional position, worst alignment) has to be
+# before most of the element's bricks really are (same calibration: at 1.0 x one brick in ten, at 1.15 x more than half)
+_LARGE_BOX_MARGIN = 1.15
+
+
+def _expects_large_boxes(mapping: np.ndarray | None, displacements, field_shape, out_shape, in_spacing) -> bool:
+    """Will the input box of a 16^3 output brick exceed the planned roads' staging tile for at least a quarter of the elements?
+
+    The box of a brick under the output -> input voxel mapping ``M`` spans ``15 sum_c |M_rc|`` voxels along input axis ``r``
+    (plus the displacement field's variation over the brick, plus the taps), rows padded to 16-byte chunks — the planner's
+    own arithmetic (csrc/resample_fast.hpp: plan_bricks_kernel) on the host copy of the mappings.  A HINT: it chooses between
+    roads that compute the same values (``TIO_GEOM_LARGE_BOXES``), so an estimate is enough."""
+    if mapping is None:
+        return False
+    rows = np.abs(np.asarray(mapping, dtype=np.float64)[:, :, :3]).sum(axis=2)  # (n, 3): |M_r0| + |M_r1| + |M_r2|
+    extent = 15.0 * rows
+    if field_shape is not None and displacements is not None:
+        # the field moves a point by up to d mm; between two control points it is linear, so over a brick edge (15 voxels) a
+        # component varies by ~d (15 / cell) along each output axis for typical draws (the bound is twice that)
+        cells = [max((int(out_shape[axis]) - 1) / max(int(field_shape[axis]) - 1, 1), 1.0) for axis in range(3)]
+        share = min(1.0, sum(15.0 / cell for cell in cells) / 3.0 * _FIELD_VARIATION)
+        spacing = np.asarray(in_spacing, dtype=np.float64)
+        per_element = list(displacements) if len(displacements) == len(extent) else [displacements[0]] * len(extent)
+        for n, displacement in enumerate(per_element):
+            if displacement is not None:
+                extent[n] += np.abs(np.asarray(displacement, dtype=np.float64)) / spacing * share
+    length = np.floor(extent) + 3.0  # first tap to last tap + 1, the fractional position
+    chunks = np.ceil((length[:, 2] + 3.0) / 4.0)  # rows start on a 16-byte boundary: up to three floats in front
+    floats = length[:, 0] * length[:, 1] * chunks * 4.0
+    return bool((floats > _LARGE_BOX_MARGIN * _PLANNED_TILE_FLOATS).mean() >= _LARGE_BOX_FRACTION)
 
 
 def _prepare_launch_geometry(
@@ -723,7 +767,11 @@ def _prepare_launch_geometry(
         flags = [False] * batch_size
 
     mapping_dev = _identity_mapping(device) if mapping is None else ops.h2d(torch.from_numpy(mapping), device)
-    return _LaunchGeometry(in_shape, in_affine, out_shape, out_affine, mapping_dev, field_tensor, cp_skip, passthrough_all, flags)
+    large_boxes = _expects_large_boxes(
+        mapping, displacements if field_tensor is not None else None, None if field_tensor is None else tuple(field_tensor.shape[1:4]), out_shape,
+        in_affine.spacing,
+    )
+    return _LaunchGeometry(in_shape, in_affine, out_shape, out_affine, mapping_dev, field_tensor, cp_skip, passthrough_all, flags, large_boxes)
 
 
 
@@ -785,7 +833,7 @@ def _apply_spatial_to_batch(
                     [tensors[n] for n in members], out_shape=out_shape, mapping=mapping_dev, control_points=field_tensor,
                     in_spacing=in_affine.spacing, out_spacing=out_affine.spacing, affine_first=affine_first,
                     interps=[interps[n] for n in members], fills=[fills[n] for n in members], cp_skip=cp_skip,
-                    passthrough=passthrough, norm_shape=in_shape, **extra,
+                    passthrough=passthrough, norm_shape=in_shape, large_boxes=prepared.large_boxes, **extra,
                 )
                 for n, result in zip(members, results, strict=True):
                     outputs[n] = result
@@ -803,6 +851,7 @@ def _apply_spatial_to_batch(
             cp_skip=cp_skip,
             passthrough=passthrough,
             plan=prepared.plan if gated else None,  # (made for the gated geometry of the fused call; ignored by calls that take another road)
+            large_boxes=prepared.large_boxes,
             **label_arguments,
         )
 
