@@ -664,22 +664,25 @@ def _expects_large_boxes(mapping: np.ndarray | None, displacements, field_shape,
     roads that compute the same values (``TIO_GEOM_LARGE_BOXES``), so an estimate is enough."""
     if mapping is None:
         return False
-    rows = np.abs(np.asarray(mapping, dtype=np.float64)[:, :, :3]).sum(axis=2)  # (n, 3): |M_r0| + |M_r1| + |M_r2|
-    extent = 15.0 * rows
+    extent = 15.0 * np.abs(mapping[:, :, :3]).sum(axis=2)  # (n, 3): 15 (|M_r0| + |M_r1| + |M_r2|)
     if field_shape is not None and displacements is not None:
         # the field moves a point by up to d mm; between two control points it is linear, so over a brick edge (15 voxels) a
         # component varies by ~d (15 / cell) along each output axis for typical draws (the bound is twice that)
-        cells = [max((int(out_shape[axis]) - 1) / max(int(field_shape[axis]) - 1, 1), 1.0) for axis in range(3)]
-        share = min(1.0, sum(15.0 / cell for cell in cells) / 3.0 * _FIELD_VARIATION)
-        spacing = np.asarray(in_spacing, dtype=np.float64)
-        per_element = list(displacements) if len(displacements) == len(extent) else [displacements[0]] * len(extent)
-        for n, displacement in enumerate(per_element):
-            if displacement is not None:
-                extent[n] += np.abs(np.asarray(displacement, dtype=np.float64)) / spacing * share
+        share = 0.0
+        for axis in range(3):
+            share += 15.0 * max(int(field_shape[axis]) - 1, 1) / max(int(out_shape[axis]) - 1, 1)
+        share = min(1.0, share / 3.0 * _FIELD_VARIATION)
+        if isinstance(displacements, np.ndarray):  # (make_params' block draw: already (n, 3))
+            limits = displacements
+        else:  # a list with None for the elements without a field (one entry when the batch shares its parameters)
+            limits = np.array([(0.0, 0.0, 0.0) if d is None else d for d in displacements])
+        if limits.shape[0] not in (1, extent.shape[0]):
+            limits = limits[:1]
+        extent = extent + np.abs(limits) * np.array([share / float(in_spacing[0]), share / float(in_spacing[1]), share / float(in_spacing[2])])
     length = np.floor(extent) + 3.0  # first tap to last tap + 1, the fractional position
-    chunks = np.ceil((length[:, 2] + 3.0) / 4.0)  # rows start on a 16-byte boundary: up to three floats in front
+    chunks = np.ceil((length[:, 2] + 3.0) * 0.25)  # rows start on a 16-byte boundary: up to three floats in front
     floats = length[:, 0] * length[:, 1] * chunks * 4.0
-    return bool((floats > _LARGE_BOX_MARGIN * _PLANNED_TILE_FLOATS).mean() >= _LARGE_BOX_FRACTION)
+    return int(np.count_nonzero(floats > _LARGE_BOX_MARGIN * _PLANNED_TILE_FLOATS)) >= _LARGE_BOX_FRACTION * floats.shape[0]
 
 
 def _prepare_launch_geometry(
