@@ -588,6 +588,7 @@ def main() -> None:
                 "tests/test_gpu_tight.py::test_lean_exact_kernel_small_shapes (54 cases: partial bricks, fills, gated / control-point-free elements, both composition orders)",
                 "tests/test_gpu_lazy_fusion.py (fused BiasField / Blur / Noise launch == the three separate launches bit for bit, == oracle to 2e-5; asserts the fused branch ran)",
                 "tests/native/resample_bench --cases parity|perf, paths tight / lean-exact (every case inside the per-voxel bar / bit for bit against the gather kernel and the oracle)",
+                "tests/test_gpu_large_boxes.py (3 x 256^3 at 25 degrees about every axis: the brick-kernel road TIO_GEOM_LARGE_BOXES selects == the planned road, bit for bit in the exact mode, inside the bars in the others)",
             ],
             "noise=philox,resample=exact": ["tests/test_gpu_lazy_fusion.py", "tests/test_gpu_ops_parity.py (philox add_noise vs oracle philox)", "tests/test_gpu_golden.py (resampling: bit-exact)", "tests/test_gpu_tight.py (exact mode on the lean exact-coordinate kernel: bit-exact at 3 x 256^3)"],
             "noise=philox,resample=fast (headline of rounds 2 - 4; NOT inside the per-voxel bar on white noise)": [
