@@ -163,3 +163,38 @@ def test_tight_precision_of_small_launches_is_the_exact_kernel(hip):
     kwargs = dict(out_shape=(48, 48, 48), mapping=_mapping(2, 3, scale=0.1, shift=2.0).cuda(), control_points=None, in_spacing=(1, 1, 1),
                   out_spacing=(1, 1, 1), affine_first=True, interps=["linear"], fills=[None])
     assert torch.equal(hip.resample3d([data], precision="exact", **kwargs)[0], hip.resample3d([data], precision="tight", **kwargs)[0])
+
+
+def test_tap_addresses_of_a_very_long_volume(hip, monkeypatch):
+    """The exact-coordinate kernel forms a tap's LDS address in float32 from ABSOLUTE voxel indices (tile_issue_folded): exact while
+    every partial sum stays below 2^24, which `box_address_fits` checks per box — 6 144 planes of 32 x 32 put the far half of the
+    volume beyond it (x * row pitch > 2^23): those bricks take the per-voxel road, the near half the staged one, and the launch is
+    still the brick kernel's result bit for bit (exact) / inside the per-voxel bar (tight)."""
+    shape = (6144, 32, 32)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    data = torch.rand(1, 1, *shape, generator=g, device="cuda") * 4 - 1
+    # a rotation of 6 degrees about the long axis (through the centre of the 32 x 32 cross-section) and a sub-voxel shift along it:
+    # every plane keeps the volume in view
+    import math
+
+    c, s_, centre = math.cos(math.radians(6.0)), math.sin(math.radians(6.0)), 15.5
+    mapping = torch.tensor([[[1.0, 0.0, 0.0, 0.3],
+                             [0.0, c, -s_, centre - c * centre + s_ * centre],
+                             [0.0, s_, c, centre - s_ * centre - c * centre]]], dtype=torch.float32)
+    kwargs = dict(
+        out_shape=shape, mapping=mapping.cuda(), control_points=None, in_spacing=(1, 1, 1), out_spacing=(1, 1, 1),
+        affine_first=True, interps=["linear"], fills=[torch.tensor([-1.0], device="cuda")],
+    )
+    monkeypatch.setenv("TIO_EXACT_LEAN", "0")
+    brick = hip.resample3d([data], precision="exact", **kwargs)[0]
+    monkeypatch.setenv("TIO_EXACT_LEAN", "2")
+    monkeypatch.setenv("TIO_FAST_KERNEL", "planned")
+    lean = hip.resample3d([data], precision="exact", **kwargs)[0]
+    tight = hip.resample3d([data], precision="tight", **kwargs)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(lean, brick)
+    stats = per_voxel(brick, tight)
+    assert stats["beyond_1e-4"] == 0, stats
+    assert not torch.equal(tight, brick), "the launch fell back to the brick kernel"
+    # both halves were sampled (not filled): the far end of the volume holds data, not the fill value everywhere
+    assert float((tight[0, 0, -64:] != -1.0).float().mean()) > 0.5
