@@ -25,10 +25,6 @@
 #include "../../include/tio_hip.h"
 
 extern "C" int tio_oracle_resample3d(const tio_resample_geom*, int32_t, const tio_resample_image*, void*);
-// only in libraries built with -DTIO_LE_TIMELINE (csrc/resample_lean_exact.hpp): per-phase clock sums of the exact-coordinate kernel
-// (looked up at run time: a weak reference of a non-PIC executable is settled — to null — when the executable is linked)
-typedef int (*tio_debug_le_timeline_fn)(unsigned long long* out8, int reset);
-static tio_debug_le_timeline_fn tio_debug_le_timeline = nullptr;
 
 #define HIP_CHECK(x)                                                                  \
   do {                                                                                \
@@ -188,9 +184,7 @@ static const Paths kPaths[] = {
     // (TIO_LEAN_INTERLEAVE=0, A/B of the interleaved DMA issue)
     {"lean-exact", "tile", "0", 0, "planned", "lean-exact"}, {"tight", "tile", "0", 2, "planned", "0"},
     {"lean-exact-seq", "tile", "0", 0, "planned", "lean-exact-seq"}, {"tight-seq", "tile", "0", 2, "planned", "seq"},
-    {"tight-dma1st", "tile", "0", 2, "planned", "dmafirst"},
-    // the persistent double-buffered form (resample_lean_persist.hpp; affine launches): one block of 1 024 threads per CU
-    {"lean-exact-pdb", "tile", "0", 0, "planned", "lean-exact-pdb"}, {"tight-pdb", "tile", "0", 2, "planned", "pdb"}};
+    {"tight-dma1st", "tile", "0", 2, "planned", "dmafirst"}};
 
 // --ablate 64: the lean kernel overwrites the first output row of every brick with its block's shader-clock stamps
 // (resample_fast.hpp); medians of the phases, and how many blocks of a CU were alive together
@@ -349,7 +343,6 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     const std::string mix = kPaths[p].v2 ? kPaths[p].v2 : "";
     setenv("TIO_PLANNED_LEAN", mix == "nolean" ? "0" : "1", 1);
     setenv("TIO_EXACT_LEAN", mix.rfind("lean-exact", 0) == 0 ? "2" : "0", 1);  // the older exact paths stay on the brick kernel
-    setenv("TIO_LEAN_PERSIST", (mix == "pdb" || mix == "lean-exact-pdb") ? "1" : "0", 1);
     setenv("TIO_LEAN_INTERLEAVE", (mix == "seq" || mix == "lean-exact-seq") ? "0" : (mix == "dmafirst" ? "2" : "1"), 1);
     setenv("TIO_NEAREST_KERNEL", p == 0 ? "0" : "1", 1);  // the baseline keeps nearest images on the gather kernel's exact chain
     tio_reload_env();  // (the library parses its switches once per process otherwise)
@@ -369,23 +362,12 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     if (time_it) {
       for (int w = 0; w < 2; w++) tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
       HIP_CHECK(hipDeviceSynchronize());
-      if (tio_debug_le_timeline) tio_debug_le_timeline(nullptr, 1);
       HIP_CHECK(hipEventRecord(e0, nullptr));
       for (int r = 0; r < reps; r++) tio_resample3d(&geom, static_cast<int>(descs.size()), descs.data(), nullptr);
       HIP_CHECK(hipEventRecord(e1, nullptr));
       HIP_CHECK(hipEventSynchronize(e1));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       ms /= reps;
-      unsigned long long tl[8] = {0};
-      const int tl_status = tio_debug_le_timeline ? tio_debug_le_timeline(tl, 1) : -1;
-      if (tl_status > 0) fprintf(stderr, "tio_debug_le_timeline failed: %d\n", tl_status);
-      if (tl_status == 0 && tl[5] != 0) {
-        // a library built with -DTIO_LE_TIMELINE: the mean shader-clock ticks a block of the exact-coordinate kernel spends per phase
-        const double n = static_cast<double>(tl[5]);
-        const double total = static_cast<double>(tl[0] + tl[1] + tl[2] + tl[3] + tl[4]);
-        printf("  [timeline %s: %.0f blocks; ticks per block: entry->descriptor %.0f, ->box requested + coordinates %.0f, ->box landed %.0f, ->sampled %.0f, ->stores acknowledged %.0f; total %.0f]\n",
-               kPaths[p].name, n, tl[0] / n, tl[1] / n, tl[2] / n, tl[3] / n, tl[4] / n, total / n);
-      }
     }
     if (p != 0 && getenv("TIO_TILE_ABLATE") && (atoi(getenv("TIO_TILE_ABLATE")) & 64)) report_stamps(cs, B, n_out);
     size_t diff_first = 0, diff_oracle = 0;
@@ -481,8 +463,6 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--ablate") && i + 1 < argc) setenv("TIO_TILE_ABLATE", argv[++i], 1);
     else if (!strcmp(argv[i], "--lds") && i + 1 < argc) setenv("TIO_TILE_LDS_FLOATS", argv[++i], 1);
   }
-  tio_debug_le_timeline = reinterpret_cast<tio_debug_le_timeline_fn>(dlsym(RTLD_DEFAULT, "tio_debug_le_timeline"));
-  if (tio_debug_le_timeline) fprintf(stderr, "library built with TIO_LE_TIMELINE: per-phase block timeline follows the lean-exact / tight lines\n");
   if (tio_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
   int failures = 0;
   if (cases == "calib") return run_calibration();

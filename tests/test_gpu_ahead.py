@@ -110,7 +110,7 @@ def test_compose_on_the_side_stream_changes_nothing(hip, _modes, mode):
     """The headline pipeline (and the library default), 3 x 256^3 float32 + int16 labels: values bit for bit, history and the
     global generator's state with and without the side stream; steps issued back to back without a synchronisation in
     between (the uploads and plans of step k + 1 run while the kernels of step k are still in flight)."""
-    tio.set_noise_rng(mode[0]); tio.set_resample_precision(mode[1]); tio.set_stencil_precision(mode[1])
+    tio.set_noise_rng(mode[0]); tio.set_resample_precision(mode[1], allow_out_of_tolerance=True); tio.set_stencil_precision(mode[1])
     size, batch, steps = 256, 3, 6
     g = torch.Generator().manual_seed(17)
     subjects = [
@@ -151,7 +151,7 @@ def test_compose_on_the_side_stream_changes_nothing(hip, _modes, mode):
 def test_compose_announces_the_minimum_to_the_launch_before(hip, _modes):
     """`Compose[Affine, ElasticDeformation]` in the FAST mode: the affine launch folds the minimum of its first element into
     its stores because the elastic child will ask for it — one `channel_min` reduction per step instead of two, same values."""
-    tio.set_resample_precision("fast")
+    tio.set_resample_precision("fast", allow_out_of_tolerance=True)
     size, batch = 256, 3
     g = torch.Generator().manual_seed(29)
     subjects = [tio.Subject(t1=tio.ScalarImage(torch.rand(1, size, size, size, generator=g) - 0.3)) for _ in range(batch)]

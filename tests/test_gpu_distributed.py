@@ -47,6 +47,7 @@ def test_bench_under_torchrun_one_rank_uses_rccl(hip):
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0
     assert line["config"]["global_batch"] == 2 and line["distributed"]["backend"] == "nccl"
     assert line["distributed"]["world_size"] == 1 and line["distributed"]["counters_shape"] == [1, 3]
+    assert len(json.dumps(line)) < 6000  # (the line must survive the driver's 8 KB tail)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on one node")

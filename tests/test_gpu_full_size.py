@@ -111,7 +111,7 @@ def test_fast_precision_256_within_tolerance_of_the_oracle(oracle, hip):
         expected = transform(cpu)
     previous = tio.get_resample_precision()
     try:
-        tio.set_resample_precision("fast")
+        tio.set_resample_precision("fast", allow_out_of_tolerance=True)
         torch.manual_seed(22)
         actual = transform(gpu)
         torch.cuda.synchronize()
@@ -180,7 +180,7 @@ def test_headline_mode_256_matches_oracle(oracle, hip, intensity_scale, precisio
     previous = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision())
     try:
         tio.set_noise_rng("philox")
-        tio.set_resample_precision(precision)
+        tio.set_resample_precision(precision, allow_out_of_tolerance=True)
         tio.set_stencil_precision("fast")  # bench.py's headline: fused multiply-adds in the Blur's taps
         torch.manual_seed(32)
         with use_engine(oracle):

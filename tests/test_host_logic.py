@@ -865,6 +865,19 @@ def test_precision_and_draw_policy_switches():
         assert tio.get_resample_precision() == "tight"
         with pytest.raises(ValueError):
             tio.set_resample_precision("approximate")
+        # round 6: "fast" is outside the per-voxel tolerance on noisy data and is refused without an explicit opt-in
+        opted = ops._FAST_OPTED_IN
+        ops._FAST_OPTED_IN = False
+        try:
+            with pytest.raises(ValueError, match="allow_out_of_tolerance"):
+                tio.set_resample_precision("fast")
+            assert tio.get_resample_precision() == "tight"
+            tio.set_resample_precision("fast", allow_out_of_tolerance=True)
+            assert tio.get_resample_precision() == "fast"
+            tio.set_resample_precision("exact")
+            tio.set_resample_precision("fast")  # (restoring a saved mode after the opt-in)
+        finally:
+            ops._FAST_OPTED_IN = opted
     finally:
         tio.set_resample_precision(previous)
     policy = tio.get_draw_policy()

@@ -30,13 +30,12 @@ struct EnvSwitches {
   int tile_variant = 0;          // TIO_TILE_VARIANT
   int tile_lds_floats = 0;       // TIO_TILE_LDS_FLOATS
   int tile_ablate = 0;           // TIO_TILE_ABLATE (instrumented instantiations only)
-  int resample_exact = 0;        // TIO_RESAMPLE_EXACT set: never the FAST kernels
+  int resample_exact = 0;        // TIO_RESAMPLE_EXACT set: never the FAST kernels, and TIGHT launches interpolate in ATen's order (bit-exact)
   int fast_kernel = 0;           // TIO_FAST_KERNEL: 0 unset, 1 brick, 2 planned
   int planned_lean = 1;          // TIO_PLANNED_LEAN
   int dma_packed = 1;            // TIO_DMA_PACKED
   int exact_plan = -1;           // TIO_EXACT_PLAN: -1 unset, else its value
   int exact_lean = -1;           // TIO_EXACT_LEAN: -1 unset (large exact float32 launches take resample_lean_exact_kernel), 0 never, 2 small launches too
-  int lean_persist = 0;          // TIO_LEAN_PERSIST=1: affine launches of the exact-coordinate kernel take the persistent three-tile form (measured slower: resample_lean_persist.hpp)
   int lean_interleave = 1;       // TIO_LEAN_INTERLEAVE (0: the exact-coordinate kernel issues its whole box before phase A, A/B)
   int fast_fill_recheck = 1;     // TIO_FAST_FILL_RECHECK (0: the FAST fill rule decides alone, A/B)
   int conv_no_fuse = 0;          // TIO_CONV_NO_FUSE set

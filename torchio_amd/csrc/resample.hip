@@ -606,7 +606,6 @@ __global__ __launch_bounds__(kRowsPerBlock* kLanes) void resample_kernel(const R
 #include "resample_tile.hpp"
 #include "resample_fast.hpp"
 #include "resample_lean_exact.hpp"
-#include "resample_lean_persist.hpp"
 #include "resample_nearest.hpp"
 
 // Device scratch for the brick plan of a planned launch (resample_fast.hpp): one buffer per (device, stream), grown on
@@ -629,19 +628,6 @@ struct PlanLease {
   int* ptr = nullptr;
 };
 }  // namespace
-
-// blocks of a persistent launch: one per CU of the current device, a multiple of 8 (the XCDs; resample_lean_persist.hpp)
-static int persist_blocks() {
-  static int cached[64] = {0};
-  int device = 0;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return 0;
-  if (cached[device] == 0) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
-    cached[device] = cus >= 8 ? cus / 8 * 8 : -1;
-  }
-  return cached[device] > 0 ? cached[device] : 0;
-}
 
 static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
   static std::mutex registry_mu;
@@ -946,8 +932,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     // bit-identical to the brick kernel below (TIO_EXACT_LEAN=0 keeps large exact launches on the brick kernel, =2 sends
     // small ones to the lean kernel as well: A/B and tests).  Float32 trilinear images only, divisors the short division is
     // proven for, unit spacing whenever a displacement is divided by it; everything else runs the exact brick kernel.
-    const bool tight = geom->precision == TIO_PRECISION_TIGHT;
-    const bool lean_exact = !fast && (tight || (geom->precision == TIO_PRECISION_EXACT && env.exact_lean != 0)) && dtmode == 0 &&
+    const bool tight = geom->precision == TIO_PRECISION_TIGHT && !env.resample_exact;  // (TIO_RESAMPLE_EXACT: the A/B switch forces ATen's interpolation order too)
+    const bool lean_exact = !fast && (tight || ((geom->precision == TIO_PRECISION_EXACT || geom->precision == TIO_PRECISION_TIGHT) && env.exact_lean != 0)) && dtmode == 0 &&
                             !a.any_nearest && variant == 0 && a.ablate == 0 && a.short_div != 0 && (a.cp == nullptr || a.unit_spacing != 0);
     if (fast || lean_exact) {
       a.tiles_k = (a.Ko + 15) / 16; a.tiles_j = (a.Jo + 15) / 16; a.tiles_i = (a.Io + 15) / 16;
@@ -982,8 +968,6 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         // floats keep three blocks resident, 13 568 drop to two — profiles/r04_tile_cap.log); 300 floats more than the round-3
         // value, which is 1.5 % of a fused affine + elastic launch (fewer bricks on the per-voxel road)
         int cap_p = (kLdsFloatsPerCU / kTileBlocksPerCU) / 320 * 320;
-        // the persistent form (resample_lean_persist.hpp): ONE block of 1 024 threads per CU, three tiles of the same size
-        const bool persist = lean_exact && a.cp == nullptr && env.lean_persist != 0 && persist_blocks() >= 8;
         if (env.tile_lds_floats > 0) cap_p = env.tile_lds_floats;
         if (cap_p < kTileMinCap) cap_p = kTileMinCap;
         if (cap_p > kLdsFloatsPerCU) cap_p = kLdsFloatsPerCU;
@@ -1083,14 +1067,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, true>;
           else if (min_channels > 0)  // the folded minimum: the instantiation whose element-0 bricks track what they store
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, false, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, false, true>;
-          size_t lds_launch = lds_p;
-          unsigned grid_launch = static_cast<unsigned>(n_items), block_launch = 256;
-          if (persist) {
-            if (tight) kernel = min_channels > 0 ? resample_lean_exact_persistent_kernel<false, true> : resample_lean_exact_persistent_kernel<false, false>;
-            else kernel = min_channels > 0 ? resample_lean_exact_persistent_kernel<true, true> : resample_lean_exact_persistent_kernel<true, false>;
-            lds_launch = 3 * lds_p;
-            grid_launch = static_cast<unsigned>(persist_blocks()); block_launch = 1024;
-          }
+          const size_t lds_launch = lds_p;
+          const unsigned grid_launch = static_cast<unsigned>(n_items), block_launch = 256;
           if (lds_launch > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       static_cast<int>(lds_launch)) != hipSuccess)
             return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_launch);
@@ -1242,21 +1220,3 @@ extern "C" int tio_resample3d(const tio_resample_geom* geom, int32_t n_images, c
   return TIO_OK;
 }
 
-#ifdef TIO_LE_TIMELINE
-// measurement builds only (resample_lean_exact.hpp: TIO_LE_TIMELINE): the per-phase clock sums of the exact-coordinate kernel
-extern "C" __attribute__((visibility("default"))) int tio_debug_le_timeline(unsigned long long* out8, int reset) {
-  static std::vector<unsigned long long> table(tio::kTimelineSlots * 8);
-  const size_t bytes = table.size() * sizeof(unsigned long long);
-  if (out8 != nullptr) {
-    if (hipMemcpyFromSymbol(table.data(), HIP_SYMBOL(tio::g_le_timeline), bytes) != hipSuccess) return 1;
-    for (int q = 0; q < 8; q++) out8[q] = 0;
-    for (int slot = 0; slot < tio::kTimelineSlots; slot++)
-      for (int q = 0; q < 8; q++) out8[q] += table[slot * 8 + q];
-  }
-  if (reset) {
-    std::fill(table.begin(), table.end(), 0ull);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(tio::g_le_timeline), table.data(), bytes) != hipSuccess) return 1;
-  }
-  return 0;
-}
-#endif

@@ -298,21 +298,6 @@ __device__ __forceinline__ bool lean_exact_group_leaves(const float (&X4)[4], co
   return !inside;
 }
 
-// Measurement build (-DTIO_LE_TIMELINE, see tests/native/build_timeline.sh): where a block's lifetime goes.  Every block adds the
-// shader-clock differences between six marks to a table in global memory (tio_debug_le_timeline sums it; resample_bench
-// prints it): entry -> descriptor in registers -> box requested and coordinates formed -> box landed (barrier) -> sixteen
-// planes sampled -> stores acknowledged.  The production build compiles none of it.
-#ifdef TIO_LE_TIMELINE
-constexpr int kTimelineSlots = 4096;  // (one table per slot, blocks spread by brick index: six hot addresses serialise the atomics
-                                      //  — the first version, with one table, ran the kernel six times slower)
-__device__ unsigned long long g_le_timeline[kTimelineSlots * 8];
-#define TIO_LE_MARK(var)                                       \
-  __builtin_amdgcn_sched_barrier(0);                           \
-  const unsigned long long var = __builtin_amdgcn_s_memtime(); \
-  __builtin_amdgcn_sched_barrier(0);
-#else
-#define TIO_LE_MARK(var)
-#endif
 
 template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, int WAVES_PER_SIMD, bool FOLD_MIN = false>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kernel(const LeanArgs a) {
@@ -322,7 +307,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   typedef __attribute__((address_space(4))) const int* const_int_ptr;
   typedef __attribute__((address_space(4))) const float* const_float_ptr;
 
-  TIO_LE_MARK(tl_entry)
   // every argument the road to the first DMA needs, in scalar registers NOW (resample_planned_lean_kernel)
   // (round 5: the first build of this kernel fetched mapping_batched, tile_floats, the strides and the output shape one by one,
   // each behind its own `s_waitcnt lgkmcnt(0)` — nine scalar round trips between entry and the first DMA instruction)
@@ -369,7 +353,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
                               !box_address_fits(bx.bx0, bx.by0, bx.za, bx.Lx, bx.Ly, bx.cpr)))
     kind = kDescSlow;
   bx.kind = kind; bx.interior = kind_w >> 8;
-  TIO_LE_MARK(tl_desc)
   BoxDmaStepper<NW> dma;
   dma.left = 0;
   if (kind == kDescStaged) dma.init(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane);
@@ -501,10 +484,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
   ta.c_f = ta.base_f - ta.ox * ta.sXbf - ta.oy * ta.sYbf - 4.0f * ta.oz;  // (exact: box_address_fits held above)
 
-  TIO_LE_MARK(tl_issued)
   tile_dma_wait_all();
   __syncthreads();
-  TIO_LE_MARK(tl_landed)
 
   // ---- phase B: sample.  The fill rule only matters where a tap can leave the volume: interior boxes never, the others
   // group by group and wave by wave (the masked code runs only in waves one of whose four voxels has a tap outside)
@@ -539,20 +520,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
 #undef TIO_LE_GROUPS_GUARDED
 #undef TIO_LE_COORDS4
 #undef TIO_LE_GROUPS
-#ifdef TIO_LE_TIMELINE
-  TIO_LE_MARK(tl_sampled)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores acknowledged)
-  TIO_LE_MARK(tl_stored)
-  if (tid == 0) {
-    unsigned long long* slot = g_le_timeline + (brick & (kTimelineSlots - 1)) * 8;
-    atomicAdd(&slot[0], tl_desc - tl_entry);
-    atomicAdd(&slot[1], tl_issued - tl_desc);
-    atomicAdd(&slot[2], tl_landed - tl_issued);
-    atomicAdd(&slot[3], tl_sampled - tl_landed);
-    atomicAdd(&slot[4], tl_stored - tl_sampled);
-    atomicAdd(&slot[5], 1ull);
-  }
-#endif
 }
 
 }  // namespace tio

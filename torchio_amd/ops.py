@@ -43,9 +43,10 @@ INTERP_CODES = {
 
 PRECISION_CODES = {"exact": _abi.PRECISION_EXACT, "fast": _abi.PRECISION_FAST, "tight": _abi.PRECISION_TIGHT}
 _RESAMPLE_PRECISION = "exact"
+_FAST_OPTED_IN = False  # set_resample_precision("fast", allow_out_of_tolerance=True) was called in this process
 
 
-def set_resample_precision(mode: str) -> None:
+def set_resample_precision(mode: str, *, allow_out_of_tolerance: bool = False) -> None:
     """Process-wide arithmetic of ``tio_resample3d`` for float32 trilinear images.
 
     ``"exact"`` (default) reproduces the reference's float32 operation sequence bit for bit.
@@ -53,20 +54,21 @@ def set_resample_precision(mode: str) -> None:
     the same weights and the same fill decisions — and fuses only the interpolation (three nested fma lerps): results
     within the rounding of seven multiply-adds of the reference, i.e. inside the north-star bar PER VOXEL
     (``|d| <= 1e-4 max(|ref|, 1e-3 range)``) even on white noise.  The mode of the bench's headline.
-    ``"fast"`` — coordinates as a line per control cell: within 1e-4 of the intensity RANGE, not per voxel on noisy data
-    (one ulp of a coordinate already moves a white-noise value by more than the per-voxel bar allows) — lets the float32 trilinear images of a call skip the coordinates' normalise /
-    un-normalise round trip and interpolate with nested fma lerps: the same interpolant, results
-    within ~1e-5 of the exact ones on unit-range data (the contract for intensities is 1e-4
-    relative), ~25 % less kernel time; the fill decision (``mask > 0.5``) of every voxel is the
-    reference's in both modes (voxels within rounding of the threshold are re-decided with the exact
-    coordinate chain).  Label maps resampled with ``"nearest"`` — with or without a fill value
-    (``default_pad_label``) — and ``"label"`` (partial-volume) images are bit-identical to the
-    reference in either mode: they run their own kernels inside the call and no longer hold the float
-    images of the same call back.
+    ``"fast"`` is NOT north-star compliant and is refused unless ``allow_out_of_tolerance=True``: coordinates as a line
+    per control cell, within 1e-4 of the intensity RANGE but not per voxel on noisy data (one ulp of a coordinate already
+    moves a white-noise value by more than the per-voxel bar allows: 4.4 M of 134 M voxels of a bare launch beyond it).
+    It is kept for A/B measurements of the coordinate chain's cost; once a process has opted in, the mode can be
+    re-selected (restoring a saved mode) without repeating the flag.  Label maps resampled with ``"nearest"`` and
+    ``"label"`` (partial-volume) images are bit-identical to the reference in every mode.
     """
-    global _RESAMPLE_PRECISION
+    global _RESAMPLE_PRECISION, _FAST_OPTED_IN
     if mode not in PRECISION_CODES:
         raise ValueError(f"precision must be one of {sorted(PRECISION_CODES)}, got {mode!r}")
+    if mode == "fast":
+        if not (allow_out_of_tolerance or _FAST_OPTED_IN):
+            raise ValueError('resample precision "fast" is outside the per-voxel tolerance (1e-4 relative) on noisy data; '
+                             'pass allow_out_of_tolerance=True to select it for measurements')
+        _FAST_OPTED_IN = True
     _RESAMPLE_PRECISION = mode
 
 
@@ -199,13 +201,27 @@ _DRAWS_IN_FLIGHT = 4
 #   "free"   round 4's behaviour (no gate);
 #   "off"    no draw stream: the draws are made on the data stream, in front of the stencil (the road of round 3).
 # `calibrate_draw_policy` measures the three on the caller's own pipeline and keeps the fastest.
-_DRAW_POLICY = os.environ.get("TIO_DRAW_POLICY", "off")
+_DRAW_POLICIES = ("gated", "free", "off")
+
+
+def _draw_policy_from_env() -> str:
+    """``TIO_DRAW_POLICY`` validated like ``set_draw_policy`` (a typo — "on", "1" — silently behaved as "free")."""
+    value = os.environ.get("TIO_DRAW_POLICY", "off")
+    if value not in _DRAW_POLICIES:
+        raise ValueError(f'TIO_DRAW_POLICY must be one of {_DRAW_POLICIES}, got {value!r}')
+    return value
+
+
+_DRAW_POLICY = _draw_policy_from_env()
 _LAST_RESAMPLE: dict = {}  # (device index, data stream id) -> event recorded behind the latest tio_resample3d launch
 
 
 def set_draw_policy(policy: str) -> None:
+    """Where the draws of the reference's noise stream run (see above).  The library default is ``"off"`` since round 5
+    (round 4 shipped ``"free"``): without a call of ``calibrate_draw_policy`` the reference-noise mode has no draw-stream
+    overlap — and nothing that can contend with the resamplers."""
     global _DRAW_POLICY
-    if policy not in ("gated", "free", "off"):
+    if policy not in _DRAW_POLICIES:
         raise ValueError(f'draw policy must be "gated", "free" or "off", got {policy!r}')
     _DRAW_POLICY = policy
 
@@ -527,7 +543,7 @@ class HostNormalStream:
                 raise EngineError(f"tio_host_mt19937_plan failed with status {status}")
             plan_dev = torch.empty(used.value, dtype=torch.int32, device=device)
             plan_dev.copy_(plan_host[: used.value], non_blocking=True)
-            HostNormalStream._rings().uploaded[id(plan_host)].record()
+            HostNormalStream._rings().uploaded.setdefault(id(plan_host), torch.cuda.Event()).record()
             return plan_host, plan_dev
         finally:
             if ahead is not None:  # from here on the upload event (if any) guards the buffer
@@ -638,15 +654,23 @@ class HostNormalStream:
     @classmethod
     def _ring_buffer(cls, rings: dict, uploaded: dict, size: int, dtype, length: int) -> Tensor:
         ring = rings.setdefault(size, [])
+        lent = cls._rings().lent
         if len(rings) > 4:  # (a few distinct sizes at most: drop the rest)
+            # (never a buffer a native plan job still owns — `_device_plan` records its upload event later; a
+            # ring keeps such buffers and is dropped at a later call)
             for key in [k for k in rings if k != size]:
-                for tensor in rings.pop(key):
-                    uploaded.pop(id(tensor), None)
+                kept = [tensor for tensor in rings[key] if id(tensor) in lent]
+                for tensor in rings[key]:
+                    if id(tensor) not in lent:
+                        uploaded.pop(id(tensor), None)
+                if kept:
+                    rings[key] = kept
+                else:
+                    rings.pop(key)
         # (`query()` is True for an event that was never recorded — a buffer handed to a native plan job by
         # `prefetch_plan` has no recorded upload yet, so a second request of the same size, before the first plan is collected,
         # used to get the SAME buffer: two Noise children of one Compose then shared a plan.  Buffers lent to a job are listed
         # in `lent` until `_device_plan` has recorded their upload.)
-        lent = cls._rings().lent
         for tensor in ring:
             if id(tensor) not in lent and uploaded[id(tensor)].query():
                 return tensor

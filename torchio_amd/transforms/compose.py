@@ -59,14 +59,15 @@ class Compose(Transform):
             # known while the earlier ones are still being enqueued (Noise's seed: the plan of its generator stream, 0.6 - 0.9 ms
             # of host time in the reference-identical noise mode, is computed on a helper thread meanwhile).
             drawn = [transform._draw(batch) for transform in self.transforms]
-            # (children whose preparation runs on a native THREAD go first — Noise: the plan of its generator's stream takes
-            # 0.6 - 0.8 ms of wall time, and every other child's preparation, ~0.25 ms of host work, then runs beside it)
-            for early in (True, False):
-                for transform, params in zip(self.transforms, drawn, strict=True):
-                    if params is not None and bool(getattr(transform, "prefetch_is_threaded", False)) == early:
-                        transform._prefetch(batch, params)
             applying = [(transform, params) for transform, params in zip(self.transforms, drawn, strict=True) if params is not None]
             try:
+                # (children whose preparation runs on a native THREAD go first — Noise: the plan of its generator's stream takes
+                # 0.6 - 0.8 ms of wall time, and every other child's preparation, ~0.25 ms of host work, then runs beside it;
+                # inside the try — a later child's `_prefetch` that raises must not leave the earlier ones' jobs running)
+                for early in (True, False):
+                    for transform, params in applying:
+                        if bool(getattr(transform, "prefetch_is_threaded", False)) == early:
+                            transform._prefetch(batch, params)
                 for index, (transform, params) in enumerate(applying):
                     # the child after this one will ask for the minimum of what this one writes (default_pad_value="minimum"):
                     # a large resampling launch folds it into its stores (ops.expect_minimum_fill)
