@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 14
+#define TIO_ABI_VERSION 15
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -186,16 +186,22 @@ typedef struct tio_resample_geom {
    * the call's kernels have finished; a call that takes another road than the one the plan was made for ignores it. */
   const void* plan_dev;
   int64_t plan_bytes;
-  /* TIO_GEOM_* bits (ABI 14; 0 = none).  TIO_GEOM_LARGE_BOXES: the caller, who holds the mappings on the host, expects the
-   * input boxes of most 16^3 output bricks to exceed the staging tile of the planned roads (rotations beyond ~12 degrees about
-   * all three axes, strong zooms: a brick whose box does not fit samples voxel by voxel from global memory there — 3 x the
-   * time).  The call then takes the brick kernels with in-kernel boxes, which split such a brick into two or four passes
-   * over its planes (resample_tile.hpp).  A hint about speed only: every road computes the same values in the exact
-   * modes and stays within the FAST mode's tolerance otherwise. */
+  /* TIO_GEOM_* bits (ABI 14; 0 = none).  Hints of a caller who holds the mappings on the host, about SPEED only: every road
+   * computes the same values in the exact modes and stays within its mode's tolerance otherwise.
+   * TIO_GEOM_LARGE_BOXES: the input boxes of SOME 16^3 output bricks are expected to exceed the staging tile of the planned
+   * roads (an element rotated beyond ~12 degrees about all three axes, a strong zoom).  Without the hint such a brick samples
+   * voxel by voxel from global memory (3.5 x the time; fine for the odd brick).  With it (ABI 15) the exact-coordinate lean
+   * kernels — TIO_PRECISION_EXACT / TIGHT, large float32 launches — have the planner bound such bricks again in halves /
+   * quarters of their planes and list them; a second kernel behind the first walks the list and stages each brick in two or
+   * four passes (~6 - 15 us per launch when the list is short: why it is a hint).  FAST launches take the brick kernels with
+   * in-kernel boxes, which split such a brick likewise (resample_tile.hpp).
+   * TIO_GEOM_MOSTLY_LARGE_BOXES (ABI 15): MOST bricks are expected to — the pass logic then runs in every block of ONE launch
+   * (no list, no second kernel; its one-pass bricks cost 2 - 7 % more than without the hint). */
   int32_t flags;
 } tio_resample_geom;
 
 #define TIO_GEOM_LARGE_BOXES 1
+#define TIO_GEOM_MOSTLY_LARGE_BOXES 2
 
 /* One image tensor resampled with the shared geometry
  * (_resample_image_batch, spatial.py:1194-1272; _sample_batch_grid_sample,

@@ -148,6 +148,7 @@ struct Case {
   std::vector<Image> images;
   std::vector<uint8_t> cp_skip, passthrough;
   bool half_shift = false;  // identity mapping shifted by exactly half a voxel: every nearest index is a tie
+  int large_boxes = 0;  // the caller's hint (tio_hip.h): 1 = TIO_GEOM_LARGE_BOXES (some bricks' boxes beyond the tile: listed, staged in passes), 2 = TIO_GEOM_MOSTLY_LARGE_BOXES
 };
 
 static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
@@ -168,6 +169,7 @@ static void fill_random(std::vector<uint8_t>& buf, int dtype, size_t n) {
   }
 }
 
+static double g_hint_from = 12.0;
 struct Paths { const char* name; const char* path; const char* variant; int precision; const char* kernel; const char* v2; };
 static const Paths kPaths[] = {
     {"gather", "gather", "0", 0, nullptr, nullptr}, {"tile16x16x16", "tile", "0", 0, nullptr, nullptr}, {"tile16x8x32", "tile", "1", 0, nullptr, nullptr},
@@ -347,6 +349,7 @@ static int run_case(Case& cs, int reps, bool check_oracle, bool time_it) {
     setenv("TIO_NEAREST_KERNEL", p == 0 ? "0" : "1", 1);  // the baseline keeps nearest images on the gather kernel's exact chain
     tio_reload_env();  // (the library parses its switches once per process otherwise)
     geom.precision = kPaths[p].precision;
+    geom.flags = p == 0 ? 0 : (cs.large_boxes == 2 ? TIO_GEOM_MOSTLY_LARGE_BOXES : (cs.large_boxes == 1 ? TIO_GEOM_LARGE_BOXES : 0));
     // a FAST call samples its float32 trilinear images within 1e-4 when every other image of the call has a kernel of its
     // own (nearest without a fill rule: resample_nearest.hpp, bit-exact); any other image pins the exact kernels for all
     bool fast_set = true;
@@ -462,6 +465,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--path") && i + 1 < argc) g_path_filter = argv[++i];
     else if (!strcmp(argv[i], "--ablate") && i + 1 < argc) setenv("TIO_TILE_ABLATE", argv[++i], 1);
     else if (!strcmp(argv[i], "--lds") && i + 1 < argc) setenv("TIO_TILE_LDS_FLOATS", argv[++i], 1);
+    else if (!strcmp(argv[i], "--hint-from") && i + 1 < argc) g_hint_from = atof(argv[++i]);  // geometry cases: TIO_GEOM_LARGE_BOXES from this many degrees (< 0: never)
   }
   if (tio_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
   int failures = 0;
@@ -483,6 +487,17 @@ int main(int argc, char** argv) {
       Case c = make_case("far-out f32 linear nofill", 2, 64, 48, 96, true, false);
       c.max_deg = 40; c.shift = 30; c.scale_dev = 0.4;
       c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, false});
+      failures += run_case(c, 1, true, false);
+    }
+    // round 6: the same far-out geometries, and one with partial bricks on every axis, under the caller's hint
+    // TIO_GEOM_LARGE_BOXES — boxes beyond the tile are staged in two / four passes over the brick's planes (lean-exact / tight
+    // paths; parts that still do not fit, or see nothing of the volume, take their own roads inside the brick)
+    for (int variant = 0; variant < 4; variant++) {
+      const char* names[4] = {"multi-pass far-out f32 fill", "multi-pass far-out f32 nofill elastic", "multi-pass odd shape f32 fill 2ch", "multi-pass 45 deg f32 fill"};
+      Case c = variant == 2 ? make_case(names[variant], 2, 72, 52, 88, true, true) : make_case(names[variant], 2, 64, 48, 96, true, variant == 1);
+      c.max_deg = variant == 3 ? 45 : 40; c.shift = variant == 3 ? 3 : 30; c.scale_dev = variant == 3 ? 0.05 : 0.4;
+      c.large_boxes = 1 + (variant & 1);
+      c.images.push_back(Image{variant == 2 ? 2 : 1, TIO_F32, TIO_LINEAR, variant != 1});
       failures += run_case(c, 1, true, false);
     }
     {  // multi-modal subject: 2 x f32 linear + int16 labels nearest, per-instance, flags
@@ -626,6 +641,21 @@ int main(int argc, char** argv) {
       c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
       c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
       c.images.push_back(Image{1, TIO_I16, TIO_NEAREST, false});
+      failures += run_case(c, reps, false, true);
+    }
+  }
+  if (cases == "geometry") {
+    // round 6: the same launch over geometries that change the size of a brick's input box — a pure translation (the
+    // smallest box a brick can have: what more resident blocks per CU would buy, with --lds), the bench's ranges, and
+    // rotations beyond them (boxes beyond the tile: what the multi-pass form is for)
+    const double degs[] = {0.0, 10.0, 15.0, 20.0, 30.0, 45.0};
+    for (double deg : degs) {
+      char name[64];
+      snprintf(name, sizeof name, "affine f32 fill %2.0f deg", deg);
+      Case c = make_case(name, batch, size, size, size, true, false);
+      c.max_deg = deg; if (deg == 0.0) c.scale_dev = 0.0;
+      c.large_boxes = (g_hint_from >= 0.0 && deg >= g_hint_from) ? (deg >= g_hint_from + 6.0 ? 2 : 1) : 0;  // (the host layer's estimate: some from ~12 degrees, most from ~18)
+      c.images.push_back(Image{1, TIO_F32, TIO_LINEAR, true});
       failures += run_case(c, reps, false, true);
     }
   }

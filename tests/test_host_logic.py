@@ -927,34 +927,42 @@ def _rotation_mapping(degrees, zoom=1.0) -> np.ndarray:
 
 
 def test_large_box_hint_follows_the_planner_arithmetic():
-    """transforms/spatial.py `_expects_large_boxes` (TIO_GEOM_LARGE_BOXES, ABI 14): the box of a 16^3 brick under the mapping, in
-    floats, against the planned roads' staging tile — False over the bench's parameter ranges (calibrated against the planner's
-    own descriptors on the GPU: scripts/r5_box_estimate.py), True where most bricks of a quarter of the elements cannot be staged."""
+    """transforms/spatial.py `_expects_large_boxes` (TIO_GEOM_LARGE_BOXES / TIO_GEOM_MOSTLY_LARGE_BOXES, ABI 15): the box of a 16^3
+    brick under the mapping, in floats, against the planned roads' staging tile — 0 over the bench's parameter ranges (calibrated
+    against the planner's own descriptors on the GPU: scripts/r5_box_estimate.py), 1 as soon as ONE element's boxes exceed the
+    tile (round 6: per element, the listed bricks are staged in passes behind the launch), 2 where most elements' do."""
     from torchio_amd.transforms.spatial import _expects_large_boxes
 
     shape, spacing = (256, 256, 256), (1.0, 1.0, 1.0)
-    assert not _expects_large_boxes(None, None, None, shape, spacing)  # (the identity mapping is not even materialised)
-    assert not _expects_large_boxes(_rotation_mapping((0, 0, 0)), None, None, shape, spacing)
-    assert not _expects_large_boxes(_rotation_mapping((10, 10, 10)), None, None, shape, spacing)  # the bench's largest rotation (measured: staged)
-    assert _expects_large_boxes(_rotation_mapping((25, 25, 25)), None, None, shape, spacing)
-    assert _expects_large_boxes(_rotation_mapping((0, 0, 0), 2.0), None, None, shape, spacing)  # downsampling by two: 31-voxel boxes
-    # a launch-level choice: one large element in eight stays on the planned road, two do not
-    small, large = _rotation_mapping((5, 5, 5)), _rotation_mapping((25, 25, 25))
-    assert not _expects_large_boxes(np.concatenate([large] + [small] * 7), None, None, shape, spacing)
-    assert _expects_large_boxes(np.concatenate([large] * 2 + [small] * 6), None, None, shape, spacing)
-    # the displacement field's share: the bench's 7^3 control points / 7.5 mm do not tip a 10-degree launch over
-    assert not _expects_large_boxes(_rotation_mapping((10, 10, 10)), [(7.5, 7.5, 7.5)], (7, 7, 7), shape, spacing)
-    # the bench's draws: never
+    assert _expects_large_boxes(None, None, None, shape, spacing) == 0  # (the identity mapping is not even materialised)
+    assert _expects_large_boxes(_rotation_mapping((0, 0, 0)), None, None, shape, spacing) == 0
+    assert _expects_large_boxes(_rotation_mapping((10, 10, 10)), None, None, shape, spacing) == 0  # the bench's largest rotation (measured: staged)
+    assert _expects_large_boxes(_rotation_mapping((25, 25, 25)), None, None, shape, spacing) == 2
+    assert _expects_large_boxes(_rotation_mapping((0, 0, 0), 2.0), None, None, shape, spacing) == 2  # downsampling by two: 31-voxel boxes
+    assert _expects_large_boxes(_rotation_mapping((0, 0, 180)), None, None, shape, spacing) == 0  # half a turn about one axis: the boxes of the identity
+    # per ELEMENT: one large element in eight is enough for the list, most of them for the one-launch form
+    small, large = _rotation_mapping((5, 5, 5)), _rotation_mapping((30, 30, 30))
+    assert _expects_large_boxes(np.concatenate([large] + [small] * 7), None, None, shape, spacing) == 1
+    assert _expects_large_boxes(np.concatenate([large] * 3 + [small] * 5), None, None, shape, spacing) == 1
+    assert _expects_large_boxes(np.concatenate([large] * 4 + [small] * 4), None, None, shape, spacing) == 2
+    # the displacement field's share: the bench's 7^3 control points / 7.5 mm on top of its LARGEST rotation list some bricks
+    # (the fused tio.Spatial's 2 % that sampled voxel by voxel until round 5), on top of a typical one nothing
+    assert _expects_large_boxes(_rotation_mapping((10, 10, 10)), [(7.5, 7.5, 7.5)], (7, 7, 7), shape, spacing) == 1
+    assert _expects_large_boxes(_rotation_mapping((6, 6, 6)), [(7.5, 7.5, 7.5)], (7, 7, 7), shape, spacing) == 0
+    # the bench's draws: never "most"
     transform = tio.Spatial(degrees=(-10, 10), scales=(0.9, 1.1), translation=(-5, 5), max_displacement=7.5, per_instance=True)
     batch = tio.SubjectsBatch.from_subjects(make_subjects(16, 8, 1, with_label=False))
     from torchio_amd.transforms import spatial as sp
 
+    affine_only = 0
     for seed in range(20):
         torch.manual_seed(seed)
         params = transform.make_params(batch)
         matrix, field, displacement, per_sample = sp._resolve_spatial_params(params)
         matrices = np.stack([np.linalg.inv(np.asarray(m, dtype=np.float64))[:3] for m in per_sample.affine_matrices]).astype(np.float32)
-        assert not _expects_large_boxes(matrices, per_sample.max_displacements, (7, 7, 7), shape, spacing), seed
+        assert _expects_large_boxes(matrices, per_sample.max_displacements, (7, 7, 7), shape, spacing) <= 1, seed
+        affine_only += _expects_large_boxes(matrices, None, None, shape, spacing)
+    assert affine_only <= 2  # (the headline's Affine launch, 16 elements per draw: a zoom-out of 1.1 on top of ~9 degrees — one draw in twenty)
 
 
 def test_large_box_hint_reaches_the_geometry_struct():

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_IMAGES = 8
 
 # tio_status
@@ -24,7 +24,8 @@ BSPLINE4, BSPLINE5, BSPLINE6, BSPLINE7 = 6, 7, 8, 9  # B-spline orders 4 - 7 ("f
 PAD_CONSTANT, PAD_REFLECT, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2, 3
 # tio_precision
 PRECISION_EXACT, PRECISION_FAST, PRECISION_TIGHT = 0, 1, 2
-GEOM_LARGE_BOXES = 1  # tio_resample_geom.flags (ABI 14)
+GEOM_LARGE_BOXES = 1  # tio_resample_geom.flags (ABI 14): SOME bricks' boxes exceed the staging tile
+GEOM_MOSTLY_LARGE_BOXES = 2  # (ABI 15): MOST do
 
 
 class ResampleGeom(C.Structure):

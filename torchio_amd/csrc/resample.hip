@@ -74,6 +74,7 @@ struct ResampleArgs {
   int ablate;    // profiling only (TIO_TILE_ABLATE): 1 = no staging, 2 = no sampling, 4 = trivial coordinates
   int dma_packed;  // planned bricks: DMA instructions cover rows across x-plane boundaries (A/B: TIO_DMA_PACKED=0)
   int any_fill;      // an image of the launch has a fill rule
+  int plan_multi;    // plan_bricks_kernel: bricks whose box exceeds the tile get pass boxes over halves / quarters of their planes (the exact-coordinate lean kernel reads them)
   int fill_recheck;  // FAST kernels: voxels whose in-bounds weight is within a margin of 1/2 take the exact chain's decision (A/B: TIO_FAST_FILL_RECHECK=0)
 };
 
@@ -654,6 +655,8 @@ static PlanLease plan_workspace(hipStream_t s, size_t bytes) {
       slot->ptr = nullptr; slot->cap = 0;
     }
     if (hipMalloc(&slot->ptr, bytes) != hipSuccess) { slot->ptr = nullptr; return lease; }
+    // (the first tio::kPlanHeaderInts ints: the multi-pass bricks' list header — zero between launches, see resample_lean_exact_kernel)
+    if (hipMemsetAsync(slot->ptr, 0, tio::kPlanHeaderInts * sizeof(int), s) != hipSuccess) { (void)hipFree(slot->ptr); slot->ptr = nullptr; return lease; }
     slot->cap = bytes;
   }
   lease.ptr = slot->ptr;
@@ -953,7 +956,8 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       for (int i = 0; i < a.n_images; i++) planned = planned && (reinterpret_cast<uintptr_t>(a.img[i].in) & 15) == 0;
       // the caller expects boxes beyond the staging tile (tio_hip.h: TIO_GEOM_LARGE_BOXES): a planned brick whose box does not fit
       // samples voxel by voxel from global memory, the brick kernels below split it into passes over its planes
-      if ((geom->flags & TIO_GEOM_LARGE_BOXES) != 0 && !force_planned) planned = false;
+      // (round 6: the exact-coordinate lean road stages such bricks in passes itself — the hint only sends FAST launches elsewhere)
+      if ((geom->flags & (TIO_GEOM_LARGE_BOXES | TIO_GEOM_MOSTLY_LARGE_BOXES)) != 0 && !force_planned && !lean_exact) planned = false;
       if (planned && a.cp != nullptr) {
         const int n_ctl[3] = {a.ni, a.nj, a.nk}, n_vox[3] = {a.Io, a.Jo, a.Ko};
         for (int d = 0; d < 3; d++)
@@ -978,7 +982,16 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         // round 3: DMA instructions that cover rows across x-plane boundaries (resample_fast.hpp: stream_stage_packed);
         // TIO_DMA_PACKED=0 switches them off in the general kernel (A/B)
         a.dma_packed = env.dma_packed;
-        const size_t plan_need = (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int);
+        // (the exact-coordinate kernel stages bricks whose box exceeds the tile in passes over their planes: pass boxes behind the descriptors)
+        // — on the hint of a caller who holds the mappings (TIO_GEOM_LARGE_BOXES): the second kernel sits BEHIND the first on the stream,
+        // ~6 - 15 us that a launch without such bricks should not pay (measured +0 ... +3.7 % on the bench's launches when it was
+        // unconditional: profiles/r06_resample.md); without the hint such bricks sample voxel by voxel, as until round 5
+        // (TIO_GEOM_MOSTLY_LARGE_BOXES: plan_multi = 2 — every block of ONE launch runs the body with the pass switches, nothing is listed)
+        a.plan_multi = (lean_exact && env.lean_multi != 0) ? ((geom->flags & TIO_GEOM_MOSTLY_LARGE_BOXES) != 0 ? 2 : ((geom->flags & TIO_GEOM_LARGE_BOXES) != 0 ? 1 : 0)) : 0;
+        // [header: kPlanHeaderInts ints] [B x 16 floats] [n_items descriptors] ( [n_items x 4 pass boxes] [the list of multi-pass bricks] )
+        const size_t plan_list_at = static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * (kDescInts + kPassInts * kPassesPerBrick);  // (ints behind the header)
+        const size_t plan_need = (kPlanHeaderInts + (a.plan_multi ? plan_list_at + ((static_cast<size_t>(n_items) + 3) & ~static_cast<size_t>(3))
+                                                                    : static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts)) * sizeof(int);
         if (mode == kPlanQuery) { *plan_bytes = static_cast<int64_t>(plan_need); return TIO_OK; }
         PlanLease lease;
         int* plan = nullptr;
@@ -986,20 +999,24 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         if (mode == kPlanOnly) {
           if (plan_out == nullptr || plan_out_bytes < static_cast<int64_t>(plan_need) || (reinterpret_cast<uintptr_t>(plan_out) & 15) != 0)
             return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d_plan: the plan needs %zu bytes, 16-byte aligned", plan_need);
-          plan = plan_out;
+          plan = plan_out + kPlanHeaderInts;
         } else if (geom->plan_dev != nullptr && geom->plan_bytes >= static_cast<int64_t>(plan_need) &&
                    (reinterpret_cast<uintptr_t>(geom->plan_dev) & 15) == 0) {
-          plan = static_cast<int*>(const_cast<void*>(geom->plan_dev));  // made ahead by tio_resample3d_plan: no planning kernel on this stream
+          plan = static_cast<int*>(const_cast<void*>(geom->plan_dev)) + kPlanHeaderInts;  // made ahead by tio_resample3d_plan: no planning kernel on this stream
           planned_ahead = true;
         } else {
           lease = plan_workspace(s, plan_need);
-          plan = lease.ptr;  // (the lease is released when this function returns: after both kernels are enqueued)
-          if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+          if (lease.ptr == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+          plan = lease.ptr + kPlanHeaderInts;  // (the lease is released when this function returns: after both kernels are enqueued)
         }
         if (!planned_ahead) {
           const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick
           const int plan_threads = n_items * plan_lanes > a.B ? n_items * plan_lanes : a.B;
           const dim3 plan_grid((plan_threads + 255) / 256);
+          // the header of the multi-pass bricks' list (length, cursor, done count) is zero between launches: the leased workspace is
+          // zeroed when it is allocated and the last walker of a launch leaves zeros; a caller's buffer is zeroed here
+          if (a.plan_multi && mode == kPlanOnly && hipMemsetAsync(plan - kPlanHeaderInts, 0, kPlanHeaderInts * sizeof(int), s) != hipSuccess)
+            return fail(TIO_ERR_LAUNCH, "tio_resample3d_plan: cannot reset the brick plan");
           if (a.cp != nullptr) hipLaunchKernelGGL((plan_bricks_kernel<true, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
           else hipLaunchKernelGGL((plan_bricks_kernel<false, 16, 16, 16>), plan_grid, dim3(256), 0, s, a, plan, n_items);
         }
@@ -1069,9 +1086,33 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
             kernel = a.cp != nullptr ? resample_planned_lean_kernel<true, 16, 16, 16, 3, false, true> : resample_planned_lean_kernel<false, 16, 16, 16, 3, false, true>;
           const size_t lds_launch = lds_p;
           const unsigned grid_launch = static_cast<unsigned>(n_items), block_launch = 256;
-          if (lds_launch > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      static_cast<int>(lds_launch)) != hipSuccess)
+          // ... and, behind an exact-coordinate launch, the kernel whose blocks walk the planner's list of multi-pass bricks (boxes beyond
+          // the tile: staged in halves / quarters of their planes) — three per CU, leaving at once when the list is empty
+          auto kernel_multi = a.cp != nullptr ? resample_lean_exact_multi_kernel<true, false> : resample_lean_exact_multi_kernel<false, false>;
+          if (a.plan_multi == 1) {
+            if (tight) {
+              if (min_channels > 0) kernel_multi = a.cp != nullptr ? resample_lean_exact_multi_kernel<true, false, true> : resample_lean_exact_multi_kernel<false, false, true>;
+            } else if (min_channels > 0) {
+              kernel_multi = a.cp != nullptr ? resample_lean_exact_multi_kernel<true, true, true> : resample_lean_exact_multi_kernel<false, true, true>;
+            } else {
+              kernel_multi = a.cp != nullptr ? resample_lean_exact_multi_kernel<true, true> : resample_lean_exact_multi_kernel<false, true>;
+            }
+          }
+          if (a.plan_multi == 2) {  // most bricks need passes: ONE launch of the body that knows them
+            if (tight) kernel = min_channels > 0 ? (a.cp != nullptr ? resample_lean_exact_all_kernel<true, false, true> : resample_lean_exact_all_kernel<false, false, true>)
+                                                 : (a.cp != nullptr ? resample_lean_exact_all_kernel<true, false> : resample_lean_exact_all_kernel<false, false>);
+            else kernel = min_channels > 0 ? (a.cp != nullptr ? resample_lean_exact_all_kernel<true, true, true> : resample_lean_exact_all_kernel<false, true, true>)
+                                           : (a.cp != nullptr ? resample_lean_exact_all_kernel<true, true> : resample_lean_exact_all_kernel<false, true>);
+          }
+          const bool walk_list = a.plan_multi == 1;
+          const unsigned grid_multi = static_cast<unsigned>(std::min<int64_t>(n_items, 3 * 256));
+          if (lds_launch > 48 * 1024 && (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             static_cast<int>(lds_launch)) != hipSuccess ||
+                                         (walk_list && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                              static_cast<int>(lds_launch)) != hipSuccess)))
             return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_launch);
+          int launches_left = 0;
+          for (int i = 0; i < a.n_images; i++) launches_left += a.img[i].channels;
           // one plan, one launch per channel of every image (the geometry, hence the plan, is shared)
           for (int i = 0; i < a.n_images; i++) {
             const ImgArgs& g = a.img[i];
@@ -1082,7 +1123,9 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
               la.out = static_cast<float*>(g.out) + static_cast<int64_t>(c) * n_out;
               la.fill = g.fill != nullptr ? g.fill + c : nullptr;
               la.min_keys = (min_channels > 0 && g.min_keys != nullptr) ? g.min_keys + c * kMinSlots : nullptr;
+              la.last_use = --launches_left == 0;
               hipLaunchKernelGGL(kernel, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
+              if (walk_list) hipLaunchKernelGGL(kernel_multi, dim3(grid_multi), dim3(block_launch), lds_launch, s, la);
             }
           }
           if (min_channels > 0)
@@ -1127,22 +1170,24 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
         const int64_t items64 = static_cast<int64_t>(a.B) * a.tiles_i * a.tiles_j * a.tiles_k;
         if (items64 < (1LL << 26)) {
           const int n_items = static_cast<int>(items64);
-          const size_t plan_need = (static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int);
+          // (every plan starts behind kPlanHeaderInts ints — the list header of the exact-coordinate lean road, which shares the leased
+          // workspace of the stream with this one and must find it zero)
+          const size_t plan_need = (kPlanHeaderInts + static_cast<size_t>(a.B) * 16 + static_cast<size_t>(n_items) * kDescInts) * sizeof(int);
           if (mode == kPlanQuery) { *plan_bytes = static_cast<int64_t>(plan_need); return TIO_OK; }
           int* plan = nullptr;
           bool planned_ahead = false;
           if (mode == kPlanOnly) {
             if (plan_out == nullptr || plan_out_bytes < static_cast<int64_t>(plan_need) || (reinterpret_cast<uintptr_t>(plan_out) & 15) != 0)
               return fail(TIO_ERR_INVALID_ARGUMENT, "tio_resample3d_plan: the plan needs %zu bytes, 16-byte aligned", plan_need);
-            plan = plan_out;
+            plan = plan_out + kPlanHeaderInts;
           } else if (geom->plan_dev != nullptr && geom->plan_bytes >= static_cast<int64_t>(plan_need) &&
                      (reinterpret_cast<uintptr_t>(geom->plan_dev) & 15) == 0) {
-            plan = static_cast<int*>(const_cast<void*>(geom->plan_dev));
+            plan = static_cast<int*>(const_cast<void*>(geom->plan_dev)) + kPlanHeaderInts;
             planned_ahead = true;
           } else {
             exact_lease = plan_workspace(s, plan_need);
-            plan = exact_lease.ptr;
-            if (plan == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+            if (exact_lease.ptr == nullptr) return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot allocate the brick plan");
+            plan = exact_lease.ptr + kPlanHeaderInts;
           }
           if (!planned_ahead) {
             const int plan_lanes = plan_group(a.cp != nullptr);  // lanes per brick

@@ -517,7 +517,41 @@ __device__ __forceinline__ void pipe_vertex(const ResampleArgs& a, const FastFra
 //   brick:  [0] kind | interior << 8   [1] bx0 [2] by0 [3] za [4] Lx [5] Ly [6] cpr   [7..9] C3 (float bits): the mapping
 //           of (i_begin, j_lo, k_lo) relative to the box origin   [10] b [11] i_begin [12] j_lo [13] k_lo [14] elastic
 //   batch:  [0..11] mapping rows scaled by the axis ratios (S_own - 1) / max(S_norm - 1, 1)   [12] margin of the fill decision
+// Round 6 (a.plan_multi, the exact-coordinate lean kernel only): a brick whose box exceeds the tile is bounded again in HALVES,
+// then QUARTERS, of its planes.  kind = kDescMulti, [1..6] = the box of pass 0, [15] = passes | state of pass q << (8 + 4 q), and the
+// boxes of ALL passes follow the descriptors: kPassInts ints per pass, 4 passes per brick, at plan + B 16 + n_items 16 +
+// brick 32:  [0] bx0 [1] by0 [2] za [3] Lx [4] Ly [5] cpr [6] state (kPassStaged / kPassOutside / kPassSlow) | interior << 8
+// [7] planes.  A pass that still does not fit samples its planes voxel by voxel; the others stage their box one after the other.
+// Behind the pass boxes: the LIST of these bricks, which the walker blocks of resample_lean_exact_kernel take bricks from; its
+// header — [0] their number, [1] / [2] the walkers' cursor and done count — sits in FRONT of the plan (plan[-kPlanHeaderInts ...]:
+// one place whatever the launch's size, zero between launches).
 // =====================================================================================================================
+enum : int { kPlanHeaderInts = 16, kDescMulti = 4, kPassInts = 8, kPassesPerBrick = 4, kPassStaged = 0, kPassOutside = 1, kPassSlow = 2 };
+
+// the integer box of extremes `ext` (butterfly-reduced: identical in every lane of the group)
+struct PlanBox {
+  int xmin, ymin, za, Lx, Ly, cpr, interior, outside, fits;
+};
+__device__ __forceinline__ PlanBox plan_box(const ResampleArgs& a, const int (&ext)[7], bool weird) {
+  PlanBox pb;
+  const int xmin = -ext[0], xmax = ext[1], ymin = -ext[2], ymax = ext[3], zmin = -ext[4], zmax = ext[5];
+  const bool wrd = weird | (ext[6] != 0);
+  pb.interior = (xmin >= 0) & (xmax + 1 <= a.I - 1) & (ymin >= 0) & (ymax + 1 <= a.J - 1) & (zmin >= 0) & (zmax + 1 <= a.K - 1) & !wrd;
+  pb.outside = ((xmax + 1 < 0) | (xmin > a.I - 1) | (ymax + 1 < 0) | (ymin > a.J - 1) | (zmax + 1 < 0) | (zmin > a.K - 1)) & !wrd;
+  pb.za = zmin & ~3; pb.Lx = xmax + 2 - xmin; pb.Ly = ymax + 2 - ymin;
+  const int Lz = ((zmax + 1 + 4) & ~3) - pb.za;
+  pb.fits = !wrd && (Lz <= 256) && (pb.Lx <= 4096) && (pb.Ly <= 4096) && (static_cast<int64_t>(pb.Lx) * pb.Ly * Lz <= static_cast<int64_t>(a.tile_cap));
+  pb.xmin = xmin; pb.ymin = ymin; pb.cpr = Lz >> 2;
+  return pb;
+}
+// ... of a PASS of a multi-pass brick: the consumer (resample_lean_exact_kernel) takes the planner's word for these, so the
+// conditions it re-checks for a one-pass box — the tap addresses formed from absolute indices stay exact in float32
+// (box_address_fits, resample_tile.hpp) — are decided here
+__device__ __forceinline__ PlanBox plan_pass_box(const ResampleArgs& a, const int (&ext)[7], bool weird) {
+  PlanBox pb = plan_box(a, ext, weird);
+  if (pb.fits && !box_address_fits(pb.xmin, pb.ymin, pb.za, pb.Lx, pb.Ly, pb.cpr)) pb.fits = 0;
+  return pb;
+}
 // A group of lanes per brick, one vertex per lane: 32 lanes (27 busy) when the launch has control points — a vertex then
 // reads 24 control values, and one thread walking its 27 vertices one after the other made the planner a chain of 27
 // memory round trips (21.6 us per bench launch; side by side 16.4) — 8 lanes for affine-only launches (5.8 us either
@@ -539,7 +573,8 @@ __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, 
       fr[12] = fast_fill_margin(mm, static_cast<float>(a.Io), static_cast<float>(a.Jo), static_cast<float>(a.Ko), a.size_m1[0] + 1.0f,
                                 a.size_m1[1] + 1.0f, a.size_m1[2] + 1.0f);
     }
-    for (int q = 13; q < 16; q++) fr[q] = 0.0f;
+    fr[13] = __int_as_float(a.tile_cap);  // (the tile the boxes were sized for: the consumer of a multi-pass brick compares it with its own)
+    for (int q = 14; q < 16; q++) fr[q] = 0.0f;
   }
   const int t = gtid / GROUP, v = gtid % GROUP;
   if (t >= n_items) return;  // (whole groups leave together: the shuffles below stay inside a group)
@@ -585,17 +620,59 @@ __global__ __launch_bounds__(256) void plan_bricks_kernel(const ResampleArgs a, 
 #pragma unroll
     for (int q = 0; q < 7; q++) ext[q] = max(ext[q], __shfl_xor(ext[q], s));
   }
-  if (v != 0) return;
-  d[10] = p.b; d[11] = p.i_begin; d[12] = p.j_lo; d[13] = p.k_lo; d[15] = 0;
-  const int xmin = -ext[0], xmax = ext[1], ymin = -ext[2], ymax = ext[3], zmin = -ext[4], zmax = ext[5];
+  // (the butterfly leaves the extremes in EVERY lane of the group: the decisions below are uniform across it)
+  const PlanBox whole = plan_box(a, ext, weird);
   const bool wrd = weird | (ext[6] != 0);
-  const int interior = (xmin >= 0) & (xmax + 1 <= a.I - 1) & (ymin >= 0) & (ymax + 1 <= a.J - 1) & (zmin >= 0) & (zmax + 1 <= a.K - 1) & !wrd;
-  const int outside = ((xmax + 1 < 0) | (xmin > a.I - 1) | (ymax + 1 < 0) | (ymin > a.J - 1) | (zmax + 1 < 0) | (zmin > a.K - 1)) & !wrd;
-  const int za = zmin & ~3, Lx = xmax + 2 - xmin, Ly = ymax + 2 - ymin, Lz = ((zmax + 1 + 4) & ~3) - za;
-  const bool fits = !wrd && (Lz <= 256) && (Lx <= 4096) && (Ly <= 4096) && (static_cast<int64_t>(Lx) * Ly * Lz <= static_cast<int64_t>(a.tile_cap));
-  d[0] = (outside ? kDescOutside : (fits ? kDescStaged : kDescSlow)) | (interior << 8);
-  d[1] = xmin; d[2] = ymin; d[3] = za; d[4] = Lx; d[5] = Ly; d[6] = Lz >> 2;
-  const double org[3] = {static_cast<double>(xmin), static_cast<double>(ymin), static_cast<double>(za)};
+  int kind = whole.outside ? kDescOutside : (whole.fits ? kDescStaged : kDescSlow);
+  PlanBox first = whole;
+  int d15 = 0;
+  if (a.plan_multi != 0 && kind == kDescSlow && !wrd) {
+    // the box exceeds the tile: halves of the planes, else quarters (pass boxes behind the descriptors)
+    int* passes = plan + a.B * 16 + n_items * kDescInts + t * (kPassInts * kPassesPerBrick);
+    for (int nsplit = 2; nsplit <= 4; nsplit *= 2) {
+      const int span = TI / nsplit;
+      bool all_ok = true;
+      for (int q = 0; q < nsplit; q++) {
+        const int u0 = p.i_begin + q * span, n = min(span, p.i_begin + p.i_count - u0);
+        int e7[7] = {-0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, -0x40000000, 0};
+        if (v < n_vert && n > 0) {
+          int r[6]; bool bad;
+          pipe_vertex(a, f, v, u0, n, p.nv, p.nw, r, bad);
+#pragma unroll
+          for (int c = 0; c < 6; c++) e7[c] = r[c];
+          e7[6] = bad ? 1 : 0;
+        }
+#pragma unroll
+        for (int sft = GROUP / 2; sft > 0; sft >>= 1) {
+#pragma unroll
+          for (int c = 0; c < 7; c++) e7[c] = max(e7[c], __shfl_xor(e7[c], sft));
+        }
+        PlanBox pb = plan_pass_box(a, e7, weird);
+        if (n <= 0) { pb.outside = 1; pb.fits = 0; pb.interior = 0; }  // (no plane of a partial brick in this part: nothing to do)
+        all_ok &= (pb.fits | pb.outside) != 0;
+        const int state = pb.outside ? kPassOutside : (pb.fits ? kPassStaged : kPassSlow);
+        if (q == 0) { first = pb; d15 = nsplit; }
+        d15 |= state << (8 + 4 * q);
+        if (v == 0) {
+          int* r8 = passes + q * kPassInts;
+          r8[0] = pb.xmin; r8[1] = pb.ymin; r8[2] = pb.za; r8[3] = pb.Lx; r8[4] = pb.Ly; r8[5] = pb.cpr;
+          r8[6] = state | (pb.interior << 8); r8[7] = max(n, 0);
+        }
+      }
+      kind = kDescMulti;
+      if (all_ok) break;
+    }
+  }
+  if (v != 0) return;
+  if (kind == kDescMulti && a.plan_multi == 1) {  // ... and listed for the walker blocks of resample_lean_exact_kernel: [0] the count (left at zero by the last launch that read this buffer), [4 ...] the bricks
+    int* list = plan + a.B * 16 + n_items * (kDescInts + kPassInts * kPassesPerBrick);
+    const int at = atomicAdd(plan - kPlanHeaderInts, 1);
+    if (at < n_items) list[at] = t;
+  }
+  d[10] = p.b; d[11] = p.i_begin; d[12] = p.j_lo; d[13] = p.k_lo; d[15] = d15;
+  d[0] = kind | (first.interior << 8);
+  d[1] = first.xmin; d[2] = first.ymin; d[3] = first.za; d[4] = first.Lx; d[5] = first.Ly; d[6] = first.cpr;
+  const double org[3] = {static_cast<double>(first.xmin), static_cast<double>(first.ymin), static_cast<double>(first.za)};
 #pragma unroll
   for (int r = 0; r < 3; r++) d[7 + r] = __float_as_int(static_cast<float>(static_cast<double>(f.m[4 * r]) * p.i_begin + f.c[r] - org[r]));
   d[14] = f.elastic ? 1 : 0;
@@ -853,6 +930,7 @@ struct LeanArgs {
   float dh[3], rdh[3], half_h[3];
   int interleave;
   int tile_floats;  // floats of ONE staging tile of this launch (the planner's tile_cap)
+  int last_use;     // resample_lean_exact_multi_kernel: this launch is the last one that reads the plan (the last walker zeroes the list's length)
   // the folded minimum (tio_resample_image.out_min_dev): kMinSlots keys of this channel, or nullptr.  Only the bricks of batch
   // element 0 track what they store (a block-uniform branch into the TRACK instantiation of the sampling loop).
   uint32_t* min_keys;

@@ -140,6 +140,39 @@ __device__ __forceinline__ void lean_exact_coord(const float (&m)[12], const Lea
   z = normalise_roundtrip_folded<SHORT>(vk, a.dh[2], a.rdh[2], a.half_h[2]);
 }
 
+// ---- round 6: what a ROW of the wave shares ---------------------------------------------------------------------------------
+// A wave is 4 rows of 16 lanes (tk = lane & 15 along K, one tj per row).  Everything that depends on (plane, j) only — the
+// first two terms of the affine row, fma(j, m1, i * m0) — is the same in the 16 lanes of a row, and so is what depends on
+// the plane alone (the control grid's lerp along I).  Lane t of a row computes it for plane t ONCE per brick; plane t's
+// value reaches the other lanes through the DPP row broadcast of gfx90a+ (v_mov_b32_dpp row_newbcast:t — one full-rate move
+// instead of a multiply, a multiply-add and a conversion per row, or of a half-rate v_readlane per scalar).
+__device__ __forceinline__ float row_bcast16(float v, int t) {  // (t is a literal after unrolling: the control word must be)
+  const int b = __float_as_int(v);
+  switch (t) {
+#define TIO_LE_BCAST(T) case T: return __int_as_float(__builtin_amdgcn_update_dpp(0, b, 0x150 + T, 0xF, 0xF, false));
+    TIO_LE_BCAST(0) TIO_LE_BCAST(1) TIO_LE_BCAST(2) TIO_LE_BCAST(3) TIO_LE_BCAST(4) TIO_LE_BCAST(5) TIO_LE_BCAST(6) TIO_LE_BCAST(7)
+    TIO_LE_BCAST(8) TIO_LE_BCAST(9) TIO_LE_BCAST(10) TIO_LE_BCAST(11) TIO_LE_BCAST(12) TIO_LE_BCAST(13) TIO_LE_BCAST(14) TIO_LE_BCAST(15)
+#undef TIO_LE_BCAST
+  }
+  return v;
+}
+
+// lean_exact_coord for the modes whose affine row acts on the integer voxel index (MODE 0 and 2), from the row's shared
+// partial sums p_r = fma(j, m[4r+1], i * m[4r]): the remaining two terms in MKL's order — fma(k, m2, p), then
+// fma(1, m3, .), which IS the rounded sum — bit for bit the same value
+template <int MODE, bool SHORT>
+__device__ __forceinline__ void lean_exact_coord_shared(const float (&m)[12], const LeanArgs& a, float p0, float p1, float p2, float ck, float di,
+                                                        float dj, float dk, float& x, float& y, float& z) {
+  static_assert(MODE == 0 || MODE == 2, "the shared partial sums are those of the integer voxel index");
+  float vi = __fadd_rn(__builtin_fmaf(ck, m[2], p0), m[3]);
+  float vj = __fadd_rn(__builtin_fmaf(ck, m[6], p1), m[7]);
+  float vk = __fadd_rn(__builtin_fmaf(ck, m[10], p2), m[11]);
+  if constexpr (MODE == 2) { vi = __fadd_rn(vi, di); vj = __fadd_rn(vj, dj); vk = __fadd_rn(vk, dk); }  // (unit spacing: d / 1)
+  x = normalise_roundtrip_folded<SHORT>(vi, a.dh[0], a.rdh[0], a.half_h[0]);
+  y = normalise_roundtrip_folded<SHORT>(vj, a.dh[1], a.rdh[1], a.half_h[1]);
+  z = normalise_roundtrip_folded<SHORT>(vk, a.dh[2], a.rdh[2], a.half_h[2]);
+}
+
 // (j, k)-lerped control planes ia, ia + 1, ia + 2 of this thread's column, three components each.  NAMED members, not an
 // array: the optimiser turns `e == 0 ? P[0] : (e == 3 ? P[3] : P[6])` into a dynamically indexed load of a stack object
 // (first build of this kernel: 48 bytes of scratch per lane and a scratch_load per component per plane).
@@ -156,6 +189,22 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
                                                   float (&X)[16], float (&Y)[16], float (&Z)[16]) {
   float pa_i = 0.f, pa_j = 0.f, pa_k = 0.f, pb_i = 0.f, pb_j = 0.f, pb_k = 0.f;
   int cur0 = -1, cur1 = -1;
+  // what the row shares (round 6): lane t of a row holds plane t's partial sums of the three affine rows ...
+  constexpr bool SHARED = (MODE == 0 || MODE == 2) && UNIT;
+  float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;
+  if constexpr (SHARED) {
+    const float ci_l = static_cast<float>(min(i0 + (lane & 15), i_last));
+    ps0 = __builtin_fmaf(cj, m[1], __fmul_rn(ci_l, m[0]));
+    ps1 = __builtin_fmaf(cj, m[5], __fmul_rn(ci_l, m[4]));
+    ps2 = __builtin_fmaf(cj, m[9], __fmul_rn(ci_l, m[8]));
+  }
+  // ... and which control planes plane t lerps between, as two bit masks per operand (bit t: the operand is control plane
+  // ia + 1 or beyond / ia + 2): scalar compares on literals instead of two v_readlane per plane
+  unsigned long long e0_ge1 = 0, e0_ge2 = 0, e1_ge1 = 0, e1_ge2 = 0;
+  if constexpr (MODE != 0) {
+    e0_ge1 = __builtin_amdgcn_ballot_w64(li_lane.i0 - ia >= 1); e0_ge2 = __builtin_amdgcn_ballot_w64(li_lane.i0 - ia >= 2);
+    e1_ge1 = __builtin_amdgcn_ballot_w64(li_lane.i1 - ia >= 1); e1_ge2 = __builtin_amdgcn_ballot_w64(li_lane.i1 - ia >= 2);
+  }
 #pragma unroll
   for (int t = 0; t < 16; t++) {
     if constexpr (INTERLEAVE) {
@@ -165,15 +214,13 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
       if (dma.left > 0) dma.template issue<true>(lane);  // (wave-uniform branch)
       __builtin_amdgcn_sched_barrier(0);
     }
-    const float ci = static_cast<float>(min(i0 + t, i_last));  // (scalar unit, one conversion)
     float di = 0.0f, dj = 0.0f, dk = 0.0f;
     if constexpr (MODE != 0) {
       // the two control planes a voxel lerps between change once or twice per brick: named registers that a SCALAR branch
       // refreshes (resample_tile.hpp: indexing by the plane number costs an s_set_gpr_idx sequence per access)
-      const int e0 = __builtin_amdgcn_readlane(li_lane.i0, t) - ia;
-      const int e1 = __builtin_amdgcn_readlane(li_lane.i1, t) - ia;
-      const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l0), t));
-      const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(li_lane.l1), t));
+      const int e0 = static_cast<int>((e0_ge1 >> t) & 1ull) + static_cast<int>((e0_ge2 >> t) & 1ull);
+      const int e1 = static_cast<int>((e1_ge1 >> t) & 1ull) + static_cast<int>((e1_ge2 >> t) & 1ull);
+      const float l0 = row_bcast16(li_lane.l0, t), l1 = row_bcast16(li_lane.l1, t);
       // (ONE rarely taken scalar branch per operand plane, branch-free selects inside: the nested if / else form compiled into
       // ~45 scalar instructions per plane — and a CU has one scalar unit for its twelve resident waves)
       if (e0 != cur0) {
@@ -194,7 +241,12 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
       dj = lerp2(pa_j, l0, pb_j, l1);
       dk = lerp2(pa_k, l0, pb_k, l1);
     }
-    lean_exact_coord<MODE, UNIT, SHORT>(m, a, ci, cj, ck, di, dj, dk, X[t], Y[t], Z[t]);
+    if constexpr (SHARED) {
+      lean_exact_coord_shared<MODE, SHORT>(m, a, row_bcast16(ps0, t), row_bcast16(ps1, t), row_bcast16(ps2, t), ck, di, dj, dk, X[t], Y[t], Z[t]);
+    } else {
+      const float ci = static_cast<float>(min(i0 + t, i_last));  // (scalar unit, one conversion)
+      lean_exact_coord<MODE, UNIT, SHORT>(m, a, ci, cj, ck, di, dj, dk, X[t], Y[t], Z[t]);
+    }
     if constexpr (INTERLEAVE) {
       // pin the plane HERE: the optimiser sinks the (pure) chain of all 16 planes behind the last DMA instruction otherwise —
       // the first build of this kernel "interleaved" nothing (its assembly: 16 DMA blocks back to back, then 16 planes)
@@ -299,17 +351,85 @@ __device__ __forceinline__ bool lean_exact_group_leaves(const float (&X4)[4], co
 }
 
 
-template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, int WAVES_PER_SIMD, bool FOLD_MIN = false>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kernel(const LeanArgs a) {
+// The planes of a brick that are NOT staged, voxel by voxel: every plane of a brick the planner could not stage (box beyond the
+// LDS budget, non-finite geometry; bricks over more than three control planes), or — round 6 — the planes of those passes of a
+// multi-pass brick that still do not fit (kPassSlow) or see nothing of the volume (kPassOutside: the fill value).  `states`: 4
+// bits per pass, a pass = 1 << span_shift planes.  Everything but the brick index is derived HERE, from the argument block
+// (through a pointer the optimiser cannot see through) and the descriptor: the call that follows the staged passes of a
+// multi-pass brick must not keep the mapping, the control-point pointers and the column's constants alive across the sampling
+// loop (first build: 24 - 60 scalar registers spilled in every instantiation, +2 ... +7 % on launches without such a brick).
+template <bool ELASTIC_POSSIBLE>
+__device__ __forceinline__ void lean_exact_slow_planes(unsigned brick, int states, int span_shift, uint32_t& kmin) {
+  typedef __attribute__((address_space(4))) const LeanArgs* const_args_ptr;
+  typedef __attribute__((address_space(4))) const int* const_int_ptr;
+  typedef __attribute__((address_space(4))) const float* const_float_ptr;
+  const_args_ptr ka = (const_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const int b = static_cast<int>(fastdiv_exact(brick, ka->bpe_magic, ka->bricks_per_element));
+  const_int_ptr d = (const_int_ptr)(ka->plan + ka->B * 16) + static_cast<size_t>(brick) * kDescInts;
+  const int i_begin = d[11], j_lo = d[12], k_lo = d[13];
+  const bool elastic = ELASTIC_POSSIBLE && d[14] != 0;
+  const_float_ptr mp = (const_float_ptr)(ka->mapping) + (ka->mapping_batched ? b * 12 : 0);
+  float m[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) m[q] = mp[q];
+  const int tid = threadIdx.x, tk = tid & 15, tj = tid >> 4;
+  const int Io = ka->Io, Jo = ka->Jo, Ko = ka->Ko;
+  const int i_count = min(16, Io - i_begin), nv = min(16, Jo - j_lo), nw = min(16, Ko - k_lo);
+  if (!((tj < nv) & (tk < nw))) return;
+  const int col_off = (j_lo + tj) * Ko + (k_lo + tk);
+  const int64_t slab_b = static_cast<int64_t>(Jo) * Ko * 4;
+  const float* in_chan = ka->in + static_cast<int64_t>(b) * ka->in_stride;
+  char* out_chan = reinterpret_cast<char*>(ka->out + static_cast<int64_t>(b) * ka->out_stride);
+  const bool has_fill = ka->fill != nullptr;
+  const float fillv = has_fill ? ((const_float_ptr)ka->fill)[0] : 0.0f;
+  const float hx = ka->hx, hy = ka->hy, hz = ka->hz;
+  const float cj = static_cast<float>(j_lo + tj), ck = static_cast<float>(k_lo + tk);
+  const float* cp = elastic ? ka->cp + (ka->cp_batched ? static_cast<int64_t>(b) * (ka->ni * ka->nj * ka->nk * 3) : 0) : nullptr;
+  Lerp1D lj{0, 0, 1.0f, 0.0f}, lk{0, 0, 1.0f, 0.0f};
+  if constexpr (ELASTIC_POSSIBLE) {
+    if (elastic) {
+      lj = lerp_index(j_lo + tj, ka->nj, Jo, ka->scj);
+      lk = lerp_index(k_lo + tk, ka->nk, Ko, ka->sck);
+    }
+  }
+  ExactChainArgs ea;
+  ea.ni = ka->ni; ea.nj = ka->nj; ea.nk = ka->nk; ea.Io = Io; ea.unit_spacing = ka->unit_spacing; ea.affine_first = ka->affine_first;
+  ea.scale_i = ka->sci;
+#pragma unroll
+  for (int e = 0; e < 3; e++) { ea.sp[e] = ka->sp[e]; ea.rsp[e] = ka->rsp[e]; ea.den[e] = ka->den[e]; ea.rden[e] = ka->rden[e]; }
+  ea.size_m1[0] = hx; ea.size_m1[1] = hy; ea.size_m1[2] = hz;
+  for (int t = 0; t < i_count; t++) {
+    const int st = (states >> (4 * (t >> span_shift))) & 0xF;  // (block uniform)
+    if (st == kPassStaged) continue;
+    float val = fillv;
+    if (st == kPassSlow) {
+      float x, y, z;
+      exact_voxel_coords<ELASTIC_POSSIBLE>(ea, m, elastic, cp, lj, lk, i_begin + t, cj, ck, x, y, z);
+      val = lean_exact_gather(in_chan, ka->J, ka->K, x, y, z, has_fill, fillv, hx, hy, hz);
+    }
+    *reinterpret_cast<float*>(out_chan + (i_begin + t) * slab_b + static_cast<unsigned>(col_off) * 4u) = val;
+    kmin = min(kmin, float_to_key(val));
+  }
+}
+
+// One brick.  MULTI = false: the body of resample_lean_exact_kernel, one block per brick of the launch — a multi-pass brick
+// (kDescMulti) is NOT its business: it returns at once, and resample_lean_exact_multi_kernel, behind it on the stream, walks
+// the list of those bricks the planner left (first build of round 6: the pass logic inside the one kernel cost every
+// instantiation 24 - 75 spilled scalar registers, +2 ... +7 % on launches that have no such brick).  MULTI = true: the same body
+// with the pass switches compiled in.
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool FOLD_MIN, bool MULTI>
+__device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsigned brick, float* s_tile) {
   constexpr int TI = 16, TJ = 16, TK = 16, NW = 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_tile = smem;
   typedef __attribute__((address_space(4))) const int* const_int_ptr;
   typedef __attribute__((address_space(4))) const float* const_float_ptr;
 
   // every argument the road to the first DMA needs, in scalar registers NOW (resample_planned_lean_kernel)
   // (round 5: the first build of this kernel fetched mapping_batched, tile_floats, the strides and the output shape one by one,
   // each behind its own `s_waitcnt lgkmcnt(0)` — nine scalar round trips between entry and the first DMA instruction)
+  // (round 6, measured and not kept: the descriptor's address from PRELOADED leading kernel arguments — kernarg preload,
+  // -mllvm -amdgpu-kernarg-preload-count=9 — same-box A/B +0.7 % / 0.0 % / -0.4 % on the affine / elastic / fused launch against
+  // -1.0 / -1.3 / -1.9 % without it: the preload is not free at wave launch)
   {
     const int* plan_p = a.plan; const float* in_p = a.in; const float* map_p = a.mapping; float* out_p = a.out; const float* fill_p = a.fill;
     asm volatile("" ::"s"(a.n_items), "s"(a.bricks_per_element), "s"(a.bpe_magic), "s"(plan_p), "s"(in_p), "s"(map_p), "s"(a.B), "s"(a.I), "s"(a.J), "s"(a.K),
@@ -320,7 +440,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
       asm volatile("" ::"s"(cp_p), "s"(a.cp_batched), "s"(a.ni), "s"(a.nj), "s"(a.nk), "s"(a.sci), "s"(a.scj), "s"(a.sck));
     }
   }
-  const unsigned brick = xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items));
   const int b = static_cast<int>(fastdiv_exact(brick, a.bpe_magic, a.bricks_per_element));
   // descriptor and the element's UNSCALED mapping (the planner's copy is scaled by the axis ratios), requested together
   const_int_ptr d = (const_int_ptr)(a.plan + a.B * 16) + static_cast<size_t>(brick) * kDescInts;
@@ -330,10 +449,16 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   bx.bx0 = d[1]; bx.by0 = d[2]; bx.za = d[3]; bx.Lx = d[4]; bx.Ly = d[5]; bx.cpr = d[6];
   const int i_begin = d[11], j_lo = d[12], k_lo = d[13];
   const int elastic_w = d[14];
+  int multi_w = 0, plan_tile = 0;
+  if constexpr (MULTI) {
+    multi_w = d[15];
+    plan_tile = ((const_int_ptr)(a.plan))[b * 16 + 13];  // (the tile the planner sized the boxes for)
+  }
   float m[12];
 #pragma unroll
   for (int q = 0; q < 12; q++) m[q] = mp[q];
   asm volatile("" ::"s"(kind_w), "s"(i_begin), "s"(j_lo), "s"(k_lo), "s"(elastic_w));  // (the whole descriptor behind ONE wait)
+  if constexpr (MULTI) asm volatile("" ::"s"(multi_w), "s"(plan_tile));
   const bool elastic = ELASTIC_POSSIBLE && elastic_w != 0;
 
   const int tid = threadIdx.x;
@@ -346,16 +471,34 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   char* out_chan = reinterpret_cast<char*>(a.out + static_cast<int64_t>(b) * a.out_stride);
 
   int kind = kind_w & 0xFF;
+  // round 6: a brick whose box exceeds the tile, bounded again by the planner in halves / quarters of its planes (kDescMulti:
+  // [1..6] hold pass 0's box, [15] the number of passes and every pass's state; the other passes' boxes are fetched when
+  // their turn comes).  Pass 0 is requested, and waited for, exactly like the box of a one-pass brick.  The planner has checked
+  // for every pass what this kernel re-checks for a one-pass box; its word holds if the plan was sized for a tile no larger
+  // than this launch's (a plan made AHEAD may have been made for another road).
+  const bool multi = MULTI && kind == kDescMulti;
+  if constexpr (!MULTI) {
+    if (kind == kDescMulti) return;  // (resample_lean_exact_multi_kernel's)
+  }
+  int nsplit = 1, states = 0;  // states: 4 bits per pass (kPassStaged = 0: a one-pass brick is "all staged")
+  if constexpr (MULTI) {
+    if (multi) {
+      nsplit = multi_w & 0xF; states = multi_w >> 8;
+      kind = plan_tile <= a.tile_floats ? kDescStaged : kDescSlow;
+    }
+  }
   // (a plan made AHEAD may have been sized for another road's tile: a box beyond THIS launch's tile takes the per-voxel road)
   // ... and so does a box whose taps' LDS addresses cannot be formed from absolute indices in float32 (box_address_fits: a
   // volume thousands of voxels long)
-  if (kind == kDescStaged && (static_cast<int64_t>(bx.Lx) * bx.Ly * (bx.cpr * 4) > static_cast<int64_t>(a.tile_floats) ||
-                              !box_address_fits(bx.bx0, bx.by0, bx.za, bx.Lx, bx.Ly, bx.cpr)))
+  if (!multi && kind == kDescStaged && (static_cast<int64_t>(bx.Lx) * bx.Ly * (bx.cpr * 4) > static_cast<int64_t>(a.tile_floats) ||
+                                        !box_address_fits(bx.bx0, bx.by0, bx.za, bx.Lx, bx.Ly, bx.cpr)))
     kind = kDescSlow;
+  if (kind == kDescSlow) states = 0x2222;  // (every plane on the per-voxel road)
+  const int span_shift = nsplit == 4 ? 2 : (nsplit == 2 ? 3 : 4);  // planes per pass = 1 << span_shift
   bx.kind = kind; bx.interior = kind_w >> 8;
   BoxDmaStepper<NW> dma;
   dma.left = 0;
-  if (kind == kDescStaged) dma.init(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane);
+  if (kind == kDescStaged && (states & 0xF) == kPassStaged) dma.init(s_tile, in_chan, bx, a.I, a.J, a.K, wave, lane);
 
   const int i_count = min(TI, a.Io - i_begin), nv = min(TJ, a.Jo - j_lo), nw = min(TK, a.Ko - k_lo);
   const bool col_active = (tj < nv) & (tk < nw);
@@ -408,26 +551,15 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
     }
   }
 
-  // Bricks the planner could not stage (box beyond the LDS budget, non-finite geometry) and — never on the planned road,
-  // whose gate asks for control cells at least a brick wide — bricks over more than three control planes: per-voxel
-  // evaluation of the exact chain, global gathers.
-  if (kind == kDescSlow || (elastic && ib - ia > 2)) {
-    if (kind == kDescStaged) { tile_dma_wait_all(); }  // (the box was requested: let it land before the block ends)
-    ExactChainArgs ea;
-    ea.ni = a.ni; ea.nj = a.nj; ea.nk = a.nk; ea.Io = a.Io; ea.unit_spacing = a.unit_spacing; ea.affine_first = a.affine_first;
-    ea.scale_i = a.sci;
-#pragma unroll
-    for (int e = 0; e < 3; e++) { ea.sp[e] = a.sp[e]; ea.rsp[e] = a.rsp[e]; ea.den[e] = a.den[e]; ea.rden[e] = a.rden[e]; }
-    ea.size_m1[0] = hx; ea.size_m1[1] = hy; ea.size_m1[2] = hz;
-    if (col_active) {
-      for (int t = i_begin; t < i_begin + i_count; t++) {
-        float x, y, z;
-        exact_voxel_coords<ELASTIC_POSSIBLE>(ea, m, elastic, cp, lj, lk, t, cj, ck, x, y, z);
-        const float val = lean_exact_gather(in_chan, a.J, a.K, x, y, z, has_fill, fillv, hx, hy, hz);
-        *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
-        kmin = min(kmin, float_to_key(val));
-      }
-    }
+  // Bricks the planner could not stage (box beyond the LDS budget, non-finite geometry) and — never on the planned road, whose
+  // gate asks for control cells at least a brick wide — bricks over more than three control planes: every plane voxel by voxel
+  if (elastic && ib - ia > 2) states = 0x2222;
+  bool any_staged = states == 0;
+  if constexpr (MULTI) {
+    for (int pass = 0; pass < nsplit; pass++) any_staged |= ((states >> (4 * pass)) & 0xF) == kPassStaged;
+  }
+  if (!any_staged) {
+    lean_exact_slow_planes<ELASTIC_POSSIBLE>(brick, states, span_shift, kmin);
     if (track) publish_min();
     return;
   }
@@ -478,11 +610,14 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   while (dma.left > 0) dma.template issue<true>(lane);  // (interior boxes with more instructions per wave than planes)
 
   TileAddr ta;
-  ta.ox = static_cast<float>(bx.bx0); ta.oy = static_cast<float>(bx.by0); ta.oz = static_cast<float>(bx.za);
-  ta.sYb = bx.cpr * 16; ta.sXb = bx.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
-  ta.sYbf = static_cast<float>(ta.sYb); ta.sXbf = static_cast<float>(ta.sXb);
-  ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
-  ta.c_f = ta.base_f - ta.ox * ta.sXbf - ta.oy * ta.sYbf - 4.0f * ta.oz;  // (exact: box_address_fits held above)
+  auto set_tile_addr = [&](const StreamBox& box) {
+    ta.ox = static_cast<float>(box.bx0); ta.oy = static_cast<float>(box.by0); ta.oz = static_cast<float>(box.za);
+    ta.sYb = box.cpr * 16; ta.sXb = box.Ly * ta.sYb; ta.sXYb = ta.sXb + ta.sYb;
+    ta.sYbf = static_cast<float>(ta.sYb); ta.sXbf = static_cast<float>(ta.sXb);
+    ta.base_f = static_cast<float>(static_cast<unsigned>(reinterpret_cast<uintptr_t>((fast_lds_wptr)s_tile)));
+    ta.c_f = ta.base_f - ta.ox * ta.sXbf - ta.oy * ta.sYbf - 4.0f * ta.oz;  // (exact: box_address_fits held above / in the planner)
+  };
+  set_tile_addr(bx);
 
   tile_dma_wait_all();
   __syncthreads();
@@ -490,7 +625,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
   // ---- phase B: sample.  The fill rule only matters where a tap can leave the volume: interior boxes never, the others
   // group by group and wave by wave (the masked code runs only in waves one of whose four voxels has a tap outside)
   char* out_t = out_chan + static_cast<int64_t>(i_begin) * slab_b;
-  const bool may_leave = has_fill & !bx.interior;  // block uniform
+  bool may_leave = has_fill & !bx.interior;  // block uniform
+  if constexpr (!MULTI) {
 #define TIO_LE_COORDS4                                                          \
   const float x4[4] = {X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]};     \
   const float y4[4] = {Y[4 * q], Y[4 * q + 1], Y[4 * q + 2], Y[4 * q + 3]};     \
@@ -505,21 +641,132 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kerne
     else                                                                                                                                  \
       lean_exact_group<EXACT_LERP, false, false, TRACK>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, false, fillv, kmin); \
   }
-  // partial bricks (a volume edge that is not a multiple of 16: rare): one copy, predicated stores, the mask wherever the image has a fill rule
+    // partial bricks (a volume edge that is not a multiple of 16: rare): one copy, predicated stores, the mask wherever the image has a fill rule
 #define TIO_LE_GROUPS_GUARDED(TRACK)                                                                                                      \
   _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                                         \
     TIO_LE_COORDS4                                                                                                                        \
     lean_exact_group<EXACT_LERP, true, true, TRACK>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, has_fill, fillv, kmin); \
   }
-  if (FOLD_MIN && track) {
-    if (full) { TIO_LE_GROUPS(true) } else { TIO_LE_GROUPS_GUARDED(true) }
-    publish_min();
-  } else {
-    if (full) { TIO_LE_GROUPS(false) } else { TIO_LE_GROUPS_GUARDED(false) }
-  }
+    if (FOLD_MIN && track) {
+      if (full) { TIO_LE_GROUPS(true) } else { TIO_LE_GROUPS_GUARDED(true) }
+      publish_min();
+    } else {
+      if (full) { TIO_LE_GROUPS(false) } else { TIO_LE_GROUPS_GUARDED(false) }
+    }
 #undef TIO_LE_GROUPS_GUARDED
 #undef TIO_LE_COORDS4
 #undef TIO_LE_GROUPS
+    return;
+  }
+  // the next pass of a multi-pass brick: every wave is done with the tile, then the pass's box is requested and waited for
+  // (nothing of this block overlaps the wait — the other resident blocks do)
+  // (what it needs of the launch's arguments is re-read from the argument block through a pointer the optimiser cannot see
+  // through: kept live across the sampling groups instead, those ~20 scalars pushed 26 - 58 others out of the register file)
+  auto next_pass = [&](int pass) {
+    __syncthreads();
+    typedef __attribute__((address_space(4))) const LeanArgs* const_args_ptr;
+    const_args_ptr ka = (const_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const_int_ptr r8 = (const_int_ptr)(ka->plan + ka->B * 16 + static_cast<size_t>(ka->n_items) * kDescInts) +
+                       (static_cast<size_t>(brick) * kPassesPerBrick + pass) * kPassInts;
+    StreamBox nb;
+    nb.bx0 = r8[0]; nb.by0 = r8[1]; nb.za = r8[2]; nb.Lx = r8[3]; nb.Ly = r8[4]; nb.cpr = r8[5];
+    nb.interior = r8[6] >> 8; nb.kind = kDescStaged;
+    BoxDmaStepper<NW> step;  // (its own stepper: re-using phase A's keeps twenty fields alive across the groups)
+    step.init(s_tile, ka->in + static_cast<int64_t>(b) * ka->in_stride, nb, ka->I, ka->J, ka->K, wave, lane);
+    if (nb.interior) { while (step.left > 0) step.template issue<true>(lane); }
+    else { while (step.left > 0) step.template issue<false>(lane); }
+    set_tile_addr(nb);
+    may_leave = (ka->fill != nullptr) & !nb.interior;
+    tile_dma_wait_all();
+    __syncthreads();
+  };
+  const bool track_min = FOLD_MIN && track;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (multi) {  // (block uniform; one-pass bricks in this kernel's list — none today — : states == 0, nothing of this)
+      const int pass = (4 * q) >> span_shift;
+      if (((states >> (4 * pass)) & 0xF) != kPassStaged) {  // this group's planes were written above
+        out_t += 4 * slab_b;
+        continue;
+      }
+      if (q > 0 && ((4 * q) & ((1 << span_shift) - 1)) == 0) next_pass(pass);
+    }
+    const float x4[4] = {X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]};
+    const float y4[4] = {Y[4 * q], Y[4 * q + 1], Y[4 * q + 2], Y[4 * q + 3]};
+    const float z4[4] = {Z[4 * q], Z[4 * q + 1], Z[4 * q + 2], Z[4 * q + 3]};
+    if (!full) {
+      // partial bricks (a volume edge that is not a multiple of 16: rare): one copy, predicated stores, the mask wherever the image has a fill rule
+      if (track_min) lean_exact_group<EXACT_LERP, true, true, FOLD_MIN>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, has_fill, fillv, kmin);
+      else lean_exact_group<EXACT_LERP, true, true, false>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, has_fill, fillv, kmin);
+      continue;
+    }
+    bool masked = false;
+    if (may_leave) masked = __builtin_amdgcn_ballot_w64(lean_exact_group_leaves(x4, y4, z4, hx, hy, hz)) != 0ull;
+    if (track_min) {
+      if (masked) lean_exact_group<EXACT_LERP, true, false, FOLD_MIN>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, true, fillv, kmin);
+      else lean_exact_group<EXACT_LERP, false, false, FOLD_MIN>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, false, fillv, kmin);
+    } else {
+      if (masked) lean_exact_group<EXACT_LERP, true, false, false>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, true, fillv, kmin);
+      else lean_exact_group<EXACT_LERP, false, false, false>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, false, fillv, kmin);
+    }
+  }
+  // the planes of the passes that were NOT staged (a multi-pass brick one of whose parts still does not fit, or sees nothing
+  // of the volume): voxel by voxel, behind everything else
+  if (multi && states != 0) lean_exact_slow_planes<ELASTIC_POSSIBLE>(brick, states, span_shift, kmin);
+  if (track_min) publish_min();
+}
+
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, int WAVES_PER_SIMD, bool FOLD_MIN = false>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kernel(const LeanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  lean_exact_brick<ELASTIC_POSSIBLE, EXACT_LERP, FOLD_MIN, false>(a, xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items)), smem);
+}
+
+// ... the same with the pass switches compiled in: what a launch MOST of whose bricks need passes takes (the caller's hint
+// TIO_GEOM_MOSTLY_LARGE_BOXES: rotations beyond ~15 degrees about all axes) — one block per brick, no list, no second kernel; its
+// one-pass bricks pay the pass logic's registers (+2 ... +7 %, measured: the reason it is not the only kernel)
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool FOLD_MIN = false>
+__global__ __launch_bounds__(256, 3) void resample_lean_exact_all_kernel(const LeanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  lean_exact_brick<ELASTIC_POSSIBLE, EXACT_LERP, FOLD_MIN, true>(a, xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items)), smem);
+}
+
+// The multi-pass bricks of the launch (round 6), behind resample_lean_exact_kernel on the stream: a few blocks per CU are
+// WALKERS of the planner's list (header in front of the plan: [0] the bricks listed, [1] the walkers' cursor, [2] the walkers
+// that are done), taking one brick at a time from the cursor — an atomic per brick: the bricks cost two to four passes and some
+// of them a per-voxel part, a static share leaves the launch waiting for its unluckiest walker.  At the bench's ranges the list
+// holds the 1.6 % of the bricks that sampled voxel by voxel from global memory until round 5 — every walker takes one or
+// none; beyond ~12 degrees about all axes it holds most bricks.  The last walker to finish zeroes cursor and done count — and
+// the list's length when the host says this launch is the last one that reads this plan (a.last_use: the launches of a call's
+// channels share a plan) — so the planner starts from zeros without a memset on the stream.
+// (Both kinds of blocks in ONE launch — walkers behind the bricks' own blocks — were built and measured: +9 % on the bench's
+// affine launch, the register allocation of the walker's body leaks into the one-brick body; profiles/r06_resample.md.)
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool FOLD_MIN = false>
+__global__ __launch_bounds__(256, 3) void resample_lean_exact_multi_kernel(const LeanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* head = const_cast<int*>(a.plan) - kPlanHeaderInts;
+  const int* list = a.plan + a.B * 16 + static_cast<size_t>(a.n_items) * (kDescInts + kPassInts * kPassesPerBrick);
+  const int count = min(__builtin_nontemporal_load(head), a.n_items);
+  int* mailbox = reinterpret_cast<int*>(smem);  // (the tile is nobody's between two bricks)
+  while (count > 0) {
+    if (threadIdx.x == 0) mailbox[0] = atomicAdd(head + 1, 1);
+    __syncthreads();
+    const int at = __builtin_amdgcn_readfirstlane(mailbox[0]);
+    __syncthreads();
+    if (at >= count) break;
+    const int brick = __builtin_amdgcn_readfirstlane(list[at]);
+    if (brick >= 0 && brick < a.n_items)
+      lean_exact_brick<ELASTIC_POSSIBLE, EXACT_LERP, FOLD_MIN, true>(a, static_cast<unsigned>(brick), smem);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(head + 2, 1) == static_cast<int>(gridDim.x) - 1) {
+      head[1] = 0; head[2] = 0;
+      if (a.last_use) head[0] = 0;
+    }
+  }
 }
 
 }  // namespace tio

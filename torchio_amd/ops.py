@@ -883,7 +883,7 @@ class Engine:
         if norm_shape is not None:  # the shape the coordinates are normalised with, when it is not the images' own
             geom.norm_shape = _i32x3(norm_shape)
         geom.precision = PRECISION_CODES[precision if precision is not None else _RESAMPLE_PRECISION]
-        geom.flags = _abi.GEOM_LARGE_BOXES if large_boxes else 0
+        geom.flags = (0, _abi.GEOM_LARGE_BOXES, _abi.GEOM_MOSTLY_LARGE_BOXES)[min(int(large_boxes), 2)]  # (0 / False: no hint, 1 / True: some bricks, 2: most)
         self._check("resample3d", mapping, control_points, cp_skip, passthrough)
         return geom, [mapping, control_points, cp_skip, passthrough]
 
@@ -947,8 +947,8 @@ class Engine:
         fused partial-volume mode: ``label_tables[n]`` is ``torch.unique(images[n])`` as
         float64 on the data's device (or ``None``: exact for fewer than 16 labels) and
         ``pad_labels[n]`` the out-of-bounds label; ``fills[n]`` is ignored for them.
-        ``large_boxes``: the caller's hint that most bricks' input boxes exceed the staging tile (``TIO_GEOM_LARGE_BOXES``,
-        transforms/spatial.py: ``_expects_large_boxes``) — a choice of road, never of values.
+        ``large_boxes``: the caller's hint that some (1 / True: ``TIO_GEOM_LARGE_BOXES``) or most (2: ``TIO_GEOM_MOSTLY_LARGE_BOXES``)
+        bricks' input boxes exceed the staging tile (transforms/spatial.py: ``_expects_large_boxes``) — a choice of road, never of values.
         """
         if not images:
             return []

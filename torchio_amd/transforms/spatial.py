@@ -638,32 +638,31 @@ class _LaunchGeometry:
         self.in_shape, self.in_affine, self.out_shape, self.out_affine = in_shape, in_affine, out_shape, out_affine
         self.mapping_dev, self.field_tensor, self.cp_skip, self.passthrough_all, self.flags = mapping_dev, field_tensor, cp_skip, passthrough_all, flags
         self.plan = None
-        self.large_boxes = large_boxes  # most bricks' input boxes exceed the planned roads' staging tile (`_expects_large_boxes`)
+        self.large_boxes = large_boxes  # 0 / 1 / 2: no / some / most bricks' input boxes exceed the planned roads' staging tile (`_expects_large_boxes`)
 
 
 # floats of ONE staging tile of the planned roads (csrc/resample.hip: 160 KB of LDS per CU, three blocks, granules of 1 280 bytes)
 _PLANNED_TILE_FLOATS = 13440
-# elements of a launch whose bricks exceed it from which on the brick kernels (in-kernel boxes, a large brick in two / four passes over
-# its planes) are the faster road for the WHOLE launch: a brick without a box costs a planned kernel ~3.5 x, the brick kernels cost
-# every brick ~1.2 - 1.7 x (profiles/r05_large_rotation.json: break-even near a quarter of the elements)
-_LARGE_BOX_FRACTION = 0.25
 # how much of `d (15 / cell)` per output axis a displacement component typically varies over a brick (calibrated against the planner's
 # own boxes: scripts/r5_box_estimate.py)
 _FIELD_VARIATION = 0.2
-# ... and how far beyond the tile the ESTIMATE (the largest box of the element: worst fractional position, worst alignment) has to be
-# before most of the element's bricks really are (same calibration: at 1.0 x one brick in ten, at 1.15 x more than half)
-_LARGE_BOX_MARGIN = 1.15
+# The ESTIMATE below is the largest box of an element (worst fractional position, worst alignment); calibrated against the planner's
+# descriptors (scripts/r5_box_estimate.py): at 1.0 x the tile one brick in ten of the element really exceeds it, at 1.15 x more than half.
+#   level 1 (TIO_GEOM_LARGE_BOXES): ANY element at 1.05 x (the bench's extreme — 10 degrees about all three axes — sits at 1.008) — the exact-coordinate lean road lists such bricks and stages them in passes
+#     behind the launch (6 - 15 us: more than the odd brick on the per-voxel road costs, less than a tenth of an element's does);
+#   level 2 (TIO_GEOM_MOSTLY_LARGE_BOXES): at least half of the elements at 1.15 x — the pass logic in every block of one launch.
+_LARGE_BOX_MARGIN_SOME, _LARGE_BOX_MARGIN_MOST, _LARGE_BOX_FRACTION_MOST = 1.05, 1.15, 0.5
 
 
-def _expects_large_boxes(mapping: np.ndarray | None, displacements, field_shape, out_shape, in_spacing) -> bool:
-    """Will the input box of a 16^3 output brick exceed the planned roads' staging tile for at least a quarter of the elements?
+def _expects_large_boxes(mapping: np.ndarray | None, displacements, field_shape, out_shape, in_spacing) -> int:
+    """Will the input box of a 16^3 output brick exceed the planned roads' staging tile — for some element (1), for most (2)?
 
     The box of a brick under the output -> input voxel mapping ``M`` spans ``15 sum_c |M_rc|`` voxels along input axis ``r``
     (plus the displacement field's variation over the brick, plus the taps), rows padded to 16-byte chunks — the planner's
     own arithmetic (csrc/resample_fast.hpp: plan_bricks_kernel) on the host copy of the mappings.  A HINT: it chooses between
-    roads that compute the same values (``TIO_GEOM_LARGE_BOXES``), so an estimate is enough."""
+    roads that compute the same values (``TIO_GEOM_LARGE_BOXES`` / ``TIO_GEOM_MOSTLY_LARGE_BOXES``), so an estimate is enough."""
     if mapping is None:
-        return False
+        return 0
     extent = 15.0 * np.abs(mapping[:, :, :3]).sum(axis=2)  # (n, 3): 15 (|M_r0| + |M_r1| + |M_r2|)
     if field_shape is not None and displacements is not None:
         # the field moves a point by up to d mm; between two control points it is linear, so over a brick edge (15 voxels) a
@@ -682,7 +681,9 @@ def _expects_large_boxes(mapping: np.ndarray | None, displacements, field_shape,
     length = np.floor(extent) + 3.0  # first tap to last tap + 1, the fractional position
     chunks = np.ceil((length[:, 2] + 3.0) * 0.25)  # rows start on a 16-byte boundary: up to three floats in front
     floats = length[:, 0] * length[:, 1] * chunks * 4.0
-    return int(np.count_nonzero(floats > _LARGE_BOX_MARGIN * _PLANNED_TILE_FLOATS)) >= _LARGE_BOX_FRACTION * floats.shape[0]
+    if int(np.count_nonzero(floats > _LARGE_BOX_MARGIN_MOST * _PLANNED_TILE_FLOATS)) >= _LARGE_BOX_FRACTION_MOST * floats.shape[0]:
+        return 2
+    return 1 if bool(np.any(floats > _LARGE_BOX_MARGIN_SOME * _PLANNED_TILE_FLOATS)) else 0
 
 
 def _prepare_launch_geometry(
