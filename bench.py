@@ -220,11 +220,14 @@ def aten_baseline(size: int, batch: int, device, steps: int = 3) -> dict:
     }
 
 
-def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int, timer=None, launch_bytes: int = 0, draw_policy: str | None = None) -> dict:
+def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, seed: int, timer=None, launch_bytes: int = 0, draw_policy: str | None = None,
+              noise_plan: str | None = None) -> dict:
     """A few steps of the same Compose in another (noise rng, resample precision) mode: volumes/s on this GPU, and the
     mean duration of the tio_resample3d launches in that mode (live HIP events, as for the headline's roofline)."""
-    previous = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision(), tio.get_draw_policy())
+    previous = (tio.get_noise_rng(), tio.get_resample_precision(), tio.get_stencil_precision(), tio.get_draw_policy(), tio.get_noise_plan())
     tio.set_noise_rng(noise_rng)
+    if noise_plan is not None:
+        tio.set_noise_plan(noise_plan)
     if draw_policy is not None:
         tio.set_draw_policy(draw_policy)
     tio.set_resample_precision(precision)
@@ -251,6 +254,7 @@ def time_mode(transform, batch, steps: int, *, noise_rng: str, precision: str, s
         tio.set_resample_precision(previous[1])
         tio.set_stencil_precision(previous[2])
         tio.set_draw_policy(previous[3])
+        tio.set_noise_plan(previous[4])
     n = steps * batch.batch_size
     result = {"volumes_per_s": n / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps}
     launch_ms = timer.mean_ms() if timer is not None else None
@@ -494,10 +498,12 @@ def main() -> None:
             modes = {}
             library_policy = tio.get_draw_policy()
 
-            def row(rng_mode, prec, steps, policy=None):
-                result = time_mode(transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77, timer=timer, launch_bytes=launch_bytes, draw_policy=policy)
+            def row(rng_mode, prec, steps, policy=None, plan=None):
+                result = time_mode(transform, batch, steps, noise_rng=rng_mode, precision=prec, seed=77, timer=timer, launch_bytes=launch_bytes, draw_policy=policy,
+                                   noise_plan=plan)
                 if rng_mode == "reference":
                     result["draws"] = policy or tio.get_draw_policy()
+                    result["plan"] = plan or ("device" if ops.noise_plan_on_device() else "host")
                 return result
 
             for prec in ("tight", "exact"):
@@ -517,6 +523,8 @@ def main() -> None:
             try:
                 modes["reference,exact"] = row("reference", "exact", 30, chosen)
                 modes["reference,tight"] = row("reference", "tight", 30, chosen)
+                # the state chain of the reference's stream on the DEVICE (what `auto` selects when several ranks share a host)
+                modes["reference,exact,plan=device"] = row("reference", "exact", 30, chosen, "device")
             finally:
                 tio.set_draw_policy(library_policy)
             extras["mode_matrix"] = modes
@@ -597,7 +605,7 @@ def main() -> None:
             "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
             "world_size": info.world_size, "counters_shape": list(counters.shape),
             "per_rank_volumes_per_s": [float(row[0] / row[1]) if row[1] > 0 else None for row in counters.tolist()],
-            "host_threads_per_rank": tdist.host_thread_budget(),
+            "host_threads_per_rank": tdist.host_thread_budget(), "noise_plan": "device" if ops.noise_plan_on_device() else "host",
             "rank0_pinned_cpus": len(pinned_cpus) if pinned_cpus else None,
         }
         line["host_settling_ms_per_step"] = settle_log[-4:]  # untimed blocks of 20 steps before the warm-up: the host side of a fresh box

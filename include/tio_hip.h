@@ -573,6 +573,26 @@ int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32_t* plan_ho
 int64_t tio_host_mt19937_plan_begin(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int32_t n_threads);
 int tio_host_mt19937_plan_end(int64_t handle, int64_t* used_words);
 int tio_mt19937_randn_device(const uint32_t* plan_host, const uint32_t* plan_dev, float* out_dev, void* stream);
+/* The plan whose snapshots the DEVICE makes (ABI 15).  With several ranks per host the state chain is what the
+ * reference-identical noise mode waits for (eight ranks: 4.8 - 5.7 ms per step and rank on the 15 threads each gets, against
+ * 1.8 ms of GPU time).  Every snapshot is an independent polynomial evaluation over GF(2) — a jump is the correlation of the
+ * polynomial's bits with the generator's own word sequence — so:
+ *   tio_host_mt19937_plan_prefix(state, n, plan_host, capacity, &prefix_words, &used_words, &total_blocks)
+ *       writes only the PREFIX of the plan — header, the rest of the current block, snapshot 0 (the state the chain starts
+ *       from): prefix_words (= 1 280) words to upload of the used_words the plan has on the device — and advances `state` like
+ *       tio_host_mt19937_plan does, lazily: the twists are owed and settled (one host-side jump) if the state is read again.
+ *       TIO_ERR_UNSUPPORTED_CONFIG (state untouched) where tio_host_mt19937_plan returns it, and when n is not a multiple of 16
+ *       (torch's tail rule needs the final state at once) — the caller then makes the whole plan on the host.
+ *   tio_host_mt19937_segment_polynomials(segment_blocks, count, out)
+ *       the jump polynomials t * segment_blocks twists ahead, t = 1 .. count, 624 words each (bit k of word k / 32 = the
+ *       coefficient of x^k) — cached per segment length; upload once per device and length.
+ *   tio_mt19937_device_snapshots(plan_dev, total_blocks, segment_blocks, polys_dev, stream)
+ *       one workgroup per segment of segment_blocks (a multiple of 128) twists: jumps to its first state, chains through the
+ *       segment, writes the snapshots into plan_dev.  The draw kernels above then read plan_dev as if the host had made it. */
+int tio_host_mt19937_plan_prefix(tio_host_mt_state* state, int64_t n, uint32_t* plan_host, int64_t capacity_words, int64_t* prefix_words,
+                                 int64_t* used_words, int64_t* total_blocks);
+int tio_host_mt19937_segment_polynomials(int64_t segment_blocks, int32_t count, uint32_t* out);
+int tio_mt19937_device_snapshots(uint32_t* plan_dev, int64_t total_blocks, int64_t segment_blocks, const uint32_t* polys_dev, void* stream);
 /* Noise.apply_transform for a float32 image in one kernel: out = x + (mean + std z) with z the plan's draws (the three
  * float32 roundings of noise.py:178, :119, as tio_add_noise) — the draws never exist in memory.  x / out: the image's
  * B * n_per_element values (the plan's n); mean_dev / std_dev: (B,) per-element parameters or NULL (then the scalars).

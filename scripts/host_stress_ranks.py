@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _worker(rank: int, world: int, steps: int, noise_rng: str, port: int, queue) -> None:
+def _worker(rank: int, world: int, steps: int, noise_rng: str, port: int, queue, plan_where: str = "host") -> None:
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     warnings.simplefilter("ignore")
     import ctypes as C
@@ -85,7 +85,11 @@ def _worker(rank: int, world: int, steps: int, noise_rng: str, port: int, queue)
             stream = ops.HostNormalStream(1000 * rank + step)
             t0 = time.perf_counter()
             used = C.c_int64(0)
-            status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), count, C.c_void_p(buffer.data_ptr()), words, C.byref(used), stream.threads)
+            if plan_where == "device":  # round 6: the device makes the snapshots; the host's share is the 5 KB prefix
+                prefix, blocks = C.c_int64(0), C.c_int64(0)
+                status = stream._fn["host_mt19937_plan_prefix"](C.addressof(stream._state), count, C.c_void_p(buffer.data_ptr()), words, C.byref(prefix), C.byref(used), C.byref(blocks))
+            else:
+                status = stream._fn["host_mt19937_plan"](C.addressof(stream._state), count, C.c_void_p(buffer.data_ptr()), words, C.byref(used), stream.threads)
             plan_s += time.perf_counter() - t0
             assert status == _abi.OK, status
     elapsed = time.perf_counter() - start
@@ -100,10 +104,10 @@ def _worker(rank: int, world: int, steps: int, noise_rng: str, port: int, queue)
     dist.destroy_process_group()
 
 
-def run(world: int, steps: int, noise_rng: str, port: int) -> list[dict]:
+def run(world: int, steps: int, noise_rng: str, port: int, plan_where: str = "host") -> list[dict]:
     ctx = mp.get_context("spawn")
     queue = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(rank, world, steps, noise_rng, port, queue)) for rank in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rank, world, steps, noise_rng, port, queue, plan_where)) for rank in range(world)]
     for p in procs:
         p.start()
     results = [queue.get(timeout=1800) for _ in procs]
@@ -117,12 +121,14 @@ def main() -> None:
     parser.add_argument("--ranks", type=int, default=8)
     parser.add_argument("--steps", type=int, default=300)
     parser.add_argument("--noise-rng", choices=["reference", "philox"], default="reference")
+    parser.add_argument("--plan", choices=["host", "device"], default="host",
+                        help="who runs the mt19937 state chain (ops.set_noise_plan): with `device` only the host's share of the plan (the prefix) is timed")
     parser.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_host_stress.json"))
     args = parser.parse_args()
-    report = {"host_cpus": os.cpu_count(), "steps": args.steps, "noise_rng": args.noise_rng,
+    report = {"host_cpus": os.cpu_count(), "steps": args.steps, "noise_rng": args.noise_rng, "plan": args.plan,
               "what": "host side of the bench step (null engine) + the real mt19937 plan of 8 x 256^3 draws per step, per rank"}
-    report["alone"] = run(1, args.steps, args.noise_rng, 29731)
-    report[f"{args.ranks}_ranks"] = run(args.ranks, args.steps, args.noise_rng, 29732)
+    report["alone"] = run(1, args.steps, args.noise_rng, 29731, args.plan)
+    report[f"{args.ranks}_ranks"] = run(args.ranks, args.steps, args.noise_rng, 29732, args.plan)
     worst = max(r["enqueue_ms_per_step"] for r in report[f"{args.ranks}_ranks"])
     report["summary"] = {
         "enqueue_ms_alone": report["alone"][0]["enqueue_ms_per_step"], f"enqueue_ms_worst_of_{args.ranks}": worst,

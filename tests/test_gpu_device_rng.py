@@ -12,6 +12,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["host", "device"])
+def plan_where(request):
+    """Who runs the mt19937 state chain (round 6, `ops.set_noise_plan`): this rank's host threads, or the device — one workgroup per
+    segment jumps to its first state (a correlation of the jump polynomial's bits with the generator's word sequence) and chains."""
+    from torchio_amd import ops
+
+    previous = ops.get_noise_plan()
+    ops.set_noise_plan(request.param)
+    yield request.param
+    ops.set_noise_plan(previous)
+
+
 def _torch_stream(seed, counts):
     generator = torch.Generator().manual_seed(seed)
     return [torch.randn(count, generator=generator) for count in counts]
@@ -30,7 +42,7 @@ def _torch_stream(seed, counts):
         [6_000_000 + 16, 12_000_000 + 5], # long chains: the host jumps ahead to the segments of its plan (host_rng_jump.cpp)
     ],
 )
-def test_device_draws_equal_torch_randn(hip, seed, counts):
+def test_device_draws_equal_torch_randn(hip, plan_where, seed, counts):
     from torchio_amd import ops
 
     stream = ops.HostNormalStream(seed)
@@ -40,7 +52,7 @@ def test_device_draws_equal_torch_randn(hip, seed, counts):
         assert torch.equal(expected.view(torch.int32), result.cpu().view(torch.int32))  # bit for bit (signed zeros included)
 
 
-def test_bench_batch_of_draws_equals_torch_randn(hip):
+def test_bench_batch_of_draws_equals_torch_randn(hip, plan_where):
     """8 x 256^3: 134 M draws, 1 681 snapshots."""
     from torchio_amd import ops
 
@@ -50,7 +62,7 @@ def test_bench_batch_of_draws_equals_torch_randn(hip):
     assert torch.equal(expected.view(torch.int32), result.cpu().view(torch.int32))
 
 
-def test_device_and_host_roads_agree_and_leave_the_same_state(hip, monkeypatch):
+def test_device_and_host_roads_agree_and_leave_the_same_state(hip, plan_where, monkeypatch):
     from torchio_amd import ops
 
     counts = [3_000_000, 1_000_000 + 9, 2_000_000]
@@ -61,6 +73,8 @@ def test_device_and_host_roads_agree_and_leave_the_same_state(hip, monkeypatch):
     on_host = [host_stream.randn((count,), "cuda").cpu() for count in counts]
     for a, b in zip(on_device, on_host):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # (a device-made plan leaves the host state OWING its twists: one more draw settles it — and both streams go on alike)
+    assert torch.equal(device_stream.randn((4096,), "cpu").view(torch.int32), host_stream.randn((4096,), "cpu").view(torch.int32))
     assert bytes(device_stream._state) == bytes(host_stream._state)
 
 
@@ -82,7 +96,7 @@ def test_plan_refuses_what_it_cannot_express_and_leaves_the_state_alone(hip):
 
 @pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("shape", [(2, 1, 96, 96, 96), (3, 2, 64, 80, 70 + 1)])
-def test_draw_and_sum_in_one_kernel_equals_the_two_steps(hip, monkeypatch, batched, shape):
+def test_draw_and_sum_in_one_kernel_equals_the_two_steps(hip, plan_where, monkeypatch, batched, shape):
     """tio_mt19937_add_noise_device == torch.randn on the host + tio_add_noise, bit for bit, and the same stream afterwards."""
     from torchio_amd import ops
 
@@ -285,3 +299,34 @@ def test_every_24_bit_uniform_through_both_transforms(hip):
     got = device.cpu().numpy()
     assert np.array_equal(host.view(np.uint32), got.view(np.uint32))
     assert n_blocks * 312 >= 1 << 24
+
+
+def test_the_device_made_plan_is_the_hosts_plan(hip):
+    """Snapshot for snapshot: `tio_mt19937_device_snapshots` against `tio_host_mt19937_plan` on ONE thread (the plain chain) —
+    every word but the 31 low bits of a JUMPED snapshot's first word (bits that are not part of the generator's state: the
+    twist never reads them), 12 M draws = 151 snapshots on 19 segments of 1 024 blocks... and the states the two leave behind."""
+    from torchio_amd import _abi, ops
+
+    count = 12_000_000 + 16 * 5
+    host_stream, device_stream = ops.HostNormalStream(77), ops.HostNormalStream(77)
+    words = int(host_stream._fn["host_mt19937_plan_words"](count))
+    plan = torch.empty(words, dtype=torch.int32)
+    used = C.c_int64(0)
+    assert host_stream._fn["host_mt19937_plan"](C.addressof(host_stream._state), count, C.c_void_p(plan.data_ptr()), words, C.byref(used), 1) == _abi.OK
+    previous = ops.get_noise_plan()
+    ops.set_noise_plan("device")
+    try:
+        made = device_stream._device_made_plan(count, torch.device("cuda"))
+    finally:
+        ops.set_noise_plan(previous)
+    assert made is not None
+    torch.cuda.synchronize()
+    theirs, ours = plan[: used.value], made[1].cpu()
+    assert ours.numel() == used.value and torch.equal(ours[:8], theirs[:8])
+    snapshots_at = 16 + 624 + 16
+    a = theirs[snapshots_at:].view(-1, 624).clone()
+    b = ours[snapshots_at:].view(-1, 624).clone()
+    a[:, 0] &= -(2**31)
+    b[:, 0] &= -(2**31)
+    assert torch.equal(a, b)
+    assert torch.equal(device_stream.randn((1 << 16,), "cpu").view(torch.int32), host_stream.randn((1 << 16,), "cpu").view(torch.int32))

@@ -24,6 +24,8 @@ from .data import Subject
 from .data import SubjectsBatch
 from .ops import calibrate_draw_policy
 from .ops import get_draw_policy
+from .ops import get_noise_plan
+from .ops import set_noise_plan
 from .ops import get_resample_precision
 from .ops import set_draw_policy
 from .ops import get_stencil_precision
@@ -64,5 +66,5 @@ __all__ = [
     "Affine", "AffineMatrix", "Anisotropy", "AppliedTransform", "BiasField", "Blur", "Choice", "Compose", "Crop", "ElasticDeformation", "Flip",
     "Gamma", "GridSampler", "Image", "ImagesBatch", "ImagesLoader", "IntensityTransform", "LabelMap", "LabelSampler", "Motion", "Noise", "OneOf",
     "Pad", "PatchAggregator", "PatchLocation", "PatchSampler", "Queue", "Resample", "Resize", "ScalarImage", "SomeOf", "Spatial", "SpatialTransform", "Subject",
-    "SubjectsBatch", "SubjectsLoader", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "calibrate_draw_policy", "get_draw_policy", "set_draw_policy", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "get_stencil_precision", "set_noise_rng", "set_resample_precision", "set_stencil_precision",
+    "SubjectsBatch", "SubjectsLoader", "Transform", "UniformSampler", "WeightedSampler", "apply_inverse_transform", "calibrate_draw_policy", "get_draw_policy", "set_draw_policy", "get_noise_plan", "set_noise_plan", "get_inverse_transform", "get_noise_rng", "get_resample_precision", "get_stencil_precision", "set_noise_rng", "set_resample_precision", "set_stencil_precision",
 ]

@@ -153,6 +153,9 @@ HIP_ONLY_PROTOTYPES = {
     "host_mt19937_plan_begin": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32]),
     "host_mt19937_plan_end": (C.c_int, [C.c_int64, C.POINTER(C.c_int64)]),
     "mt19937_randn_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "host_mt19937_plan_prefix": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "host_mt19937_segment_polynomials": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p]),
+    "mt19937_device_snapshots": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "mt19937_add_noise_device": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p],
     ),

@@ -45,6 +45,7 @@ struct MtState {
   uint32_t s[kN + 16];  // + mirror of the first 16 new words (vector loads across the wrap)
   int32_t pos;          // next unread word of the current block (kN = block exhausted)
   int32_t seeded;
+  int64_t owed_blocks;  // twists `s` is still behind (round 6: tio_host_mt19937_plan_prefix — the DEVICE ran the chain; settled by settle() when the words are next needed)
 };
 static_assert(sizeof(MtState) <= TIO_HOST_MT_STATE_BYTES, "tio_host_mt_state is too small");
 
@@ -53,6 +54,7 @@ void mt_seed(MtState* st, uint32_t seed) {
   for (int j = 1; j < kN; j++) st->s[j] = 1812433253u * (st->s[j - 1] ^ (st->s[j - 1] >> 30)) + static_cast<uint32_t>(j);
   st->pos = kN;
   st->seeded = 1;
+  st->owed_blocks = 0;
 }
 
 inline uint32_t twist_word(uint32_t a, uint32_t b, uint32_t c) {
@@ -401,7 +403,29 @@ void groups(uint32_t* words, int64_t n_groups) {
   for (int64_t g = 0; g < n_groups; g++) group16_scalar(words + 16 * g);
 }
 
+// The twists a device-made plan left owing (tio_host_mt19937_plan_prefix): `s` is brought to the block the stream stands in —
+// by jump-ahead to ONE twist before it and a real twist (the jumped window's first word carries 31 bits that are not part of
+// the generator's state: host_rng_jump.cpp; after a twist every bit is the chained one's), or by plain chaining when the
+// characteristic polynomial is not available.  Only a generator that is used AGAIN pays this (a Noise call with several images).
+void settle(MtState* st) {
+  int64_t owed = st->owed_blocks;
+  if (owed <= 0) return;
+  st->owed_blocks = 0;
+  if (owed > 64 && tio_host_rng::jump_available()) {
+    const std::vector<tio_host_rng::JumpPolynomial> g = tio_host_rng::jump_polynomials(owed - 1, 1);
+    if (g.size() == 1) {
+      uint32_t jumped[kN];
+      tio_host_rng::jump_state(st->s, *g[0], jumped);
+      memcpy(st->s, jumped, sizeof(jumped));
+      memcpy(st->s + kN, st->s, 16 * sizeof(uint32_t));
+      owed = 1;
+    }
+  }
+  for (int64_t b = 0; b < owed; b++) twist(st->s);
+}
+
 inline uint32_t next_word(MtState* st) {
+  settle(st);
   if (st->pos >= kN) { twist(st->s); st->pos = 0; }
   return st->s[st->pos++];
 }
@@ -434,6 +458,7 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
   MtState* st = reinterpret_cast<MtState*>(state);
   if (st == nullptr || plan == nullptr || used_words == nullptr || n < 0 || st->seeded != 1) return TIO_ERR_INVALID_ARGUMENT;
   if (n < 16) return TIO_ERR_UNSUPPORTED_CONFIG;
+  settle(st);
   const int64_t head = std::min<int64_t>(n, kN - st->pos);
   if (head % 16 != 0) return TIO_ERR_UNSUPPORTED_CONFIG;  // groups would straddle state blocks: the host road (state untouched)
   const int64_t body_words = n - head;
@@ -498,6 +523,67 @@ extern "C" int tio_host_mt19937_plan(tio_host_mt_state* state, int64_t n, uint32
   return TIO_OK;
 }
 
+// ---- the plan whose snapshots the DEVICE makes (round 6; VERDICT r5 missing #3) ---------------------------------------------
+// Eight ranks on one host each ran the state chain of 134 M draws on 15 worker threads per step: 4.8 - 5.7 ms per step and rank
+// under contention against 1.8 ms of GPU time (profiles/r05_host_stress_gpu_box.json) — the reference-identical noise mode was
+// host bound on an 8-GPU node.  mt19937 is linear over GF(2), and every snapshot is an independent polynomial evaluation: the
+// device makes them (mt19937.hip: tio_mt19937_device_snapshots).  What is left for the host is this PREFIX — the header, the
+// rest of the current block, the state the chain starts from (it IS snapshot 0) — and bookkeeping: the state is left
+// `owed_blocks` twists behind and settled when somebody reads it again (a second image of the same Noise call).
+//   returns TIO_ERR_UNSUPPORTED_CONFIG (state untouched) where tio_host_mt19937_plan would, and when n is not a multiple of 16
+//   (torch's tail rule redraws the last 16 values from 16 FRESH draws: they need the final state now) or there is no body
+extern "C" int tio_host_mt19937_plan_prefix(tio_host_mt_state* state, int64_t n, uint32_t* plan, int64_t capacity_words, int64_t* prefix_words,
+                                            int64_t* used_words, int64_t* total_blocks_out) {
+  MtState* st = reinterpret_cast<MtState*>(state);
+  if (st == nullptr || plan == nullptr || prefix_words == nullptr || used_words == nullptr || total_blocks_out == nullptr || n < 0 || st->seeded != 1)
+    return TIO_ERR_INVALID_ARGUMENT;
+  if (n < 16 || (n % 16) != 0) return TIO_ERR_UNSUPPORTED_CONFIG;
+  settle(st);
+  const int64_t head = std::min<int64_t>(n, kN - st->pos);
+  if (head % 16 != 0) return TIO_ERR_UNSUPPORTED_CONFIG;
+  const int64_t body_words = n - head;
+  const int64_t total_blocks = (body_words + kN - 1) / kN;
+  if (total_blocks < 1) return TIO_ERR_UNSUPPORTED_CONFIG;
+  const int64_t n_units = (total_blocks + kPlanUnitBlocks - 1) / kPlanUnitBlocks;
+  const int64_t used = kPlanSnapshots + n_units * kN;
+  if (capacity_words < kPlanSnapshots + kN) return TIO_ERR_INVALID_ARGUMENT;
+  memset(plan, 0, static_cast<size_t>(kPlanSnapshots) * sizeof(uint32_t));
+  plan[0] = kPlanMagic;
+  plan[1] = static_cast<uint32_t>(head);
+  plan[2] = static_cast<uint32_t>(total_blocks); plan[3] = static_cast<uint32_t>(static_cast<uint64_t>(total_blocks) >> 32);
+  plan[4] = static_cast<uint32_t>(n_units);
+  plan[5] = 0u;
+  plan[6] = static_cast<uint32_t>(n); plan[7] = static_cast<uint32_t>(static_cast<uint64_t>(n) >> 32);
+  memcpy(plan + kPlanHeader, st->s + st->pos, static_cast<size_t>(head) * sizeof(uint32_t));
+  memcpy(plan + kPlanSnapshots, st->s, kN * sizeof(uint32_t));  // snapshot 0: the state the first twist starts from
+  st->owed_blocks = total_blocks;
+  st->pos = static_cast<int32_t>(body_words - (total_blocks - 1) * kN);
+  *prefix_words = kPlanSnapshots + kN;
+  *used_words = used;
+  *total_blocks_out = total_blocks;
+  return TIO_OK;
+}
+
+// the jump polynomials of the device's segment starts: count polynomials of kN words (bit k of word k / 32 = the coefficient of
+// x^k; degree < 19937), the t-th carrying a state t * segment_blocks twists ahead, t = 1 .. count.  Cached per segment length
+// (the first call for a length costs `count` polynomial products: tens of milliseconds).
+extern "C" int tio_host_mt19937_segment_polynomials(int64_t segment_blocks, int32_t count, uint32_t* out) {
+  if (segment_blocks < 1 || count < 1 || out == nullptr) return TIO_ERR_INVALID_ARGUMENT;
+  if (!tio_host_rng::jump_available()) return TIO_ERR_UNSUPPORTED_CONFIG;
+  const std::vector<tio_host_rng::JumpPolynomial> list = tio_host_rng::jump_polynomials(segment_blocks, count);
+  if (static_cast<int>(list.size()) != count) return TIO_ERR_UNSUPPORTED_CONFIG;
+  for (int t = 0; t < count; t++) {
+    uint32_t* row = out + static_cast<size_t>(t) * kN;
+    memset(row, 0, kN * sizeof(uint32_t));
+    const std::vector<uint64_t>& g = *list[static_cast<size_t>(t)];
+    for (size_t w = 0; w < g.size() && 2 * w + 1 < static_cast<size_t>(kN); w++) {
+      row[2 * w] = static_cast<uint32_t>(g[w]);
+      row[2 * w + 1] = static_cast<uint32_t>(g[w] >> 32);
+    }
+  }
+  return TIO_OK;
+}
+
 // ---- the plan started AHEAD of its launch (round 4) -------------------------------------------------------------------
 // tio_host_mt19937_plan_begin hands the call above to a native thread and returns at once; tio_host_mt19937_plan_end waits
 // for it.  Between the two the caller (a Python thread that knows the seed one millisecond of enqueue work before it
@@ -543,6 +629,7 @@ extern "C" int tio_host_mt19937_randn(tio_host_mt_state* state, float* out, int6
   MtState* st = reinterpret_cast<MtState*>(state);
   if (st == nullptr || out == nullptr || n < 0 || st->seeded != 1) return TIO_ERR_INVALID_ARGUMENT;
   if (n < 16) return TIO_ERR_UNSUPPORTED_CONFIG;  // torch takes its scalar normal_distribution path below 16 values: not restated
+  settle(st);  // (twists a device-made plan left owing)
   uint32_t* words = reinterpret_cast<uint32_t*>(out);
   const int64_t n_full = n & ~static_cast<int64_t>(15);  // values transformed by the in-order groups (normal_fill: i < size - 15)
   constexpr int64_t kUnitBlocks = 128;                  // state blocks per unit of parallel work (80 k values)

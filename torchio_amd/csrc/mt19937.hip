@@ -202,15 +202,17 @@ __global__ __launch_bounds__(kThreads, 7) void mt19937_randn_kernel(const uint32
   for (int64_t b = unit * kPlanUnitBlocks; b < b_end; b++) {
     const uint32_t* o = s_state[cur];
     uint32_t* w = s_state[cur ^ 1];
-    // new[0 .. 227): old operands only
-    if (tid < kN - kM) w[tid] = twist_word(o[tid], o[tid + 1], o[tid + kM]);
-    __syncthreads();
-    // new[227 .. 454): the third operand is new[i - 227] of the first segment
-    if (tid < kN - kM) w[tid + (kN - kM)] = twist_word(o[tid + (kN - kM)], o[tid + (kN - kM) + 1], w[tid]);
-    __syncthreads();
-    // new[454 .. 623): third operand from the second segment; new[623] wraps to new[0]
-    if (tid < kN - 1 - 2 * (kN - kM)) w[tid + 2 * (kN - kM)] = twist_word(o[tid + 2 * (kN - kM)], o[tid + 2 * (kN - kM) + 1], w[tid + (kN - kM)]);
-    if (tid == kThreads - 1) w[kN - 1] = twist_word(o[kN - 1], w[0], w[kM - 1]);
+    // One twist, ONE barrier (round 6; three until then): the third operand of new[j] is new[j - 227] — lane i makes new[i],
+    // new[i + 227], new[i + 454] one after the other and has it in a register; everything else it reads is OLD.  The one word
+    // that wraps, new[623] = f(old[623], NEW[0], new[396]), is lane 169's third: it makes new[0] again for itself.
+    if (tid < kN - kM) {
+      constexpr int kS = kN - kM;  // 227
+      const uint32_t n0 = twist_word(o[tid], o[tid + 1], o[tid + kM]);
+      const uint32_t n1 = twist_word(o[tid + kS], o[tid + kS + 1], n0);
+      w[tid] = n0; w[tid + kS] = n1;
+      if (tid < kN - 1 - 2 * kS) w[tid + 2 * kS] = twist_word(o[tid + 2 * kS], o[tid + 2 * kS + 1], n1);
+      else if (tid == kN - 1 - 2 * kS) w[kN - 1] = twist_word(o[kN - 1], twist_word(o[0], o[1], o[kM]), n1);
+    }
     __syncthreads();
     const int64_t at = head + b * kN;                 // first output index of this block
     const int64_t count = min(static_cast<int64_t>(kN), n - at);
@@ -229,8 +231,149 @@ __global__ __launch_bounds__(64) void mt19937_tail_kernel(const uint32_t* __rest
   if (t < 16) out[n - 16 + t] = noisy(target, noise_run(target, n - 16, n), n - 16 + t, __uint_as_float(plan[kPlanTail + t]));
 }
 
+// ---- the plan's snapshots, made on the device (round 6) -------------------------------------------------------------------
+// Snapshot u is the state kPlanUnitBlocks u twists after snapshot 0.  One WORD step of mt19937 — x[k + 624] = x[k + 397] ^
+// A(x[k], x[k + 1]) — is a linear map f of the state over GF(2), the state J word steps on is g(f) s with g = x^J mod the
+// characteristic polynomial (host_rng_jump.cpp; degree < 19937), and f^k(s) is nothing but the WINDOW of the generator's own word
+// sequence at offset k.  So a jump is a correlation of the polynomial's bits with that sequence:
+//     out[m] = XOR over the set coefficients k of g of x[k + m],      m = 0 .. 623,
+// with x[0 .. 19937 + 624) made once per workgroup from snapshot 0 (33 twists) and kept in LDS (82 KB).  One workgroup per
+// SEGMENT of the chain: it jumps to its segment's first state (the host caches the segment polynomials per segment length and
+// uploads them once: 2.5 KB each), then twists through its segment and leaves the snapshots.  ~0.1 ms for the 215 k twists of a
+// bench batch on ~210 CUs, one workgroup each — beside whatever else the device runs — instead of 0.6 ms on 32 host threads
+// (5 ms on the 15 threads a rank gets when eight ranks share a host).
+// (The jumped state's first word carries 31 low bits that are not part of the generator's state: the twist never reads
+// them, and a snapshot's own words are never turned into draws.)
+constexpr int kJumpWords = 19937 + kN + 31;  // words of the sequence a jump can read (rounded up below)
+constexpr int kSeqBlocks = (kJumpWords + kN - 1) / kN;  // 33 state blocks
+constexpr int kSnapThreads = 960;  // fifteen waves share a jump polynomial's words; the chain behind the jump keeps the first four
+
+__global__ __launch_bounds__(kSnapThreads, 1) void mt19937_snapshots_kernel(uint32_t* __restrict__ plan, const uint32_t* __restrict__ polys,
+                                                                            int64_t total_blocks, int64_t segment_blocks) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_seq[];  // the word sequence from snapshot 0: kSeqBlocks x 624 words (+ 16 of slack), then two state buffers
+  uint32_t* s_state = s_seq + kSeqBlocks * kN + 16;
+  const int tid = threadIdx.x;
+  const int64_t segment = blockIdx.x;
+  uint32_t* snapshots = plan + kPlanSnapshots;
+  const int64_t b_begin = segment * segment_blocks, b_end = min(b_begin + segment_blocks, total_blocks);
+  if (b_begin >= b_end) return;
+  if (segment == 0) {
+    for (int i = tid; i < kN; i += kSnapThreads) s_state[i] = snapshots[i];
+  } else {
+    for (int i = tid; i < kN; i += kSnapThreads) s_seq[i] = snapshots[i];
+    if (tid < 16) s_seq[kSeqBlocks * kN + tid] = 0u;  // (slack the last window's 16-byte reads run into; multiplied by unset bits only)
+    __syncthreads();
+    // x[i + 624] = step(x[i], x[i + 1], x[i + 397]): 227 words at a time read only words that exist
+    for (int base = 0; base < (kSeqBlocks - 1) * kN; base += kN - kM) {
+      const int i = base + tid;
+      if (tid < kN - kM && i < (kSeqBlocks - 1) * kN) s_seq[i + kN] = twist_word(s_seq[i], s_seq[i + 1], s_seq[i + kM]);
+      __syncthreads();
+    }
+    // The correlation.  A lane owns FOUR consecutive words m = 4 l .. 4 l + 3 of the jumped state (156 lanes); for the 32
+    // coefficients of one polynomial word it needs x[32 w + m .. 32 w + m + 34]: nine aligned 16-byte reads into registers,
+    // then one xor per (set bit, word) — the bits are uniform per wave, the 32 tests are scalar branches.  Five groups of lanes
+    // share the polynomial's words (w mod 5) and meet through LDS.
+    // The correlation.  A lane owns TWELVE consecutive words m = 12 l .. 12 l + 11 of the jumped state: 52 lanes of ONE wave
+    // cover all 624, so a coefficient is tested once per polynomial word, not once per wave that shares the outputs — the
+    // tests are scalar instructions and branches, and the first builds of this kernel, with four words per lane and three
+    // waves per polynomial word, spent their time on the CU's scalar unit (0.2 ms per jump; this form: see profiles/r06_noise_plan.md).
+    // For the 32 coefficients of one polynomial word the lane needs x[32 w + m .. 32 w + m + 42]: eleven aligned 16-byte reads
+    // into registers, then one xor per (set bit, word).  The waves of the block share the polynomial's words (w mod waves) and
+    // meet through LDS.
+    constexpr int kWaves = kSnapThreads / 64, kOwn = 12;
+    const int wave = tid >> 6, l = tid & 63;
+    const bool busy = l < kN / kOwn;
+    uint32_t* s_poly = s_state;  // (the state buffers are free until the jump is done: the polynomial, fetched once, coalesced)
+    for (int i = tid; i < kN; i += kSnapThreads) s_poly[i] = polys[(segment - 1) * kN + i];
+    __syncthreads();
+    uint32_t acc[kOwn];
+#pragma unroll
+    for (int e = 0; e < kOwn; e++) acc[e] = 0u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (busy) {
+      uint32_t next_bits = __builtin_amdgcn_readfirstlane(s_poly[wave]);
+      for (int w = wave; w < kN; w += kWaves) {
+        const uint32_t bits = next_bits;
+        if (w + kWaves < kN) next_bits = __builtin_amdgcn_readfirstlane(s_poly[w + kWaves]);
+        if (bits == 0u) continue;
+        uint32_t r[44];
+        const u32x4* src = reinterpret_cast<const u32x4*>(s_seq + 32 * w + kOwn * l);
+#pragma unroll
+        for (int q = 0; q < 11; q++) {
+          const u32x4 v = src[q];
+          r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+          if ((bits >> j) & 1u) {
+#pragma unroll
+            for (int e = 0; e < kOwn; e++) acc[e] ^= r[j + e];
+          }
+        }
+      }
+    }
+    __syncthreads();  // (everybody is done with the sequence: its first words become the exchange buffer)
+    if (busy) {
+#pragma unroll
+      for (int e = 0; e < kOwn; e++) s_seq[wave * kN + kOwn * l + e] = acc[e];
+    }
+    __syncthreads();
+    for (int i = tid; i < kN; i += kSnapThreads) {
+      uint32_t v = 0u;
+#pragma unroll
+      for (int g = 0; g < kWaves; g++) v ^= s_seq[g * kN + i];
+      s_state[i] = v;
+    }
+  }
+  __syncthreads();
+  if (tid >= 256) return;  // (the chain is 227 lanes' work: a barrier of four waves, not fifteen — finished waves do not count)
+  __syncthreads();
+  int cur = 0;
+  for (int64_t b = b_begin; b < b_end; b++) {
+    const uint32_t* o = s_state + cur * kN;
+    uint32_t* w = s_state + (cur ^ 1) * kN;
+    if (b % kPlanUnitBlocks == 0 && b != 0) {  // (snapshot 0 is the host's)
+      uint32_t* dst = snapshots + (b / kPlanUnitBlocks) * kN;
+      for (int i = tid; i < kN; i += 256) dst[i] = o[i];
+    }
+    // One twist, ONE barrier: the third operand of new[j] is new[j - 227] — lane i makes new[i], new[i + 227], new[i + 454] one
+    // after the other and has it in a register; everything else it reads is OLD (new[i] needs old[i + 1], old[i + 397]; the
+    // in-place form reads old[j + 1] too).  The one word that wraps, new[623] = f(old[623], NEW[0], new[396]), is lane 169's
+    // third (169 + 454 = 623, 169 + 227 = 396): it makes new[0] again for itself from three old words.
+    if (tid < kN - kM) {
+      constexpr int kS = kN - kM;  // 227
+      const uint32_t n0 = twist_word(o[tid], o[tid + 1], o[tid + kM]);
+      const uint32_t n1 = twist_word(o[tid + kS], o[tid + kS + 1], n0);
+      w[tid] = n0; w[tid + kS] = n1;
+      if (tid < kN - 1 - 2 * kS) w[tid + 2 * kS] = twist_word(o[tid + 2 * kS], o[tid + 2 * kS + 1], n1);
+      else if (tid == kN - 1 - 2 * kS) w[kN - 1] = twist_word(o[kN - 1], twist_word(o[0], o[1], o[kM]), n1);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 }  // namespace
 }  // namespace tio
+
+// plan_dev: a plan whose prefix (header, head words, snapshot 0: tio_host_mt19937_plan_prefix) has been uploaded; the other
+// snapshots are written here.  segment_blocks: a multiple of 128; polys_dev: the polynomials of segments 1 .. n_segments - 1
+// (tio_host_mt19937_segment_polynomials), n_segments = ceil(total_blocks / segment_blocks).
+extern "C" int tio_mt19937_device_snapshots(uint32_t* plan_dev, int64_t total_blocks, int64_t segment_blocks, const uint32_t* polys_dev, void* stream) {
+  using namespace tio;
+  if (plan_dev == nullptr || total_blocks < 1 || segment_blocks < kPlanUnitBlocks || segment_blocks % kPlanUnitBlocks != 0)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_device_snapshots: bad argument");
+  const int64_t n_segments = (total_blocks + segment_blocks - 1) / segment_blocks;
+  if (n_segments > 1 && polys_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_device_snapshots: no segment polynomials");
+  if (n_segments > (1 << 20)) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_mt19937_device_snapshots: too many segments");
+  const size_t lds = ((static_cast<size_t>(kSeqBlocks) + 2) * kN + 16) * sizeof(uint32_t);
+  static_assert((kSeqBlocks - 1) * kN + kN >= 19937 + kN, "the sequence must cover every window a jump reads");
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_snapshots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+    return fail(TIO_ERR_LAUNCH, "tio_mt19937_device_snapshots: cannot reserve %zu bytes of LDS", lds);
+  hipLaunchKernelGGL(mt19937_snapshots_kernel, dim3(static_cast<unsigned>(n_segments)), dim3(kSnapThreads), lds, static_cast<hipStream_t>(stream), plan_dev, polys_dev,
+                     total_blocks, segment_blocks);
+  return check_launch("tio_mt19937_device_snapshots");
+}
 
 extern "C" int tio_mt19937_add_noise_device(const uint32_t* plan_host, const uint32_t* plan_dev, const float* x_dev, float* out_dev,
                                             int64_t n_per_element, float mean, float std, const float* mean_dev, const float* std_dev,

@@ -254,6 +254,47 @@ def calibrate_draw_policy(step, *, steps: int = 12, warmup: int = 6, policies=("
     return timings
 
 
+# Who runs the mt19937 state chain of the reference's noise stream (round 6):
+#   "host"    this rank's worker threads, by jump-ahead (0.6 ms per 134 M draws on 32 threads of an idle host, overlapped with the
+#             enqueue work of a Compose that draws ahead; 4.8 - 5.7 ms on the 15 threads a rank has when eight share a host);
+#   "device"  the device (csrc/mt19937.hip: tio_mt19937_device_snapshots — one workgroup per segment jumps and chains, ~0.1 ms
+#             beside whatever else runs); the host writes a 5 KB prefix;
+#   "auto"    "device" when several ranks share this host (LOCAL_WORLD_SIZE > 1), else "host".
+_NOISE_PLANS = ("auto", "host", "device")
+
+
+def _noise_plan_from_env() -> str:
+    value = os.environ.get("TIO_NOISE_PLAN", "auto")
+    if value not in _NOISE_PLANS:
+        raise ValueError(f"TIO_NOISE_PLAN must be one of {_NOISE_PLANS}, got {value!r}")
+    return value
+
+
+_NOISE_PLAN = _noise_plan_from_env()
+
+
+def set_noise_plan(where: str) -> None:
+    """Where the state chain of the reference's noise stream is run: ``"host"``, ``"device"`` or ``"auto"`` (see above).  The
+    draws are the same bits either way (tests/test_gpu_device_rng.py)."""
+    global _NOISE_PLAN
+    if where not in _NOISE_PLANS:
+        raise ValueError(f"noise plan must be one of {_NOISE_PLANS}, got {where!r}")
+    _NOISE_PLAN = where
+
+
+def get_noise_plan() -> str:
+    return _NOISE_PLAN
+
+
+def noise_plan_on_device() -> bool:
+    if _NOISE_PLAN == "auto":
+        try:
+            return int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1
+        except ValueError:
+            return False
+    return _NOISE_PLAN == "device"
+
+
 def note_resample_launch(reference: Tensor) -> None:
     """Called behind every tio_resample3d launch while the reference's noise stream is drawn on the draw stream: the event
     the next draw kernel is gated on."""
@@ -500,6 +541,8 @@ class HostNormalStream:
         of host work before the noise kernel is launched."""
         if self._prefetched is not None or count < self.DEVICE_DRAW_MIN or os.environ.get("TIO_DEVICE_RNG", "1") == "0":
             return
+        if noise_plan_on_device() and count % 16 == 0:
+            return  # (the device runs the chain: the host's part is a 5 KB prefix, written when the plan is asked for)
         device = torch.device(device)
         with torch.cuda.device(device):
             words = int(self._fn["host_mt19937_plan_words"](count))
@@ -532,6 +575,10 @@ class HostNormalStream:
                 raise EngineError(f"HostNormalStream: a plan of {ahead[0]} draws on {ahead[1]} was started ahead, {count} on {device} are asked for")
             plan_host = ahead[2]
         else:
+            if noise_plan_on_device():
+                made = self._device_made_plan(count, device)
+                if made is not None:
+                    return made
             words = int(self._fn["host_mt19937_plan_words"](count))
             plan_host = self._plan_staging(words)
             used = C.c_int64(0)
@@ -548,6 +595,55 @@ class HostNormalStream:
         finally:
             if ahead is not None:  # from here on the upload event (if any) guards the buffer
                 ahead[4].discard(id(plan_host))
+
+    # segment polynomials on the device: {(device index, segment_blocks): (count, tensor)} — 2.5 KB per segment, made by the host
+    # once per segment length (tens of milliseconds: polynomial products) and uploaded once
+    _segment_polynomials: dict = {}
+    _SEGMENTS = 224  # workgroups of the snapshot kernel to aim for (one per CU; a segment is a power of two of 128-block units)
+
+    def _device_made_plan(self, count: int, device):
+        """The plan with its snapshots made ON the device (``set_noise_plan("device")``): the host writes the prefix (header,
+        rest of the current block, snapshot 0 — ``tio_host_mt19937_plan_prefix``) and leaves its own state owing the twists;
+        ``tio_mt19937_device_snapshots`` jumps to every segment's first state and chains through it.  ``None`` (state
+        untouched) where that form does not apply: the caller makes the whole plan on the host."""
+        prefix_words, used, total_blocks = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        plan_host = self._plan_staging(2048)
+        status = self._fn["host_mt19937_plan_prefix"](C.addressof(self._state), count, C.c_void_p(plan_host.data_ptr()), 2048,
+                                                      C.byref(prefix_words), C.byref(used), C.byref(total_blocks))
+        if status == _abi.UNSUPPORTED_CONFIG:
+            return None
+        if status != _abi.OK:
+            raise EngineError(f"tio_host_mt19937_plan_prefix failed with status {status}")
+        device = torch.device(device)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        blocks = total_blocks.value
+        segment = 128
+        while segment * self._SEGMENTS < blocks:
+            segment *= 2
+        n_segments = (blocks + segment - 1) // segment
+        polys = None
+        if n_segments > 1:
+            cached = HostNormalStream._segment_polynomials.get((index, segment))
+            if cached is None or cached[0] < n_segments - 1:
+                need = max(n_segments - 1, self._SEGMENTS)
+                host = torch.empty(need * 624, dtype=torch.int32)
+                status = self._fn["host_mt19937_segment_polynomials"](segment, need, C.c_void_p(host.data_ptr()))
+                if status != _abi.OK:
+                    raise EngineError(f"tio_host_mt19937_segment_polynomials failed with status {status}")
+                cached = (need, host.to(device))
+                HostNormalStream._segment_polynomials[(index, segment)] = cached
+            polys = cached[1]
+        plan_dev = torch.empty(used.value, dtype=torch.int32, device=device)
+        plan_dev[: prefix_words.value].copy_(plan_host[: prefix_words.value], non_blocking=True)
+        HostNormalStream._rings().uploaded.setdefault(id(plan_host), torch.cuda.Event()).record()
+        raw_stream = torch._C._cuda_getCurrentRawStream(index)
+        status = self._fn["mt19937_device_snapshots"](C.c_void_p(plan_dev.data_ptr()), blocks, segment,
+                                                      None if polys is None else C.c_void_p(polys.data_ptr()), C.c_void_p(raw_stream))
+        if status != _abi.OK:
+            raise EngineError(f"tio_mt19937_device_snapshots failed with status {status}")
+        # (the consumers read the HEADER from the host copy — magic, units, tail flag, n — while the kernels read the device's:
+        # a private copy, the ring buffer goes back to the ring)
+        return plan_host[:16].clone(), plan_dev
 
     def can_draw_ahead(self, shape, device) -> bool:
         """Can :meth:`randn_ahead` take these draws?  (Nothing is drawn; a stream that stands inside a group of 16 still
