@@ -174,7 +174,8 @@ __device__ __forceinline__ void emit_groups(Words words, int groups, float* __re
 // registers, one more than that allows, the launch took a second round for its last 145 blocks: 0.41 -> 0.47 ms)
 template <bool ADD>
 __global__ __launch_bounds__(kThreads, 7) void mt19937_randn_kernel(const uint32_t* __restrict__ plan, float* __restrict__ out, const NoiseTarget target) {
-  __shared__ uint32_t s_state[2][kN];
+  constexpr int kRing = 5, kChunk = 4;  // state buffers; state blocks turned into draws together (see the loop)
+  __shared__ uint32_t s_state[kRing][kN];
   const int tid = threadIdx.x;
   const int64_t head = plan[1];
   const int64_t total_blocks = static_cast<int64_t>(plan[2]) | (static_cast<int64_t>(plan[3]) << 32);
@@ -198,13 +199,10 @@ __global__ __launch_bounds__(kThreads, 7) void mt19937_randn_kernel(const uint32
   if constexpr (ADD) {
     if (run_per_unit) run = noise_run(target, head + unit * kPlanUnitBlocks * kN, n);
   }
-  int cur = 0;
-  for (int64_t b = unit * kPlanUnitBlocks; b < b_end; b++) {
-    const uint32_t* o = s_state[cur];
-    uint32_t* w = s_state[cur ^ 1];
-    // One twist, ONE barrier (round 6; three until then): the third operand of new[j] is new[j - 227] — lane i makes new[i],
-    // new[i + 227], new[i + 454] one after the other and has it in a register; everything else it reads is OLD.  The one word
-    // that wraps, new[623] = f(old[623], NEW[0], new[396]), is lane 169's third: it makes new[0] again for itself.
+  // One twist, ONE barrier (round 6; three until then): the third operand of new[j] is new[j - 227] — lane i makes new[i],
+  // new[i + 227], new[i + 454] one after the other and has it in a register; everything else it reads is OLD.  The one word
+  // that wraps, new[623] = f(old[623], NEW[0], new[396]), is lane 169's third: it makes new[0] again for itself.
+  auto twist = [&](const uint32_t* o, uint32_t* w) {
     if (tid < kN - kM) {
       constexpr int kS = kN - kM;  // 227
       const uint32_t n0 = twist_word(o[tid], o[tid + 1], o[tid + kM]);
@@ -214,6 +212,47 @@ __global__ __launch_bounds__(kThreads, 7) void mt19937_randn_kernel(const uint32
       else if (tid == kN - 1 - 2 * kS) w[kN - 1] = twist_word(o[kN - 1], twist_word(o[0], o[1], o[kM]), n1);
     }
     __syncthreads();
+  };
+  int cur = 0;
+  int64_t b = unit * kPlanUnitBlocks;
+  // FOUR state blocks at a time (round 6): a block is 312 pairs of draws — 1.22 rounds of the 256 threads, i.e. two rounds the
+  // second of which keeps 56 lanes busy (61 % of the lanes over the kernel's arithmetic, which is all it does: ~135 vector
+  // instructions per pair); four blocks are 1 248 pairs = 4.875 rounds, five rounds at 97.5 %.  The twists run ahead through a ring
+  // of five state buffers (the next chunk's first twist writes the one buffer this chunk's draws do not read; its barrier then
+  // orders every later write behind them).  Whole blocks of whole groups only, and parameters fetched per unit: the rest — a
+  // ragged last block, elements shorter than a unit — goes block by block as before.
+  while (b + kChunk <= b_end && head + (b + kChunk) * kN <= n_full && (!ADD || run_per_unit)) {
+#pragma unroll
+    for (int q = 0; q < kChunk; q++) {
+      const int from = cur;
+      cur = cur + 1 == kRing ? 0 : cur + 1;
+      twist(s_state[from], s_state[cur]);
+    }
+    // (cur is the LAST of the four new blocks: block q of the chunk sits (kChunk - 1 - q) buffers back)
+    for (int p = tid; p < kChunk * (kN / 2); p += kThreads) {
+      const int q = (p >= kN / 2) + (p >= kN) + (p >= 3 * (kN / 2));
+      const int pp = p - q * (kN / 2);
+      const int at = (pp >> 3) * 16 + (pp & 7);
+      int buf = cur - (kChunk - 1 - q);
+      buf = buf < 0 ? buf + kRing : buf;
+      const uint32_t* words = s_state[buf];
+      const int64_t first = head + (b + q) * kN;
+      float x, y;
+      normal_pair(words[at], words[at + 8], x, y);
+      if constexpr (ADD) {
+        x = noisy(target, run, first + at, x);
+        y = noisy(target, run, first + at + 8, y);
+      }
+      out[first + at] = x;
+      out[first + at + 8] = y;
+    }
+    b += kChunk;
+  }
+  for (; b < b_end; b++) {
+    const int from = cur;
+    cur = cur + 1 == kRing ? 0 : cur + 1;
+    twist(s_state[from], s_state[cur]);
+    const uint32_t* w = s_state[cur];
     const int64_t at = head + b * kN;                 // first output index of this block
     const int64_t count = min(static_cast<int64_t>(kN), n - at);
     const int whole = static_cast<int>((min(at + count, n_full) - at) / 16);
@@ -221,7 +260,7 @@ __global__ __launch_bounds__(kThreads, 7) void mt19937_randn_kernel(const uint32
       if (!run_per_unit) run = noise_run(target, at, n);
     }
     if (whole > 0) emit_groups<ADD>(w, whole, out, at, target, run, tid);
-    cur ^= 1;  // (no barrier here: the next twist only READS the buffer these groups read, and writes the other one)
+    // (no barrier here: the next twist only READS the buffer these groups read, and writes another one)
   }
 }
 
