@@ -128,6 +128,7 @@ def test_margin_zero_would_not_be_bit_identical(hip, monkeypatch):
     reference = hip.resample3d([seg], **kwargs)[0]
     monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
     monkeypatch.setenv("TIO_NEAREST_EPS", "0")
+    monkeypatch.setenv("TIO_NEAREST_EXACT", "0")  # (round 6: images without a fill rule take the exact-plane kernel, which has no margin — this is about the FAST-line kernel)
     loose = hip.resample3d([seg], **kwargs)[0]
     torch.cuda.synchronize()
     wrong = int((reference != loose).sum())
@@ -173,8 +174,11 @@ def test_random_geometries_against_the_all_exact_road(hip, monkeypatch, seed):
     reference = hip.resample3d([data], **kwargs)[0]
     monkeypatch.setenv("TIO_NEAREST_KERNEL", "1")
     got = hip.resample3d([data], **kwargs)[0]
+    monkeypatch.setenv("TIO_NEAREST_EXACT", "0")  # (round 6: the FAST-line kernel of rounds 3 - 5 where the exact-plane kernel is the default)
+    got_line = hip.resample3d([data], **kwargs)[0]
     torch.cuda.synchronize()
     assert torch.equal(reference, got), (seed, in_shape, out_shape, dtype, cp_shape if elastic else None)
+    assert torch.equal(reference, got_line), (seed, in_shape, out_shape, dtype, cp_shape if elastic else None)
 
 
 @pytest.mark.parametrize("norm_shape", [(48, 40, 64), (200, 150, 260), (97, 81, 130)])

@@ -805,6 +805,7 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     for (int d = 0; d < 3; d++) {
       nn.sp[d] = a.sp[d]; nn.rsp[d] = a.rsp[d]; nn.den[d] = a.den[d]; nn.rden[d] = a.rden[d]; nn.size_m1[d] = a.size_m1[d];
       nn.ratio[d] = a.half_h[d] / a.dh[d];
+      nn.dh[d] = a.dh[d]; nn.rdh[d] = a.rdh[d]; nn.half_h[d] = a.half_h[d];
     }
     const bool nn_rows = nn.Ko >= 48;  // bricks of 16 x 4 x 64 (a wave = one output row) unless the volume is narrower than that
     const int nn_tj = nn_rows ? 4 : 16, nn_tk = nn_rows ? 64 : 16;
@@ -817,10 +818,21 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
     nn.eps = kNearestEps;
     if (env.has_nearest_eps) nn.eps = env.nearest_eps;  // (calibration runs only)
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+    // round 6: without a fill rule the reference's own coordinates plane by plane (resample_nearest_exact_kernel; its gate is the
+    // float exact-coordinate kernel's: the short division, unit spacing under control points, rows of at least 48 voxels)
+    const bool nn_exact = env.nearest_exact != 0 && nn.any_fill == 0 && nn_rows && a.short_div != 0 && (a.cp == nullptr || a.unit_spacing != 0);
     for (int es = 1; es <= 8; es *= 2) {  // one launch per element size present
       bool present = false;
       for (int i = 0; i < nn.n_images; i++) present = present || nn.img[i].es == es;
       if (!present) continue;
+      if (nn_exact) {
+#define TIO_NN_EXACT(ES)                                                                                                \
+  if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_exact_kernel<true, ES>), grid, block, 0, s, nn);           \
+  else hipLaunchKernelGGL((resample_nearest_exact_kernel<false, ES>), grid, block, 0, s, nn);
+        if (es == 1) { TIO_NN_EXACT(1) } else if (es == 2) { TIO_NN_EXACT(2) } else if (es == 4) { TIO_NN_EXACT(4) } else { TIO_NN_EXACT(8) }
+#undef TIO_NN_EXACT
+        continue;
+      }
 #define TIO_NN_LAUNCH_SHAPE(ES, TJ, TK)                                                                                 \
   if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_kernel<true, ES, TJ, TK, 16>), grid, block, 0, s, nn);     \
   else hipLaunchKernelGGL((resample_nearest_kernel<false, ES, TJ, TK, 16>), grid, block, 0, s, nn);
