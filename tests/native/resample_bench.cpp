@@ -644,6 +644,19 @@ int main(int argc, char** argv) {
       failures += run_case(c, reps, false, true);
     }
   }
+  if (cases == "labels") {
+    // round 6: what bounds the label kernel — element size against chain (affine / affine + elastic), same geometry
+    const int dts[] = {TIO_U8, TIO_I16, TIO_I32};
+    const char* dn[] = {"u8", "i16", "i32"};
+    for (int e = 0; e < 2; e++)
+      for (int q = 0; q < 3; q++) {
+        char name[64];
+        snprintf(name, sizeof name, "labels %s %s", dn[q], e ? "affine+elastic" : "affine");
+        Case c = make_case(name, batch, size, size, size, true, e != 0);
+        c.images.push_back(Image{1, dts[q], TIO_NEAREST, false});
+        failures += run_case(c, reps, false, true);
+      }
+  }
   if (cases == "geometry") {
     // round 6: the same launch over geometries that change the size of a brick's input box — a pure translation (the
     // smallest box a brick can have: what more resident blocks per CU would buy, with --lds), the bench's ranges, and

@@ -825,10 +825,19 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       bool present = false;
       for (int i = 0; i < nn.n_images; i++) present = present || nn.img[i].es == es;
       if (!present) continue;
-      if (nn_exact) {
+      // ... and its tail's: 24-bit offsets and buffer loads (I J <= 2^24, every channel below 2^32 bytes)
+      const int64_t n_in_e = static_cast<int64_t>(nn.I) * nn.J * nn.K, n_out_e = static_cast<int64_t>(nn.Io) * nn.Jo * nn.Ko;
+      const bool nn_narrow = static_cast<int64_t>(nn.I) * nn.J <= (1 << 24) && static_cast<int64_t>(nn.K) * es < (1 << 24) &&
+                             n_in_e * es < (int64_t{1} << 32) - 16 && n_out_e * es < (int64_t{1} << 32) - 16;
+      if (nn_exact && nn_narrow) {
+        // resident blocks per CU through UNUSED dynamic LDS: without control points the kernel holds 61 registers (eight blocks per CU),
+        // and eight blocks' slanted input footprints evict one another's cache lines — three blocks per CU measured 0.236 -> 0.210 ms
+        // (int16) and 0.344 -> 0.286 (int32) on 8 x 256^3 at the bench's ranges, uint8 0.172 -> 0.177; with control points (95 registers,
+        // five blocks) the launch is arithmetic bound and loses from four blocks down (profiles/r06_labels.md).  TIO_NEAREST_LDS: A/B
+        const unsigned nn_lds = env.nearest_lds >= 0 ? static_cast<unsigned>(env.nearest_lds) : (nn.cp == nullptr ? 52000u : 0u);
 #define TIO_NN_EXACT(ES)                                                                                                \
-  if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_exact_kernel<true, ES>), grid, block, 0, s, nn);           \
-  else hipLaunchKernelGGL((resample_nearest_exact_kernel<false, ES>), grid, block, 0, s, nn);
+  if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_exact_kernel<true, ES>), grid, block, nn_lds, s, nn);           \
+  else hipLaunchKernelGGL((resample_nearest_exact_kernel<false, ES>), grid, block, nn_lds, s, nn);
         if (es == 1) { TIO_NN_EXACT(1) } else if (es == 2) { TIO_NN_EXACT(2) } else if (es == 4) { TIO_NN_EXACT(4) } else { TIO_NN_EXACT(8) }
 #undef TIO_NN_EXACT
         continue;

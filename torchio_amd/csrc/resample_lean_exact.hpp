@@ -183,10 +183,16 @@ struct CtlPlanes {
 // The 16 planes of this thread's column (phase A), one DMA instruction of an interior box between two planes.
 //   li_lane: lane t of the wave holds ATen's lerp of plane i_begin + t along the control grid's first axis (block uniform
 //   per plane: read back as scalars)
-template <int MODE, bool UNIT, bool SHORT, bool INTERLEAVE, int NW>
+struct LeanNoPlaneHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// `each(t)`: called once plane t's coordinates stand (resample_nearest_exact_kernel: the plane's load goes out while the next
+// plane is being formed); the float kernels pass nothing
+template <int MODE, bool UNIT, bool SHORT, bool INTERLEAVE, int NW, typename EACH = LeanNoPlaneHook>
 __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const LeanArgs& a, int i0, int i_last, float cj, float ck,
                                                   const Lerp1D& li_lane, int ia, const CtlPlanes P, BoxDmaStepper<NW>& dma, int lane,
-                                                  float (&X)[16], float (&Y)[16], float (&Z)[16]) {
+                                                  float (&X)[16], float (&Y)[16], float (&Z)[16], EACH each = EACH()) {
   float pa_i = 0.f, pa_j = 0.f, pa_k = 0.f, pb_i = 0.f, pb_j = 0.f, pb_k = 0.f;
   int cur0 = -1, cur1 = -1;
   // what the row shares (round 6): lane t of a row holds plane t's partial sums of the three affine rows ...
@@ -252,6 +258,7 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
       // the first build of this kernel "interleaved" nothing (its assembly: 16 DMA blocks back to back, then 16 planes)
       asm volatile("" : "+v"(X[t]), "+v"(Y[t]), "+v"(Z[t])::"memory");
     }
+    each(t);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

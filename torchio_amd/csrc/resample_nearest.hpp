@@ -390,6 +390,23 @@ __global__ __launch_bounds__(256) void resample_nearest_kernel(const NearestArgs
 // fill rule is the kernel above's business), divisors the short division is proven for, unit spacing under control points
 // (the float kernel's gate) and volumes at least 48 wide (a wave = one row).
 // =====================================================================================================================
+// a channel as a raw buffer (range check = the channel's bytes) and one element of it at a byte offset
+template <int ES>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nearest_channel_rsrc(const NearestImg& g, int64_t bc, int64_t n_in) {
+  const char* src = static_cast<const char*>(g.in) + bc * n_in * ES;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, static_cast<int>(static_cast<unsigned>(n_in) * ES), 0x00020000);
+}
+template <int ES>
+__device__ __forceinline__ typename NearestBits<ES>::type nearest_buffer_load(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+  if constexpr (ES == 1) return __builtin_amdgcn_raw_buffer_load_b8(rsrc, off, 0, 0);
+  else if constexpr (ES == 2) return __builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0);
+  else if constexpr (ES == 4) return __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+  else {
+    const auto w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+    return static_cast<uint64_t>(w[0]) | (static_cast<uint64_t>(w[1]) << 32);
+  }
+}
+
 template <bool ELASTIC_POSSIBLE, int ES>
 __global__ __launch_bounds__(256, 3) void resample_nearest_exact_kernel(const NearestArgs a) {
   typedef typename NearestBits<ES>::type bits_t;
@@ -487,7 +504,12 @@ __global__ __launch_bounds__(256, 3) void resample_nearest_exact_kernel(const Ne
     }
     return;
   }
-  int offs[TI];
+  unsigned boffs[TI];  // BYTE offsets of the source voxels inside their channel, 0xFFFFFFFF = none (zero padding)
+  // the launch's first channel of this element size (there is one: the host launches per element size present)
+  int im0 = 0;
+  while (im0 < a.n_images - 1 && a.img[im0].es != ES) im0++;
+  const __amdgpu_buffer_rsrc_t rsrc0 = nearest_channel_rsrc<ES>(a.img[im0], static_cast<int64_t>(b) * a.img[im0].channels, n_in);
+  bits_t v0[TI];
   {
     CtlPlanes P{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (ELASTIC_POSSIBLE) {
@@ -517,37 +539,77 @@ __global__ __launch_bounds__(256, 3) void resample_nearest_exact_kernel(const Ne
     float X[TI], Y[TI], Z[TI];
     const bool ident = (m[0] == 1.0f) & (m[1] == 0.0f) & (m[2] == 0.0f) & (m[3] == 0.0f) & (m[4] == 0.0f) & (m[5] == 1.0f) &
                        (m[6] == 0.0f) & (m[7] == 0.0f) & (m[8] == 0.0f) & (m[9] == 0.0f) & (m[10] == 1.0f) & (m[11] == 0.0f);
+    // Plane by plane, as soon as a plane's coordinates stand: its offset on the full-rate pipes (the first build of this kernel:
+    // two quarter-rate v_mad_u64_u32, six float compares and an EXEC-masked branch per voxel) — the rounded coordinates as
+    // integers: v_cvt_i32_f32 saturates, so "0 <= xn <= S - 1" on the float is ONE unsigned compare on the integer, NaN
+    // (converted to 0) caught by two ordered compares; (ix J + iy) K + iz as two 24-bit multiply-adds (the launch gate:
+    // I J <= 2^24, channels below 2^32 bytes) — and the LOAD of the launch's first channel: the memory system works while the
+    // next plane is formed (all 16 coordinates first, then 16 loads: launch time = arithmetic + traffic, not their maximum).
+    const unsigned Hx = static_cast<unsigned>(hx), Hy = static_cast<unsigned>(hy), Hz = static_cast<unsigned>(hz);
+    const int Kes = a.K * ES, Jin = a.J;
+    auto each = [&](int t) {
+      const float x = X[t], y = Y[t], z = Z[t];
+      const int ix = static_cast<int>(rintf(x)), iy = static_cast<int>(rintf(y)), iz = static_cast<int>(rintf(z));
+      const bool ok = (static_cast<unsigned>(ix) <= Hx) & (static_cast<unsigned>(iy) <= Hy) & (static_cast<unsigned>(iz) <= Hz) &
+                      !__builtin_isunordered(x, y) & (z == z);
+      const int off = mad24(mad24(ix, Jin, iy), Kes, ES == 1 ? iz : iz * ES);
+      boffs[t] = ok ? static_cast<unsigned>(off) : 0xFFFFFFFFu;
+      v0[t] = nearest_buffer_load<ES>(rsrc0, boffs[t]);
+    };
     bool done = false;
     if constexpr (ELASTIC_POSSIBLE) {
       if (elastic) {
-        if (ident) lean_exact_planes<1, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z);
-        else if (a.affine_first) lean_exact_planes<2, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z);
-        else lean_exact_planes<3, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z);
+        if (ident) lean_exact_planes<1, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z, each);
+        else if (a.affine_first) lean_exact_planes<2, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z, each);
+        else lean_exact_planes<3, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z, each);
         done = true;
       }
     }
-    if (!done) lean_exact_planes<0, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z);
-#pragma unroll
-    for (int t = 0; t < TI; t++) offs[t] = nearest_offset(X[t], Y[t], Z[t], hx, hy, hz, a.J, a.K);
+    if (!done) lean_exact_planes<0, true, true, true, 4>(m, la, i_begin, i_last, cj, ck, li_lane, ia, P, no_dma, lane, X, Y, Z, each);
   }
 
-  // sixteen unconditional loads (a voxel without a source reads element 0 and drops it), ONE wait, the stores: as above
-  for (int im = 0; im < a.n_images; im++) {
+  // (an offset beyond the channel — 0xFFFFFFFF: no source voxel — reads as zero: the zero padding is the descriptor's range
+  // check, no select behind the load.)  The stores in the `scalar base + 32-bit vector offset` form on one running scalar
+  // pointer (lean_exact_group_store); full bricks without predicates.  Further channels of this element size: sixteen loads, the stores.
+  typedef __attribute__((address_space(1))) char* global_char_ptr;
+  typedef __attribute__((address_space(1))) bits_t* global_bits_ptr;
+  const bool full = (i_count == TI) & (nv == TJ) & (nw == TK);  // block uniform
+  const unsigned urow = static_cast<unsigned>(jo * a.Ko + ko) * static_cast<unsigned>(ES);
+  const int64_t slab_b = static_cast<int64_t>(slab) * ES;
+  auto store_channel = [&](const NearestImg& g, int64_t bc, const bits_t (&v)[TI]) {
+    global_char_ptr out_t = (global_char_ptr)(static_cast<char*>(g.out) + (bc * n_out + static_cast<int64_t>(i_begin) * slab) * ES);
+    if (full) {
+      unsigned row_off = urow;
+      asm volatile("" : "+v"(row_off));  // (in the stores' own block: instruction selection must SEE the zero extension)
+#pragma unroll
+      for (int t = 0; t < TI; t++) {
+        *(global_bits_ptr)(out_t + row_off) = v[t];
+        out_t += slab_b;
+        asm volatile("" : "+s"(out_t));
+      }
+    } else if (col_active) {
+      unsigned row_off = urow;
+      asm volatile("" : "+v"(row_off));
+      for (int t = 0; t < i_count; t++) {
+        bits_t w = v[0];
+#pragma unroll
+        for (int u = 1; u < TI; u++) w = (t == u) ? v[u] : w;  // (scalar selects: no dynamically indexed register array)
+        *(global_bits_ptr)(out_t + row_off) = w;
+        out_t += slab_b;
+      }
+    }
+  };
+  store_channel(a.img[im0], static_cast<int64_t>(b) * a.img[im0].channels, v0);
+  for (int im = im0; im < a.n_images; im++) {
     const NearestImg& g = a.img[im];
     if (g.es != ES) continue;
-    for (int c = 0; c < g.channels; c++) {
+    for (int c = (im == im0 ? 1 : 0); c < g.channels; c++) {
       const int64_t bc = static_cast<int64_t>(b) * g.channels + c;
-      const bits_t* __restrict__ src = static_cast<const bits_t*>(g.in) + bc * n_in;
-      bits_t* __restrict__ dst = static_cast<bits_t*>(g.out) + bc * n_out + col;
-      carrier_t v[TI];
+      const __amdgpu_buffer_rsrc_t rsrc = nearest_channel_rsrc<ES>(g, bc, n_in);
+      bits_t v[TI];
 #pragma unroll
-      for (int t = 0; t < TI; t++) v[t] = static_cast<carrier_t>(src[max(offs[t], 0)]);
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
-                     "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-#pragma unroll
-      for (int t = 0; t < TI; t++)
-        if (col_active && t < i_count) dst[static_cast<int64_t>(t) * slab] = offs[t] >= 0 ? static_cast<bits_t>(v[t]) : static_cast<bits_t>(0);
+      for (int t = 0; t < TI; t++) v[t] = nearest_buffer_load<ES>(rsrc, boffs[t]);
+      store_channel(g, bc, v);
     }
   }
 }
