@@ -1134,6 +1134,43 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
             return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_launch);
           int launches_left = 0;
           for (int i = 0; i < a.n_images; i++) launches_left += a.img[i].channels;
+          // round 6: two channels per launch (resample_lean_exact_pair_kernel: one descriptor round trip, one set of control planes, ONE
+          // coordinate chain for both) where the launch is an exact-coordinate one without multi-pass bricks and without a folded
+          // minimum — a subject's float32 images share their geometry.  TIO_LEAN_PAIR=0: one launch per channel (A/B)
+          if (lean_exact && a.plan_multi == 0 && min_channels == 0 && launches_left >= 2 && env.lean_pair != 0) {
+            auto kernel_pair = tight ? (a.cp != nullptr ? resample_lean_exact_pair_kernel<true, false> : resample_lean_exact_pair_kernel<false, false>)
+                                     : (a.cp != nullptr ? resample_lean_exact_pair_kernel<true, true> : resample_lean_exact_pair_kernel<false, true>);
+            if (lds_launch > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                              static_cast<int>(lds_launch)) != hipSuccess)
+              return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_launch);
+            bool have_first = false;
+            for (int i = 0; i < a.n_images; i++) {
+              const ImgArgs& g = a.img[i];
+              for (int c = 0; c < g.channels; c++) {
+                const float* in_c = static_cast<const float*>(g.in) + static_cast<int64_t>(c) * n_in;
+                float* out_c = static_cast<float*>(g.out) + static_cast<int64_t>(c) * n_out;
+                const float* fill_c = g.fill != nullptr ? g.fill + c : nullptr;
+                const int64_t in_stride = static_cast<int64_t>(g.channels) * n_in, out_stride = static_cast<int64_t>(g.channels) * n_out;
+                --launches_left;
+                if (!have_first && launches_left > 0) {  // (an odd channel out is launched alone, below)
+                  la.in = in_c; la.out = out_c; la.fill = fill_c; la.in_stride = in_stride; la.out_stride = out_stride;
+                  have_first = true;
+                  continue;
+                }
+                la.last_use = launches_left == 0;
+                la.min_keys = nullptr;
+                if (have_first) {
+                  la.in2 = in_c; la.out2 = out_c; la.fill2 = fill_c; la.in_stride2 = in_stride; la.out_stride2 = out_stride;
+                  hipLaunchKernelGGL(kernel_pair, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
+                  have_first = false;
+                } else {
+                  la.in = in_c; la.out = out_c; la.fill = fill_c; la.in_stride = in_stride; la.out_stride = out_stride;
+                  hipLaunchKernelGGL(kernel, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
+                }
+              }
+            }
+            return check_launch("tio_resample3d");
+          }
           // one plan, one launch per channel of every image (the geometry, hence the plan, is shared)
           for (int i = 0; i < a.n_images; i++) {
             const ImgArgs& g = a.img[i];

@@ -934,6 +934,12 @@ struct LeanArgs {
   // the folded minimum (tio_resample_image.out_min_dev): kMinSlots keys of this channel, or nullptr.  Only the bricks of batch
   // element 0 track what they store (a block-uniform branch into the TRACK instantiation of the sampling loop).
   uint32_t* min_keys;
+  // resample_lean_exact_pair_kernel (round 6): a SECOND channel of the same geometry — another image of the subject or another channel
+  // of this one — sampled by the same block from the same coordinates (the box is staged again into the same tile)
+  const float* in2;
+  float* out2;
+  int64_t in_stride2, out_stride2;
+  const float* fill2;
 };
 
 // FAST trilinear sample straight from global memory (bricks whose box does not fit the tile, non-finite geometry): zero

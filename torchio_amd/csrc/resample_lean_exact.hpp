@@ -365,7 +365,7 @@ __device__ __forceinline__ bool lean_exact_group_leaves(const float (&X4)[4], co
 // (through a pointer the optimiser cannot see through) and the descriptor: the call that follows the staged passes of a
 // multi-pass brick must not keep the mapping, the control-point pointers and the column's constants alive across the sampling
 // loop (first build: 24 - 60 scalar registers spilled in every instantiation, +2 ... +7 % on launches without such a brick).
-template <bool ELASTIC_POSSIBLE>
+template <bool ELASTIC_POSSIBLE, bool SECOND = false>
 __device__ __forceinline__ void lean_exact_slow_planes(unsigned brick, int states, int span_shift, uint32_t& kmin) {
   typedef __attribute__((address_space(4))) const LeanArgs* const_args_ptr;
   typedef __attribute__((address_space(4))) const int* const_int_ptr;
@@ -386,10 +386,11 @@ __device__ __forceinline__ void lean_exact_slow_planes(unsigned brick, int state
   if (!((tj < nv) & (tk < nw))) return;
   const int col_off = (j_lo + tj) * Ko + (k_lo + tk);
   const int64_t slab_b = static_cast<int64_t>(Jo) * Ko * 4;
-  const float* in_chan = ka->in + static_cast<int64_t>(b) * ka->in_stride;
-  char* out_chan = reinterpret_cast<char*>(ka->out + static_cast<int64_t>(b) * ka->out_stride);
-  const bool has_fill = ka->fill != nullptr;
-  const float fillv = has_fill ? ((const_float_ptr)ka->fill)[0] : 0.0f;
+  const float* in_chan = SECOND ? ka->in2 + static_cast<int64_t>(b) * ka->in_stride2 : ka->in + static_cast<int64_t>(b) * ka->in_stride;
+  char* out_chan = reinterpret_cast<char*>(SECOND ? ka->out2 + static_cast<int64_t>(b) * ka->out_stride2 : ka->out + static_cast<int64_t>(b) * ka->out_stride);
+  const float* fill_p = SECOND ? ka->fill2 : ka->fill;
+  const bool has_fill = fill_p != nullptr;
+  const float fillv = has_fill ? ((const_float_ptr)fill_p)[0] : 0.0f;
   const float hx = ka->hx, hy = ka->hy, hz = ka->hz;
   const float cj = static_cast<float>(j_lo + tj), ck = static_cast<float>(k_lo + tk);
   const float* cp = elastic ? ka->cp + (ka->cp_batched ? static_cast<int64_t>(b) * (ka->ni * ka->nj * ka->nk * 3) : 0) : nullptr;
@@ -425,8 +426,13 @@ __device__ __forceinline__ void lean_exact_slow_planes(unsigned brick, int state
 // the list of those bricks the planner left (first build of round 6: the pass logic inside the one kernel cost every
 // instantiation 24 - 75 spilled scalar registers, +2 ... +7 % on launches that have no such brick).  MULTI = true: the same body
 // with the pass switches compiled in.
-template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool FOLD_MIN, bool MULTI>
+// PAIR (round 6; never with FOLD_MIN or MULTI): the launch carries a second channel of the same geometry (a.in2 / out2 / fill2).  The
+// block samples it from the SAME sixteen planes of coordinates: every wave done with the tile, the same box of the second
+// channel staged into it (requested and waited for in one go — the other resident blocks cover the wait), the sampling loop again.
+// What a second launch would repeat — descriptor, control planes, the coordinate chain: about half of a block's life — is done once.
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool FOLD_MIN, bool MULTI, bool PAIR = false>
 __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsigned brick, float* s_tile) {
+  static_assert(!PAIR || (!FOLD_MIN && !MULTI), "the pair kernel has no folded minimum and no passes");
   constexpr int TI = 16, TJ = 16, TK = 16, NW = 4;
   typedef __attribute__((address_space(4))) const int* const_int_ptr;
   typedef __attribute__((address_space(4))) const float* const_float_ptr;
@@ -514,8 +520,8 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
   const int jv = min(tj, nv - 1), kw = min(tk, nw - 1);
   const int col_off = (j_lo + jv) * a.Ko + (k_lo + kw);
   const unsigned urow = static_cast<unsigned>(col_off) * 4u;
-  const bool has_fill = a.fill != nullptr;
-  const float fillv = has_fill ? ((const_float_ptr)a.fill)[0] : 0.0f;
+  bool has_fill = a.fill != nullptr;
+  float fillv = has_fill ? ((const_float_ptr)a.fill)[0] : 0.0f;
   const float hx = a.hx, hy = a.hy, hz = a.hz;
 
   const bool track = FOLD_MIN && a.min_keys != nullptr && b == 0;  // block uniform
@@ -531,6 +537,15 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
         const float val = kind == kDescGated ? in_chan[static_cast<int64_t>(t) * slab + col_off] : fillv;
         *reinterpret_cast<float*>(out_chan + t * slab_b + urow) = val;
         kmin = min(kmin, float_to_key(val));
+      }
+    }
+    if constexpr (PAIR) {
+      if (col_active) {
+        const float* in2_chan = a.in2 + static_cast<int64_t>(b) * a.in_stride2;
+        char* out2_chan = reinterpret_cast<char*>(a.out2 + static_cast<int64_t>(b) * a.out_stride2);
+        const float fillv2 = a.fill2 != nullptr ? ((const_float_ptr)a.fill2)[0] : 0.0f;
+        for (int t = i_begin; t < i_begin + i_count; t++)
+          *reinterpret_cast<float*>(out2_chan + t * slab_b + urow) = kind == kDescGated ? in2_chan[static_cast<int64_t>(t) * slab + col_off] : fillv2;
       }
     }
     if (track) publish_min();
@@ -567,6 +582,7 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
   }
   if (!any_staged) {
     lean_exact_slow_planes<ELASTIC_POSSIBLE>(brick, states, span_shift, kmin);
+    if constexpr (PAIR) lean_exact_slow_planes<ELASTIC_POSSIBLE, true>(brick, states, span_shift, kmin);
     if (track) publish_min();
     return;
   }
@@ -654,7 +670,30 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
     TIO_LE_COORDS4                                                                                                                        \
     lean_exact_group<EXACT_LERP, true, true, TRACK>(x4, y4, z4, ta, out_t, urow, slab_b, 4 * q, i_count, col_active, hx, hy, hz, has_fill, fillv, kmin); \
   }
-    if (FOLD_MIN && track) {
+    if constexpr (PAIR) {
+      // (the first channel's groups as the one-channel kernel's, then — everything it needs of the launch re-read from the argument
+      // block through a pointer the optimiser cannot see through, as the passes of a multi-pass brick do — the second channel)
+      if (full) { TIO_LE_GROUPS(false) } else { TIO_LE_GROUPS_GUARDED(false) }
+      __syncthreads();
+      typedef __attribute__((address_space(4))) const LeanArgs* const_args_ptr;
+      const_args_ptr ka = (const_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      const_int_ptr d2 = (const_int_ptr)(ka->plan + ka->B * 16) + static_cast<size_t>(brick) * kDescInts;
+      StreamBox nb;
+      nb.bx0 = d2[1]; nb.by0 = d2[2]; nb.za = d2[3]; nb.Lx = d2[4]; nb.Ly = d2[5]; nb.cpr = d2[6];
+      nb.interior = d2[0] >> 8; nb.kind = kDescStaged;
+      BoxDmaStepper<NW> step;
+      step.init(s_tile, ka->in2 + static_cast<int64_t>(b) * ka->in_stride2, nb, ka->I, ka->J, ka->K, wave, lane);
+      if (nb.interior) { while (step.left > 0) step.template issue<true>(lane); }
+      else { while (step.left > 0) step.template issue<false>(lane); }
+      has_fill = ka->fill2 != nullptr;
+      fillv = has_fill ? ((const_float_ptr)ka->fill2)[0] : 0.0f;
+      may_leave = has_fill & !nb.interior;
+      out_t = reinterpret_cast<char*>(ka->out2 + static_cast<int64_t>(b) * ka->out_stride2) + static_cast<int64_t>(i_begin) * slab_b;
+      tile_dma_wait_all();
+      __syncthreads();
+      if (full) { TIO_LE_GROUPS(false) } else { TIO_LE_GROUPS_GUARDED(false) }
+    } else if (FOLD_MIN && track) {
       if (full) { TIO_LE_GROUPS(true) } else { TIO_LE_GROUPS_GUARDED(true) }
       publish_min();
     } else {
@@ -728,6 +767,14 @@ template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, int WAVES_PER_SIMD, bool FOLD_
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void resample_lean_exact_kernel(const LeanArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lean_exact_brick<ELASTIC_POSSIBLE, EXACT_LERP, FOLD_MIN, false>(a, xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items)), smem);
+}
+
+// ... two channels of one geometry per block (PAIR above): what a subject with several float32 images — or an image with several
+// channels — launches instead of one kernel per channel when the launch has no multi-pass bricks and no folded minimum
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP>
+__global__ __launch_bounds__(256, 3) void resample_lean_exact_pair_kernel(const LeanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  lean_exact_brick<ELASTIC_POSSIBLE, EXACT_LERP, false, false, true>(a, xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items)), smem);
 }
 
 // ... the same with the pass switches compiled in: what a launch MOST of whose bricks need passes takes (the caller's hint
