@@ -14,8 +14,8 @@ import bench  # noqa: E402
 import torchio_amd as tio  # noqa: E402
 
 warnings.simplefilter("ignore")
-mode = os.environ.get("TIO_PROFILE_MODE", "philox,fast").split(",")  # noise rng, resample (= stencil) precision
-tio.set_noise_rng(mode[0]); tio.set_resample_precision(mode[1]); tio.set_stencil_precision(mode[1])
+mode = os.environ.get("TIO_PROFILE_MODE", "philox,tight").split(",")  # noise rng, resample precision (the stencil's follows as in bench.py)
+tio.set_noise_rng(mode[0]); tio.set_resample_precision(mode[1]); tio.set_stencil_precision(bench.stencil_mode(mode[1]))
 transform = bench.build_transform()
 batch = bench.make_batch(256, 8, 0, "cuda")
 for _ in range(10):
@@ -33,4 +33,5 @@ for _ in range(50):
     transform(batch)
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats(sys.argv[1] if len(sys.argv) > 1 else "tottime").print_stats(75)
+for key in (sys.argv[1:] or ["tottime", "cumulative"]):
+    pstats.Stats(pr).sort_stats(key).print_stats(110)

@@ -1,5 +1,5 @@
 """Round 6: config 5 (one 512^3 subject: 2 x float32 + int16 labels through tio.Spatial) per step, by switch:
-label maps on the side stream (ops.set_label_stream), two channels per exact-coordinate launch (TIO_LEAN_PAIR)."""
+the label channel riding along the images' last launch (TIO_LEAN_LABEL), two channels per exact-coordinate launch (TIO_LEAN_PAIR)."""
 import json
 import os
 import sys
@@ -43,13 +43,13 @@ reference = None
 for precision in ("tight", "exact"):
     tio.set_resample_precision(precision)
     for rep in range(2):
-        for side in (True, False):
+        for label in ("1", "0"):
             for pair in ("1", "0"):
                 os.environ["TIO_LEAN_PAIR"] = pair
+                os.environ["TIO_LEAN_LABEL"] = label
                 ops.reload_env()
-                ops.set_label_stream(side)
                 result, ms = timed()
-                key = f"{precision},label_stream={int(side)},pair={pair}"
+                key = f"{precision},label_rides={label},pair={pair}"
                 out.setdefault(key, []).append(round(ms, 4))
                 images = {name: result.images[name].data for name in ("t1", "t2", "seg")}
                 if reference is None or reference[0] != precision:

@@ -58,6 +58,7 @@ static const EnvSwitches* parse_env() {
   e->lean_multi = num("TIO_LEAN_MULTI", 1);
   e->nearest_exact = num("TIO_NEAREST_EXACT", 1);
   e->lean_pair = num("TIO_LEAN_PAIR", 1);
+  e->lean_label = num("TIO_LEAN_LABEL", 1);
   e->nearest_lds = num("TIO_NEAREST_LDS", -1);
   e->fast_fill_recheck = num("TIO_FAST_FILL_RECHECK", 1) != 0;
   e->conv_no_fuse = getenv("TIO_CONV_NO_FUSE") != nullptr;

@@ -39,6 +39,7 @@ struct EnvSwitches {
   int nearest_exact = 1;         // TIO_NEAREST_EXACT=0: label maps without a fill rule keep the FAST-line kernel of rounds 3 - 5 (A/B)
   int nearest_lds = -1;          // TIO_NEAREST_LDS: bytes of (unused) dynamic LDS per block of resample_nearest_exact_kernel — an occupancy knob (A/B; -1: the launch's own choice)
   int lean_pair = 1;             // TIO_LEAN_PAIR=0: one exact-coordinate launch per channel (until round 6; A/B)
+  int lean_label = 1;            // TIO_LEAN_LABEL=0: a call's label channel never rides along the images' exact-coordinate launch (until round 6; A/B)
   int lean_multi = 1;            // TIO_LEAN_MULTI=0: no multi-pass bricks (boxes beyond the tile sample voxel by voxel, as until round 5: A/B)
   int lean_interleave = 1;       // TIO_LEAN_INTERLEAVE (0: the exact-coordinate kernel issues its whole box before phase A, A/B)
   int fast_fill_recheck = 1;     // TIO_FAST_FILL_RECHECK (0: the FAST fill rule decides alone, A/B)

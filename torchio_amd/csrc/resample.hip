@@ -18,6 +18,7 @@
 // "interior" path (all 8 taps of all 64 lanes in bounds: no predication, no
 // mask arithmetic — the mask is exactly > 0.5 there), (3) IEEE-exact division
 // by reciprocal + two FMA refinements instead of the 12-instruction expansion.
+#include <functional>
 #include <stdlib.h>
 #include <string.h>
 
@@ -796,6 +797,14 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_cp = a.cp != nullptr ? a.ni * a.nj * a.nk * 3 : 0;
 
+  // round 6: ONE plain label channel of a call that also samples float32 images may ride along the images' last exact-coordinate
+  // launch (resample_lean_exact_label_kernel) instead of taking its own kernel; whatever road the images take in the end — every
+  // return below — the label map is sampled: if nobody has taken it along, its own launch goes out when this scope is left
+  struct DeferredLaunch {
+    std::function<void()> launch;
+    ~DeferredLaunch() { if (launch) launch(); }
+  } label_rides;
+  int label_es = 0;
   if (nn.n_images > 0) {
     nn.B = a.B; nn.I = a.I; nn.J = a.J; nn.K = a.K; nn.Io = a.Io; nn.Jo = a.Jo; nn.Ko = a.Ko; nn.affine_first = a.affine_first;
     nn.mapping = a.mapping; nn.cp = a.cp; nn.cp_skip = a.cp_skip; nn.passthrough = a.passthrough;
@@ -829,6 +838,19 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
       const int64_t n_in_e = static_cast<int64_t>(nn.I) * nn.J * nn.K, n_out_e = static_cast<int64_t>(nn.Io) * nn.Jo * nn.Ko;
       const bool nn_narrow = static_cast<int64_t>(nn.I) * nn.J <= (1 << 24) && static_cast<int64_t>(nn.K) * es < (1 << 24) &&
                              n_in_e * es < (int64_t{1} << 32) - 16 && n_out_e * es < (int64_t{1} << 32) - 16;
+      if (nn_exact && nn_narrow && env.lean_label != 0 && nn.n_images == 1 && nn.img[0].channels == 1 && es <= 4 && a.n_images > 0 && pv.n_images == 0 &&
+          spl.n_images == 0 && !any_adjoint) {
+        const unsigned nn_lds = env.nearest_lds >= 0 ? static_cast<unsigned>(env.nearest_lds) : (nn.cp == nullptr ? 52000u : 0u);
+        label_es = es;
+        label_rides.launch = [nn, grid, block, nn_lds, s, es]() {
+#define TIO_NN_EXACT(ES)                                                                                                \
+  if (nn.cp != nullptr) hipLaunchKernelGGL((resample_nearest_exact_kernel<true, ES>), grid, block, nn_lds, s, nn);           \
+  else hipLaunchKernelGGL((resample_nearest_exact_kernel<false, ES>), grid, block, nn_lds, s, nn);
+          if (es == 1) { TIO_NN_EXACT(1) } else if (es == 2) { TIO_NN_EXACT(2) } else { TIO_NN_EXACT(4) }
+#undef TIO_NN_EXACT
+        };
+        continue;
+      }
       if (nn_exact && nn_narrow) {
         // resident blocks per CU through UNUSED dynamic LDS: without control points the kernel holds 61 registers (eight blocks per CU),
         // and eight blocks' slanted input footprints evict one another's cache lines — three blocks per CU measured 0.236 -> 0.210 ms
@@ -1136,13 +1158,23 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
           for (int i = 0; i < a.n_images; i++) launches_left += a.img[i].channels;
           // round 6: two channels per launch (resample_lean_exact_pair_kernel: one descriptor round trip, one set of control planes, ONE
           // coordinate chain for both) where the launch is an exact-coordinate one without multi-pass bricks and without a folded
-          // minimum — a subject's float32 images share their geometry.  TIO_LEAN_PAIR=0: one launch per channel (A/B)
-          if (lean_exact && a.plan_multi == 0 && min_channels == 0 && launches_left >= 2 && env.lean_pair != 0) {
+          // minimum — a subject's float32 images share their geometry — and the call's label channel, if one waits (label_rides), with the
+          // last of them (resample_lean_exact_label_kernel).  TIO_LEAN_PAIR=0: one launch per channel, TIO_LEAN_LABEL=0: the label map's own kernel (A/B)
+          const bool label_here = static_cast<bool>(label_rides.launch) && lean_exact && a.plan_multi == 0 && min_channels == 0 && a.passthrough == nn.passthrough;
+          if (lean_exact && a.plan_multi == 0 && min_channels == 0 && ((launches_left >= 2 && env.lean_pair != 0) || label_here)) {
+            const bool pairs = launches_left >= 2 && env.lean_pair != 0;
             auto kernel_pair = tight ? (a.cp != nullptr ? resample_lean_exact_pair_kernel<true, false> : resample_lean_exact_pair_kernel<false, false>)
                                      : (a.cp != nullptr ? resample_lean_exact_pair_kernel<true, true> : resample_lean_exact_pair_kernel<false, true>);
-            if (lds_launch > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                              static_cast<int>(lds_launch)) != hipSuccess)
+            auto kernel_label_pair = tight ? (a.cp != nullptr ? resample_lean_exact_label_kernel<true, false, true> : resample_lean_exact_label_kernel<false, false, true>)
+                                           : (a.cp != nullptr ? resample_lean_exact_label_kernel<true, true, true> : resample_lean_exact_label_kernel<false, true, true>);
+            auto kernel_label_one = tight ? (a.cp != nullptr ? resample_lean_exact_label_kernel<true, false, false> : resample_lean_exact_label_kernel<false, false, false>)
+                                          : (a.cp != nullptr ? resample_lean_exact_label_kernel<true, true, false> : resample_lean_exact_label_kernel<false, true, false>);
+            if (lds_launch > 48 * 1024 &&
+                (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_pair), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_launch)) != hipSuccess ||
+                 (label_here && (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_label_pair), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_launch)) != hipSuccess ||
+                                 hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_label_one), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_launch)) != hipSuccess))))
               return fail(TIO_ERR_LAUNCH, "tio_resample3d: cannot reserve %zu bytes of LDS", lds_launch);
+            if (label_here) { la.lab_in = nn.img[0].in; la.lab_out = nn.img[0].out; la.lab_es = label_es; }
             bool have_first = false;
             for (int i = 0; i < a.n_images; i++) {
               const ImgArgs& g = a.img[i];
@@ -1152,23 +1184,27 @@ static int resample3d_impl(const tio_resample_geom* geom, int32_t n_images, cons
                 const float* fill_c = g.fill != nullptr ? g.fill + c : nullptr;
                 const int64_t in_stride = static_cast<int64_t>(g.channels) * n_in, out_stride = static_cast<int64_t>(g.channels) * n_out;
                 --launches_left;
-                if (!have_first && launches_left > 0) {  // (an odd channel out is launched alone, below)
+                if (pairs && !have_first && launches_left > 0) {  // (an odd channel out is launched alone, below)
                   la.in = in_c; la.out = out_c; la.fill = fill_c; la.in_stride = in_stride; la.out_stride = out_stride;
                   have_first = true;
                   continue;
                 }
                 la.last_use = launches_left == 0;
                 la.min_keys = nullptr;
+                const bool with_label = label_here && launches_left == 0;
                 if (have_first) {
                   la.in2 = in_c; la.out2 = out_c; la.fill2 = fill_c; la.in_stride2 = in_stride; la.out_stride2 = out_stride;
-                  hipLaunchKernelGGL(kernel_pair, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
+                  if (with_label) hipLaunchKernelGGL(kernel_label_pair, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
+                  else hipLaunchKernelGGL(kernel_pair, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
                   have_first = false;
                 } else {
                   la.in = in_c; la.out = out_c; la.fill = fill_c; la.in_stride = in_stride; la.out_stride = out_stride;
-                  hipLaunchKernelGGL(kernel, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
+                  if (with_label) hipLaunchKernelGGL(kernel_label_one, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
+                  else hipLaunchKernelGGL(kernel, dim3(grid_launch), dim3(block_launch), lds_launch, s, la);
                 }
               }
             }
+            if (label_here) label_rides.launch = nullptr;  // (taken along)
             return check_launch("tio_resample3d");
           }
           // one plan, one launch per channel of every image (the geometry, hence the plan, is shared)

@@ -940,6 +940,11 @@ struct LeanArgs {
   float* out2;
   int64_t in_stride2, out_stride2;
   const float* fill2;
+  // resample_lean_exact_label_kernel (round 6): ONE nearest-neighbour label channel of the same geometry riding along — element bits of
+  // lab_es bytes (1, 2 or 4), no fill rule (zero padding) — sampled from the same coordinates behind the float channels
+  const void* lab_in;
+  void* lab_out;
+  int lab_es;
 };
 
 // FAST trilinear sample straight from global memory (bricks whose box does not fit the tile, non-finite geometry): zero

@@ -365,7 +365,21 @@ __device__ __forceinline__ bool lean_exact_group_leaves(const float (&X4)[4], co
 // (through a pointer the optimiser cannot see through) and the descriptor: the call that follows the staged passes of a
 // multi-pass brick must not keep the mapping, the control-point pointers and the column's constants alive across the sampling
 // loop (first build: 24 - 60 scalar registers spilled in every instantiation, +2 ... +7 % on launches without such a brick).
-template <bool ELASTIC_POSSIBLE, bool SECOND = false>
+// element bits of a label channel (1 / 2 / 4 bytes, block uniform) at an element offset, and their store
+__device__ __forceinline__ unsigned lean_label_load(const void* chan, int es, int64_t off) {
+  if (es == 1) return static_cast<const uint8_t*>(chan)[off];
+  if (es == 2) return static_cast<const uint16_t*>(chan)[off];
+  return static_cast<const uint32_t*>(chan)[off];
+}
+__device__ __forceinline__ void lean_label_store(void* chan, int es, int64_t off, unsigned bits) {
+  if (es == 1) static_cast<uint8_t*>(chan)[off] = static_cast<uint8_t>(bits);
+  else if (es == 2) static_cast<uint16_t*>(chan)[off] = static_cast<uint16_t>(bits);
+  else static_cast<uint32_t*>(chan)[off] = bits;
+}
+
+// LABEL (only with SECOND = false): the brick's label voxels as well, from the coordinates this road forms anyway (every plane of a
+// brick that is not staged at all — the only bricks a label launch sends here)
+template <bool ELASTIC_POSSIBLE, bool SECOND = false, bool LABEL = false>
 __device__ __forceinline__ void lean_exact_slow_planes(unsigned brick, int states, int span_shift, uint32_t& kmin) {
   typedef __attribute__((address_space(4))) const LeanArgs* const_args_ptr;
   typedef __attribute__((address_space(4))) const int* const_int_ptr;
@@ -415,6 +429,16 @@ __device__ __forceinline__ void lean_exact_slow_planes(unsigned brick, int state
       float x, y, z;
       exact_voxel_coords<ELASTIC_POSSIBLE>(ea, m, elastic, cp, lj, lk, i_begin + t, cj, ck, x, y, z);
       val = lean_exact_gather(in_chan, ka->J, ka->K, x, y, z, has_fill, fillv, hx, hy, hz);
+      if constexpr (LABEL) {
+        // nearbyint per axis, zero padding (resample_nearest.hpp: nearest_offset), element bits
+        const float xn = rintf(x), yn = rintf(y), zn = rintf(z);
+        const bool ok = (xn >= 0.0f) & (xn <= hx) & (yn >= 0.0f) & (yn <= hy) & (zn >= 0.0f) & (zn <= hz);  // NaN fails
+        const int64_t n_in_l = static_cast<int64_t>(ka->I) * ka->J * ka->K, n_out_l = static_cast<int64_t>(Io) * Jo * Ko;
+        const int es = ka->lab_es;
+        unsigned bits = 0u;
+        if (ok) bits = lean_label_load(ka->lab_in, es, b * n_in_l + (static_cast<int64_t>(static_cast<int>(xn)) * ka->J + static_cast<int>(yn)) * ka->K + static_cast<int>(zn));
+        lean_label_store(ka->lab_out, es, b * n_out_l + static_cast<int64_t>(i_begin + t) * (static_cast<int64_t>(Jo) * Ko) + col_off, bits);
+      }
     }
     *reinterpret_cast<float*>(out_chan + (i_begin + t) * slab_b + static_cast<unsigned>(col_off) * 4u) = val;
     kmin = min(kmin, float_to_key(val));
@@ -430,9 +454,105 @@ __device__ __forceinline__ void lean_exact_slow_planes(unsigned brick, int state
 // block samples it from the SAME sixteen planes of coordinates: every wave done with the tile, the same box of the second
 // channel staged into it (requested and waited for in one go — the other resident blocks cover the wait), the sampling loop again.
 // What a second launch would repeat — descriptor, control planes, the coordinate chain: about half of a block's life — is done once.
-template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool FOLD_MIN, bool MULTI, bool PAIR = false>
+// LABEL (round 6; never with FOLD_MIN or MULTI): ONE nearest-neighbour label channel of the same geometry rides along (a.lab_in /
+// lab_out / lab_es).  Its voxels depend on the SAME coordinates through three roundings, and its own kernel (resample_nearest.hpp:
+// resample_nearest_exact_kernel, 86 vector instructions per voxel with control points) spends two thirds of them forming those
+// coordinates again: here the tail alone — offset on the full-rate pipes, a buffer load whose range check is the zero padding, a store —
+// runs behind the float channels, ~20 instructions per voxel.
+// ... in two halves: the LOADS go out as soon as the sixteen planes of coordinates stand — in front of the wait for the box, which then
+// leaves exactly these sixteen in flight (`tile_dma_wait_keep16`) — and land while the float channels are sampled (three resident blocks
+// per CU hide little: with loads and stores together behind the float channels the tail cost as much as the label map's own kernel); the
+// STORES close the block.
+__device__ __forceinline__ void tile_dma_wait_keep16() { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void lean_exact_label_issue(const float (&X)[16], const float (&Y)[16], const float (&Z)[16], int b, unsigned (&vlab)[16]) {
+  typedef __attribute__((address_space(4))) const LeanArgs* const_args_ptr;
+  const_args_ptr ka = (const_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const int es = ka->lab_es;  // block uniform
+  const int J = ka->J, Kes = ka->K * es;
+  const unsigned Hx = static_cast<unsigned>(ka->hx), Hy = static_cast<unsigned>(ka->hy), Hz = static_cast<unsigned>(ka->hz);
+  const int64_t n_in = static_cast<int64_t>(ka->I) * ka->J * ka->K;
+  char* src = static_cast<char*>(const_cast<void*>(ka->lab_in)) + b * n_in * es;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(src, 0, static_cast<int>(static_cast<unsigned>(n_in) * static_cast<unsigned>(es)), 0x00020000);
+  const int sh = es >> 1;  // 1 / 2 / 4 bytes: shift 0 / 1 / 2
+  unsigned boffs[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const float x = X[t], y = Y[t], z = Z[t];
+    const int ix = static_cast<int>(rintf(x)), iy = static_cast<int>(rintf(y)), iz = static_cast<int>(rintf(z));
+    const bool ok = (static_cast<unsigned>(ix) <= Hx) & (static_cast<unsigned>(iy) <= Hy) & (static_cast<unsigned>(iz) <= Hz) &
+                    !__builtin_isunordered(x, y) & (z == z);
+    int off;
+    {  // (ix J + iy) (K es) + iz es: two 24-bit multiply-adds (the launch gate: I J <= 2^24, the channel below 2^32 bytes)
+      int t1;
+      asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t1) : "v"(ix), "v"(J), "v"(iy));
+      const int izb = iz << sh;
+      asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(t1), "v"(Kes), "v"(izb));
+    }
+    boffs[t] = ok ? static_cast<unsigned>(off) : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(boffs[t]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // (exactly sixteen vector-memory instructions whatever the element size: the wait above counts them)
+  if (ka->ablate & 256) {  // (measurement: TIO_TILE_ABLATE=256 — no label loads; sixteen loads of offset 0 keep the count)
+#pragma unroll
+    for (int t = 0; t < 16; t++) vlab[t] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, 0u, 0, 0) + boffs[t];
+  } else if (es == 1) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) vlab[t] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, boffs[t], 0, 0);
+  } else if (es == 2) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) vlab[t] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, boffs[t], 0, 0);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 16; t++) vlab[t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, boffs[t], 0, 0);
+  }
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void lean_exact_label_store(const unsigned (&vlab)[16], int b, int i_begin, int col_off, int i_count, bool col_active) {
+  typedef __attribute__((address_space(4))) const LeanArgs* const_args_ptr;
+  typedef __attribute__((address_space(1))) char* global_char_ptr;
+  const_args_ptr ka = (const_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const int es = ka->lab_es;
+  const int sh = es >> 1;
+  const int64_t slab = static_cast<int64_t>(ka->Jo) * ka->Ko;
+  const int64_t n_out = static_cast<int64_t>(ka->Io) * slab;
+  global_char_ptr out_t = (global_char_ptr)(static_cast<char*>(ka->lab_out) + (b * n_out + static_cast<int64_t>(i_begin) * slab) * es);
+  const int64_t slab_b = slab * es;
+  unsigned row_off = static_cast<unsigned>(col_off) << sh;
+#define TIO_LE_LABEL_STORES(BITS_T)                                                             \
+  {                                                                                             \
+    typedef __attribute__((address_space(1))) BITS_T* global_bits_ptr;                          \
+    asm volatile("" : "+v"(row_off));                                                           \
+    if constexpr (!GUARD) {                                                                     \
+      _Pragma("unroll") for (int t = 0; t < 16; t++) {                                          \
+        *(global_bits_ptr)(out_t + row_off) = static_cast<BITS_T>(vlab[t]);                     \
+        out_t += slab_b;                                                                        \
+        asm volatile("" : "+s"(out_t));                                                         \
+      }                                                                                         \
+    } else if (col_active) {                                                                    \
+      for (int t = 0; t < i_count; t++) {                                                       \
+        unsigned w = vlab[0];                                                                   \
+        _Pragma("unroll") for (int u = 1; u < 16; u++) w = (t == u) ? vlab[u] : w;              \
+        *(global_bits_ptr)(out_t + row_off) = static_cast<BITS_T>(w);                           \
+        out_t += slab_b;                                                                        \
+      }                                                                                         \
+    }                                                                                           \
+  }
+  if (ka->ablate & 512) return;  // (measurement: TIO_TILE_ABLATE=512 — no label stores)
+  if (es == 1) TIO_LE_LABEL_STORES(uint8_t)
+  else if (es == 2) TIO_LE_LABEL_STORES(uint16_t)
+  else TIO_LE_LABEL_STORES(uint32_t)
+#undef TIO_LE_LABEL_STORES
+}
+
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool FOLD_MIN, bool MULTI, bool PAIR = false, bool LABEL = false>
 __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsigned brick, float* s_tile) {
   static_assert(!PAIR || (!FOLD_MIN && !MULTI), "the pair kernel has no folded minimum and no passes");
+  static_assert(!LABEL || (!FOLD_MIN && !MULTI), "a label channel rides along launches without a folded minimum and without passes");
   constexpr int TI = 16, TJ = 16, TK = 16, NW = 4;
   typedef __attribute__((address_space(4))) const int* const_int_ptr;
   typedef __attribute__((address_space(4))) const float* const_float_ptr;
@@ -539,6 +659,16 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
         kmin = min(kmin, float_to_key(val));
       }
     }
+    if constexpr (LABEL) {
+      if (col_active) {  // gated-out element: the label map's bits copied; nothing of the volume in sight: zero padding
+        const int es = a.lab_es;
+        const int64_t n_out_l = static_cast<int64_t>(a.Io) * slab;
+        for (int t = i_begin; t < i_begin + i_count; t++) {
+          const int64_t e = b * n_out_l + static_cast<int64_t>(t) * slab + col_off;
+          lean_label_store(a.lab_out, es, e, kind == kDescGated ? lean_label_load(a.lab_in, es, e) : 0u);
+        }
+      }
+    }
     if constexpr (PAIR) {
       if (col_active) {
         const float* in2_chan = a.in2 + static_cast<int64_t>(b) * a.in_stride2;
@@ -581,7 +711,7 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
     for (int pass = 0; pass < nsplit; pass++) any_staged |= ((states >> (4 * pass)) & 0xF) == kPassStaged;
   }
   if (!any_staged) {
-    lean_exact_slow_planes<ELASTIC_POSSIBLE>(brick, states, span_shift, kmin);
+    lean_exact_slow_planes<ELASTIC_POSSIBLE, false, LABEL>(brick, states, span_shift, kmin);
     if constexpr (PAIR) lean_exact_slow_planes<ELASTIC_POSSIBLE, true>(brick, states, span_shift, kmin);
     if (track) publish_min();
     return;
@@ -642,7 +772,14 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
   };
   set_tile_addr(bx);
 
-  tile_dma_wait_all();
+  unsigned vlab[16];
+  (void)vlab;
+  if constexpr (LABEL) {
+    lean_exact_label_issue(X, Y, Z, b, vlab);
+    tile_dma_wait_keep16();
+  } else {
+    tile_dma_wait_all();
+  }
   __syncthreads();
 
   // ---- phase B: sample.  The fill rule only matters where a tap can leave the volume: interior boxes never, the others
@@ -693,6 +830,14 @@ __device__ __forceinline__ void lean_exact_brick(const LeanArgs& a, const unsign
       tile_dma_wait_all();
       __syncthreads();
       if (full) { TIO_LE_GROUPS(false) } else { TIO_LE_GROUPS_GUARDED(false) }
+      if constexpr (LABEL) {
+        if (full) lean_exact_label_store<false>(vlab, b, i_begin, col_off, i_count, col_active);
+        else lean_exact_label_store<true>(vlab, b, i_begin, col_off, i_count, col_active);
+      }
+    } else if constexpr (LABEL) {
+      if (full) { TIO_LE_GROUPS(false) } else { TIO_LE_GROUPS_GUARDED(false) }
+      if (full) lean_exact_label_store<false>(vlab, b, i_begin, col_off, i_count, col_active);
+      else lean_exact_label_store<true>(vlab, b, i_begin, col_off, i_count, col_active);
     } else if (FOLD_MIN && track) {
       if (full) { TIO_LE_GROUPS(true) } else { TIO_LE_GROUPS_GUARDED(true) }
       publish_min();
@@ -775,6 +920,13 @@ template <bool ELASTIC_POSSIBLE, bool EXACT_LERP>
 __global__ __launch_bounds__(256, 3) void resample_lean_exact_pair_kernel(const LeanArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lean_exact_brick<ELASTIC_POSSIBLE, EXACT_LERP, false, false, true>(a, xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items)), smem);
+}
+
+// ... one or two float32 channels AND a nearest-neighbour label channel per block (LABEL above): config 5's whole call in one launch
+template <bool ELASTIC_POSSIBLE, bool EXACT_LERP, bool PAIR>
+__global__ __launch_bounds__(256, 3) void resample_lean_exact_label_kernel(const LeanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  lean_exact_brick<ELASTIC_POSSIBLE, EXACT_LERP, false, false, PAIR, true>(a, xcd_remap(blockIdx.x, static_cast<unsigned>(a.n_items)), smem);
 }
 
 // ... the same with the pass switches compiled in: what a launch MOST of whose bricks need passes takes (the caller's hint
