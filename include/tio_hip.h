@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TIO_ABI_VERSION 15
+#define TIO_ABI_VERSION 16
 #define TIO_MAX_IMAGES 8 /* images resampled per launch with shared coordinates */
 
 typedef enum tio_status {
@@ -280,6 +280,21 @@ int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t dtype,
                          const float* taps_dev, int32_t taps_batched,
                          int32_t tap_stride, const int32_t radius[3],
                          const uint8_t* skip_dev, void* stream);
+
+/*
+ * Backward of tio_separable_conv3d with respect to x (ABI 16): gx = A_I^T A_J^T A_K^T gy, where A_a is the
+ * replicate-padded correlation along axis a — the transpose of a CLAMPED stencil folds the taps that were
+ * clamped onto a border voxel back onto it.  What autograd computes through the reference's
+ * F.pad(mode="replicate") + grouped conv3d per axis (blur.py:157-252), one gather kernel per active axis.
+ *   gy, gx: (B, C, I, J, K) float32 (the reference computes the blur, hence its backward, in float32:
+ *           blur.py:173); taps_dev / taps_batched / tap_stride / radius / skip_dev as in the forward call;
+ *           rows with skip_dev[b] != 0 pass their gradient through (the forward copied them);
+ *   tmp:    scratch with the size of gx (may be NULL when at most one axis is active).
+ */
+int tio_separable_conv3d_adjoint(const float* gy, float* gx, float* tmp, int32_t batch,
+                                 int32_t channels, const int32_t shape[3], const float* taps_dev,
+                                 int32_t taps_batched, int32_t tap_stride, const int32_t radius[3],
+                                 const uint8_t* skip_dev, void* stream);
 
 /*
  * Blur with its neighbours folded in: y = Noise(Blur(BiasField(x))) in the separable passes

@@ -718,6 +718,64 @@ int tio_oracle_separable_conv3d(const void* x, void* y, void* tmp, int32_t dtype
   return TIO_OK;
 }
 
+/* Transpose of conv_axis: every product of the forward pass goes back where its factor came from (the literal adjoint of
+ * blur.py:157-252's F.pad(mode="replicate") + conv3d along one axis — border voxels collect the taps that were clamped onto them). */
+static void conv_axis_adjoint(const float* gy, float* gx, const int32_t shape[3], int axis, const float* taps, int32_t r) {
+  const int32_t I = shape[0], J = shape[1], K = shape[2];
+  const int64_t stride = axis == 0 ? (int64_t)J * K : (axis == 1 ? K : 1);
+  const int32_t n = shape[axis];
+  const int64_t total = (int64_t)I * J * K;
+  for (int64_t e = 0; e < total; e++) gx[e] = 0.0f;
+  for (int32_t i = 0; i < I; i++)
+    for (int32_t j = 0; j < J; j++)
+      for (int32_t k = 0; k < K; k++) {
+        const int64_t idx = ((int64_t)i * J + j) * K + k;
+        const int32_t p = axis == 0 ? i : (axis == 1 ? j : k);
+        const int64_t line = idx - (int64_t)p * stride;
+        for (int32_t t = 0; t <= 2 * r; t++) {
+          int32_t q = p + t - r;
+          q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+          gx[line + (int64_t)q * stride] += taps[t] * gy[idx];
+        }
+      }
+}
+
+/* Backward of tio_oracle_separable_conv3d with respect to x (float32): the axes' transposes in reverse order; skipped rows pass
+ * their gradient through. */
+int tio_oracle_separable_conv3d_adjoint(const float* gy, float* gx, float* tmp, int32_t batch, int32_t channels,
+                                        const int32_t shape[3], const float* taps, int32_t taps_batched, int32_t tap_stride,
+                                        const int32_t radius[3], const uint8_t* skip, void* stream) {
+  (void)stream;
+  (void)tmp;
+  const int64_t n = (int64_t)shape[0] * shape[1] * shape[2];
+  float* a = (float*)__builtin_malloc((size_t)n * sizeof(float));
+  float* bbuf = (float*)__builtin_malloc((size_t)n * sizeof(float));
+  if (!a || !bbuf) return TIO_ERR_INVALID_ARGUMENT;
+  for (int32_t b = 0; b < batch; b++)
+    for (int32_t c = 0; c < channels; c++) {
+      const int64_t base = ((int64_t)b * channels + c) * n;
+      if (skip && skip[b]) {
+        memcpy(gx + base, gy + base, (size_t)n * sizeof(float));
+        continue;
+      }
+      memcpy(a, gy + base, (size_t)n * sizeof(float));
+      const float* t = taps + (taps_batched ? (int64_t)b * 3 * tap_stride : 0);
+      float* src = a;
+      float* dst = bbuf;
+      for (int axis = 2; axis >= 0; axis--) {
+        if (radius[axis] <= 0) continue;
+        conv_axis_adjoint(src, dst, shape, axis, t + (int64_t)axis * tap_stride, radius[axis]);
+        float* sw = src;
+        src = dst;
+        dst = sw;
+      }
+      memcpy(gx + base, src, (size_t)n * sizeof(float));
+    }
+  __builtin_free(a);
+  __builtin_free(bbuf);
+  return TIO_OK;
+}
+
 /* ------------------------------------------------------------------------ */
 /* BiasField: bias_field.py:201-255, 296-341                                  */
 /* ------------------------------------------------------------------------ */

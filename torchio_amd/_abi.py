@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_IMAGES = 8
 
 # tio_status
@@ -91,6 +91,11 @@ PROTOTYPES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _I32x3,
          C.c_void_p, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_void_p],
+    ),
+    "separable_conv3d_adjoint": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _I32x3, C.c_void_p, C.c_int32, C.c_int32, _I32x3,
+         C.c_void_p, C.c_void_p],
     ),
     "bias_field_apply": (
         C.c_int,

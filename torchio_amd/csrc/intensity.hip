@@ -1456,6 +1456,102 @@ extern "C" int tio_separable_conv3d(const void* x, void* y, void* tmp, int32_t d
   return fail(TIO_ERR_UNSUPPORTED_DTYPE, "tio_separable_conv3d: dtype %d", dtype);
 }
 
+// =============================================================================
+// Backward of the replicate-padded separable correlation (ABI 16)
+// =============================================================================
+// y[p] = sum_t w[t] x[clamp(p + t - r)] along one axis.  Its transpose as a GATHER (one thread per element of gx, lanes along K):
+// gx[m] = sum_p gy[p] W(p, m), W(p, m) = the taps t with clamp(p + t - r) == m — for every p within r of m the one tap
+// t = m - p + r, and on the two border voxels also every tap that was clamped onto them: m == 0 collects t < r - p of
+// p = 0 .. r - 1, m == n - 1 collects t > n - 1 - p + r of p = n - r .. n - 1.  Off the hot path (nobody trains through a
+// Gaussian blur in the pipeline of BASELINE.json): plain global loads, float32 accumulation in ascending p.
+struct ConvAdjointArgs {
+  const float* gy;
+  float* gx;
+  const float* taps;  // (1|B, 3, tap_stride)
+  const uint8_t* skip;
+  int64_t n_spatial, n_total, stride;
+  int channels, extent, r, axis, tap_stride, taps_batched, J, K;
+};
+
+__global__ __launch_bounds__(kBlock) void conv_axis_adjoint_kernel(const ConvAdjointArgs a) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= a.n_total) return;
+  const int b = static_cast<int>(e / (a.n_spatial * a.channels));
+  if (a.skip != nullptr && a.skip[b] != 0) {
+    a.gx[e] = a.gy[e];
+    return;
+  }
+  const int64_t v = e % a.n_spatial;
+  const int k = static_cast<int>(v % a.K), j = static_cast<int>((v / a.K) % a.J), i = static_cast<int>(v / (static_cast<int64_t>(a.K) * a.J));
+  const int m = a.axis == 0 ? i : (a.axis == 1 ? j : k);
+  const int n = a.extent, r = a.r;
+  const float* w = a.taps + (a.taps_batched ? static_cast<int64_t>(b) * 3 * a.tap_stride : 0) + static_cast<int64_t>(a.axis) * a.tap_stride;
+  const float* line = a.gy + (e - static_cast<int64_t>(m) * a.stride);
+  float acc = 0.0f;
+  const int lo = max(0, m - r), hi = min(n - 1, m + r);
+  for (int p = lo; p <= hi; p++) acc = __builtin_fmaf(w[m - p + r], line[static_cast<int64_t>(p) * a.stride], acc);
+  if (m == 0) {  // taps clamped onto the first voxel
+    for (int p = 0; p <= min(r - 1, n - 1); p++) {
+      float clamped = 0.0f;
+      for (int t = 0; t < r - p; t++) clamped += w[t];
+      acc = __builtin_fmaf(clamped, line[static_cast<int64_t>(p) * a.stride], acc);
+    }
+  }
+  if (m == n - 1) {  // ... onto the last
+    for (int p = max(0, n - r); p <= n - 1; p++) {
+      float clamped = 0.0f;
+      for (int t = n - p + r; t <= 2 * r; t++) clamped += w[t];
+      acc = __builtin_fmaf(clamped, line[static_cast<int64_t>(p) * a.stride], acc);
+    }
+  }
+  a.gx[e] = acc;
+}
+
+extern "C" int tio_separable_conv3d_adjoint(const float* gy, float* gx, float* tmp, int32_t batch, int32_t channels,
+                                            const int32_t shape[3], const float* taps_dev, int32_t taps_batched,
+                                            int32_t tap_stride, const int32_t radius[3], const uint8_t* skip_dev, void* stream) {
+  if (batch == 0) return TIO_OK;
+  if (gy == nullptr || gx == nullptr || shape == nullptr || radius == nullptr)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d_adjoint: null argument");
+  if (batch < 0 || channels < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d_adjoint: bad shape");
+  int n_active = 0;
+  for (int a = 0; a < 3; a++) {
+    if (radius[a] < 0 || 2 * radius[a] + 1 > tap_stride)
+      return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d_adjoint: radius[%d]=%d does not fit tap_stride=%d", a, radius[a], tap_stride);
+    if (radius[a] > 0) n_active++;
+  }
+  if (n_active > 0 && taps_dev == nullptr) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d_adjoint: null taps");
+  if (n_active > 1 && tmp == nullptr)
+    return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d_adjoint: tmp is required when more than one axis is active");
+  const int64_t n = static_cast<int64_t>(shape[0]) * shape[1] * shape[2];
+  const int64_t total = static_cast<int64_t>(batch) * channels * n;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_active == 0) {
+    if (hipMemcpyAsync(gx, gy, static_cast<size_t>(total) * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return fail(TIO_ERR_LAUNCH, "tio_separable_conv3d_adjoint: copy failed");
+    return TIO_OK;
+  }
+  if ((total + kBlock - 1) / kBlock > 0x7FFFFFFF) return fail(TIO_ERR_INVALID_ARGUMENT, "tio_separable_conv3d_adjoint: tensor too large");
+  // the forward pass runs I, J, K: the transposes run K, J, I; the last one writes gx
+  const float* src = gy;
+  int pass = 0;
+  for (int axis = 2; axis >= 0; axis--) {
+    if (radius[axis] <= 0) continue;
+    float* dst = ((n_active - 1 - pass) % 2 == 0) ? gx : tmp;
+    ConvAdjointArgs a;
+    a.gy = src; a.gx = dst; a.taps = taps_dev; a.skip = skip_dev;
+    a.n_spatial = n; a.n_total = total;
+    a.stride = axis == 0 ? static_cast<int64_t>(shape[1]) * shape[2] : (axis == 1 ? shape[2] : 1);
+    a.channels = channels; a.extent = shape[axis]; a.r = radius[axis]; a.axis = axis; a.tap_stride = tap_stride;
+    a.taps_batched = taps_batched; a.J = shape[1]; a.K = shape[2];
+    hipLaunchKernelGGL(conv_axis_adjoint_kernel, dim3(static_cast<unsigned>((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
+    src = dst;
+    pass++;
+  }
+  return check_launch("tio_separable_conv3d_adjoint");
+}
+
 extern "C" int tio_blur_fused(const void* x, void* y, void* tmp, int32_t dtype, int32_t batch, int32_t channels,
                               const int32_t shape[3], const float* taps_dev, int32_t taps_batched, int32_t tap_stride,
                               const int32_t radius[3], const float* bias_coarse_dev, const int32_t bias_coarse_shape[3],

@@ -846,40 +846,6 @@ class _PadConstantFn(torch.autograd.Function):
         return inner.contiguous(), grad_fill, None, None, None
 
 
-def _stencil_adjoint(data: Tensor, taps: Tensor, radius, skip: Tensor | None, grad: Tensor) -> Tensor:
-    """Backward of the replicate-padded separable correlation: autograd through its ATen restatement
-    (``F.pad(mode="replicate")`` + grouped ``conv3d`` per axis, reference blur.py:157-252).  The one backward that is
-    not a kernel of this library: the transpose of a CLAMPED stencil folds the border taps back onto the edge
-    voxels, and nobody trains through a Gaussian blur on the hot path."""
-    import torch.nn.functional as F  # noqa: PLC0415
-
-    batch, channels = data.shape[:2]
-    with torch.enable_grad():
-        leaf = data.float().requires_grad_(True)
-        work = leaf
-        for axis in range(3):
-            r = int(radius[axis])
-            if r <= 0:
-                continue
-            pad = [0, 0, 0, 0, 0, 0]
-            pad[2 * (2 - axis)] = pad[2 * (2 - axis) + 1] = r
-            padded = F.pad(work, pad, mode="replicate")
-            kernel = taps[:, axis, : 2 * r + 1].to(leaf.device, torch.float32)
-            shape = [1, 1, 1]
-            shape[axis] = 2 * r + 1
-            if kernel.shape[0] == 1:
-                weight = kernel.reshape(1, 1, *shape).expand(channels, 1, *shape)
-                work = F.conv3d(padded, weight, groups=channels)
-            else:  # per-element kernels: fold the batch into the channel groups
-                weight = kernel.reshape(batch, 1, 1, *shape).expand(batch, channels, 1, *shape).reshape(batch * channels, 1, *shape)
-                work = F.conv3d(padded.reshape(1, batch * channels, *padded.shape[2:]), weight, groups=batch * channels).reshape(batch, channels, *work.shape[2:])
-        if skip is not None:
-            rows = skip.to(leaf.device).bool().reshape(-1, 1, 1, 1, 1)
-            work = torch.where(rows, leaf, work)
-        (result,) = torch.autograd.grad(work, leaf, grad.float())
-    return result.to(data.dtype)
-
-
 def _wants_grad(tensor: Tensor | None) -> bool:
     return tensor is not None and torch.is_grad_enabled() and tensor.requires_grad
 
@@ -891,7 +857,7 @@ class Engine:
     of torch ops).  Here every op that has a derivative takes inputs that require grad, runs its kernel on the
     detached data and attaches a backward: the adjoint scatter kernel for trilinear resampling
     (``TIO_LINEAR_ADJOINT``), the same multiply for the bias field, the flip for the flip, closed-form tensor algebra
-    for gamma / noise, and — the one exception — the ATen restatement of the padded correlation for the stencil.
+    for gamma / noise, the transposed clamped stencil for the blur (``tio_separable_conv3d_adjoint``, round 6).
     Parameters (mapping, control points, sigmas ...) are plain numbers in the reference too and get no gradient.
     """
 
@@ -1208,7 +1174,7 @@ class Engine:
         if _wants_grad(data):
             detached = data.detach()
             result = self.separable_conv3d(detached, taps, radius, skip=skip)
-            return _AttachBackward.apply(data, result, lambda grad: _stencil_adjoint(detached, taps, radius, skip, grad))
+            return _AttachBackward.apply(data, result, lambda grad: self.separable_conv3d_adjoint(grad, taps, radius, skip=skip).to(data.dtype))
         batch, channels = data.shape[:2]
         data = data.contiguous()
         taps = taps.to(torch.float32).contiguous()
@@ -1225,6 +1191,30 @@ class Engine:
             "separable_conv3d", data, _ptr(data), _ptr(out), _ptr(tmp), dtype_code(data.dtype), batch, channels,
             _i32x3(data.shape[2:]), _ptr(taps), int(taps.shape[0] == batch and batch > 1), taps.shape[2],
             _i32x3(radius), _ptr(skip), self._stream(data),
+        )
+        return out
+
+    def separable_conv3d_adjoint(self, grad: Tensor, taps: Tensor, radius: Sequence[int], skip: Tensor | None = None) -> Tensor:
+        """Backward of ``separable_conv3d`` with respect to its data (``tio_separable_conv3d_adjoint``, ABI 16): the transposes
+        of the three replicate-padded correlations in reverse order, float32 — what autograd derives through the reference's
+        ``F.pad(mode="replicate")`` + grouped ``conv3d`` per axis (blur.py:157-252).  The transpose of a CLAMPED stencil folds the
+        taps that were clamped onto a border voxel back onto it; rows flagged in *skip* pass their gradient through."""
+        if grad.ndim != 5:
+            raise ValueError("expected a (B, C, I, J, K) gradient")
+        batch, channels = grad.shape[:2]
+        grad = grad.detach().to(torch.float32).contiguous()
+        taps = taps.to(device=grad.device, dtype=torch.float32).contiguous()
+        if taps.ndim != 3 or taps.shape[1] != 3 or taps.shape[0] not in (1, batch):
+            raise ValueError(f"taps must be (1|B, 3, stride), got {tuple(taps.shape)}")
+        skip = self._flags(skip, batch, "skip")
+        if skip is not None and skip.device != grad.device:
+            skip = skip.to(grad.device)
+        self._check("separable_conv3d_adjoint", grad, taps, skip)
+        out = torch.empty_like(grad)
+        tmp = torch.empty_like(grad) if sum(1 for r in radius if int(r) > 0) > 1 else None
+        self._call(
+            "separable_conv3d_adjoint", grad, _ptr(grad), _ptr(out), _ptr(tmp), batch, channels, _i32x3(grad.shape[2:]), _ptr(taps),
+            int(taps.shape[0] == batch and batch > 1), taps.shape[2], _i32x3(radius), _ptr(skip), self._stream(grad),
         )
         return out
 
@@ -1619,6 +1609,19 @@ class Engine:
 
 
 _ENGINE: Engine | None = None
+_HIP_ENGINE: Engine | None = None
+
+
+def hip_engine() -> Engine:
+    """The engine over ``libtio_hip.so`` whatever `engine()` currently hands out (the tests swap that one for the CPU oracle):
+    for callers that are bound to the HIP library themselves — the ``torch.ops.tio_hip`` custom ops' backward passes."""
+    global _HIP_ENGINE
+    if _HIP_ENGINE is None:
+        from . import _lib  # noqa: PLC0415
+
+        _, functions = _lib.load()
+        _HIP_ENGINE = Engine(functions, "cuda", "hip")
+    return _HIP_ENGINE
 
 
 def engine() -> Engine:

@@ -17,7 +17,7 @@ Round 3: the ops are full citizens of the dispatcher — **fake (meta) kernels**
 passes are registered with autograd** (``torch.library.register_autograd``) like the reference's compositions of torch
 ops are differentiable (reference tests/test_noise.py:75-80): the trilinear resampling through the adjoint launch
 (``resample3d_adjoint``), the bias field through the same multiply, noise through the identity (Rician: ``(x + n1) / y``),
-gamma through ``g |x|^(g-1)``, the stencil through the ATen restatement of the replicate-padded correlation.
+gamma through ``g |x|^(g-1)``, the stencil through its transposed kernel (``tio_separable_conv3d_adjoint``, round 6).
 """
 from __future__ import annotations
 
@@ -140,10 +140,11 @@ def _register_dispatcher_extras() -> None:
         ctx.radius, ctx.skip = list(radius), (inputs[3] if len(inputs) > 3 else None)
 
     def conv_backward(ctx, grad):
-        from .ops import _stencil_adjoint  # noqa: PLC0415
+        from . import ops  # noqa: PLC0415
 
-        x, taps = ctx.saved_tensors
-        return (_stencil_adjoint(x.detach(), taps.detach().cpu(), ctx.radius, ctx.skip, grad), *([None] * (ctx.n_inputs - 1)))
+        x, taps = ctx.saved_tensors  # (the transposed clamped stencil: tio_separable_conv3d_adjoint, ABI 16)
+        adjoint = ops.hip_engine().separable_conv3d_adjoint(grad, taps.detach(), ctx.radius, skip=ctx.skip)
+        return (adjoint.to(x.dtype), *([None] * (ctx.n_inputs - 1)))
 
     lib.register_autograd("tio_hip::separable_conv3d", conv_backward, setup_context=conv_setup)
 
