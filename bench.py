@@ -376,6 +376,10 @@ def compact(value, digits: int = 4):
 
 # wave64 vector instructions a SIMD issues per clock at best (SIMD-32: two cycles each — MI355X_MICROARCH.md), SIMDs, clock
 VALU_CYCLES_PER_INST, N_SIMDS, CLOCK_HZ = 2.0, 256 * 4, 2.4e9
+# ... and what tests/native/valu_rates.cpp measured on this chip with three to four resident waves per SIMD (cycles per wave64 instruction per
+# SIMD at the nominal clock, profiles/r01_valu_rates_w1-8.log): float32 add / mul / fma, and everything else (floor, conversions, integer
+# multiplies, min / max, compares, selects, moves, DPP)
+VALU_CYCLES_FAST_CLASS, VALU_CYCLES_OTHER = 2.9, 4.6
 
 
 def main() -> None:
@@ -478,6 +482,11 @@ def main() -> None:
             floor_ms = 1e3 * valu_insts * VALU_CYCLES_PER_INST / (N_SIMDS * CLOCK_HZ)
             valu = {"insts_per_voxel": valu_insts * 64 / (args.batch * args.size**3), "floor_ms": floor_ms,
                     "frac_of_issue": floor_ms / kernel_ms if kernel_ms else None}
+            fast_class = load_pmc(f"valu_fast_class_insts_per_launch_{precision}")  # (SQ_INSTS_VALU_ADD_F32 + MUL_F32 + FMA_F32)
+            if fast_class:
+                issue_ms = 1e3 * (fast_class * VALU_CYCLES_FAST_CLASS + (valu_insts - fast_class) * VALU_CYCLES_OTHER) / (N_SIMDS * CLOCK_HZ)
+                valu.update({"fast_class_share": fast_class / valu_insts, "issue_ms_at_measured_rates": issue_ms,
+                             "frac_at_measured_rates": issue_ms / kernel_ms if kernel_ms else None})
         roofline = {
             "kernel": "tio::resample_lean_exact_kernel<EXACT_LERP=%s> + plan_bricks_kernel (tio_resample3d: mean of the Affine and ElasticDeformation launches)"
                       % ("true" if precision == "exact" else "false"),
