@@ -149,7 +149,10 @@ __device__ __forceinline__ void lean_exact_coord(const float (&m)[12], const Lea
 __device__ __forceinline__ float row_bcast16(float v, int t) {  // (t is a literal after unrolling: the control word must be)
   const int b = __float_as_int(v);
   switch (t) {
-#define TIO_LE_BCAST(T) case T: return __int_as_float(__builtin_amdgcn_update_dpp(0, b, 0x150 + T, 0xF, 0xF, false));
+  // (`mov_dpp`, not `update_dpp(0, ..)`: every lane of the row is written, and with an explicit old value the compiler initialises the
+  // destination first — a `v_mov_b32 v, 0` (and often an `s_nop`) in front of EACH of the three to five broadcasts per plane, in the issue class of the
+  // move itself: 4.6 cycles apiece on this chip against 2.9 for a multiply-add)
+#define TIO_LE_BCAST(T) case T: return __int_as_float(__builtin_amdgcn_mov_dpp(b, 0x150 + T, 0xF, 0xF, false));
     TIO_LE_BCAST(0) TIO_LE_BCAST(1) TIO_LE_BCAST(2) TIO_LE_BCAST(3) TIO_LE_BCAST(4) TIO_LE_BCAST(5) TIO_LE_BCAST(6) TIO_LE_BCAST(7)
     TIO_LE_BCAST(8) TIO_LE_BCAST(9) TIO_LE_BCAST(10) TIO_LE_BCAST(11) TIO_LE_BCAST(12) TIO_LE_BCAST(13) TIO_LE_BCAST(14) TIO_LE_BCAST(15)
 #undef TIO_LE_BCAST
