@@ -210,9 +210,17 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
   // ... and which control planes plane t lerps between, as two bit masks per operand (bit t: the operand is control plane
   // ia + 1 or beyond / ia + 2): scalar compares on literals instead of two v_readlane per plane
   unsigned long long e0_ge1 = 0, e0_ge2 = 0, e1_ge1 = 0, e1_ge2 = 0;
+  unsigned changes = 0u;
   if constexpr (MODE != 0) {
     e0_ge1 = __builtin_amdgcn_ballot_w64(li_lane.i0 - ia >= 1); e0_ge2 = __builtin_amdgcn_ballot_w64(li_lane.i0 - ia >= 2);
     e1_ge1 = __builtin_amdgcn_ballot_w64(li_lane.i1 - ia >= 1); e1_ge2 = __builtin_amdgcn_ballot_w64(li_lane.i1 - ia >= 2);
+    // ... and at which planes either operand CHANGES (bit t: plane t lerps between other control planes than plane t - 1; bit 0: the
+    // first plane) — once or twice per brick.  One scalar bit test per plane decides whether the operands are looked at at all (the
+    // extraction of both operands' plane numbers and their two compares cost ten scalar instructions per plane, and a wave issues its
+    // scalar and its vector instructions in order)
+    const unsigned g01 = static_cast<unsigned>(e0_ge1) & 0xFFFFu, g02 = static_cast<unsigned>(e0_ge2) & 0xFFFFu;
+    const unsigned g11 = static_cast<unsigned>(e1_ge1) & 0xFFFFu, g12 = static_cast<unsigned>(e1_ge2) & 0xFFFFu;
+    changes = ((g01 ^ (g01 << 1)) | (g02 ^ (g02 << 1)) | (g11 ^ (g11 << 1)) | (g12 ^ (g12 << 1)) | 1u) & 0xFFFFu;
   }
 #pragma unroll
   for (int t = 0; t < 16; t++) {
@@ -227,24 +235,26 @@ __device__ __forceinline__ void lean_exact_planes(const float (&m)[12], const Le
     if constexpr (MODE != 0) {
       // the two control planes a voxel lerps between change once or twice per brick: named registers that a SCALAR branch
       // refreshes (resample_tile.hpp: indexing by the plane number costs an s_set_gpr_idx sequence per access)
-      const int e0 = static_cast<int>((e0_ge1 >> t) & 1ull) + static_cast<int>((e0_ge2 >> t) & 1ull);
-      const int e1 = static_cast<int>((e1_ge1 >> t) & 1ull) + static_cast<int>((e1_ge2 >> t) & 1ull);
       const float l0 = row_bcast16(li_lane.l0, t), l1 = row_bcast16(li_lane.l1, t);
-      // (ONE rarely taken scalar branch per operand plane, branch-free selects inside: the nested if / else form compiled into
-      // ~45 scalar instructions per plane — and a CU has one scalar unit for its twelve resident waves)
-      if (e0 != cur0) {
-        const bool z0 = e0 == 0, z1 = e0 == 1;
-        pa_i = z0 ? P.a_i : (z1 ? P.b_i : P.c_i);
-        pa_j = z0 ? P.a_j : (z1 ? P.b_j : P.c_j);
-        pa_k = z0 ? P.a_k : (z1 ? P.b_k : P.c_k);
-        cur0 = e0;
-      }
-      if (e1 != cur1) {
-        const bool z0 = e1 == 0, z1 = e1 == 1;
-        pb_i = z0 ? P.a_i : (z1 ? P.b_i : P.c_i);
-        pb_j = z0 ? P.a_j : (z1 ? P.b_j : P.c_j);
-        pb_k = z0 ? P.a_k : (z1 ? P.b_k : P.c_k);
-        cur1 = e1;
+      if ((changes >> t) & 1u) {  // (rarely taken; bit 0 is always set: the first plane loads both operands)
+        const int e0 = static_cast<int>((e0_ge1 >> t) & 1ull) + static_cast<int>((e0_ge2 >> t) & 1ull);
+        const int e1 = static_cast<int>((e1_ge1 >> t) & 1ull) + static_cast<int>((e1_ge2 >> t) & 1ull);
+        // (ONE rarely taken scalar branch per operand plane, branch-free selects inside: the nested if / else form compiled into
+        // ~45 scalar instructions per plane — and a CU has one scalar unit for its twelve resident waves)
+        if (e0 != cur0) {
+          const bool z0 = e0 == 0, z1 = e0 == 1;
+          pa_i = z0 ? P.a_i : (z1 ? P.b_i : P.c_i);
+          pa_j = z0 ? P.a_j : (z1 ? P.b_j : P.c_j);
+          pa_k = z0 ? P.a_k : (z1 ? P.b_k : P.c_k);
+          cur0 = e0;
+        }
+        if (e1 != cur1) {
+          const bool z0 = e1 == 0, z1 = e1 == 1;
+          pb_i = z0 ? P.a_i : (z1 ? P.b_i : P.c_i);
+          pb_j = z0 ? P.a_j : (z1 ? P.b_j : P.c_j);
+          pb_k = z0 ? P.a_k : (z1 ? P.b_k : P.c_k);
+          cur1 = e1;
+        }
       }
       di = lerp2(pa_i, l0, pb_i, l1);
       dj = lerp2(pa_j, l0, pb_j, l1);
